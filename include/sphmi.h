@@ -1,0 +1,175 @@
+/*
+ * sphmi.h — C ABI of the MI355X-native SPH neighbour + force engine (libsphmi.so).
+ *
+ * This is the drop-in boundary for the hot path of AhmedSalih3d/SPHExample: one call to
+ * sphmi_advance() replaces one call to the reference's
+ *     SimulationLoop(...)                      src/SPHCellList.jl:727-805 (called at :883)
+ * i.e. "advance the particle system until TotalTime > next_output_time", including the
+ * cell-list rebuild (UpdateNeighbors!, :138-163), both neighbour passes
+ * (NeighborLoop!/ComputeInteractions!, :168-217 / :268-317), mDBC (:219-266, :319-365, :598-622),
+ * the predictor / corrector (HalfTimeStep :624-638, FullTimeStep :640-652, DensityEpsi!,
+ * LimitDensityAtBoundary!, Pressure!  src/SimulationEquations.jl:9-42) and the adaptive time step
+ * (src/TimeStepping.jl:24-46, update_delta_x! src/SPHCellList.jl:706-724).
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions cross the boundary; every function returns an int
+ *     status (SPHMI_OK == 0) and sphmi_last_error() gives the text of the last failure.
+ *   - the caller owns every host array it passes; pointers only need to stay valid for the
+ *     duration of the call (Julia: GC.@preserve around the ccall).  The engine owns all device
+ *     memory behind the opaque handle.
+ *   - vector fields cross the boundary exactly as Julia lays out Vector{SVector{D,T}}:
+ *     contiguous AoS, D components interleaved, N*D scalars.
+ *   - host scalars are `host_float_bytes` wide (8 for every stock example), device arithmetic is
+ *     `device_float_bytes` wide (4 = fp32 kernels, 8 = fp64 kernels); conversion happens in
+ *     upload/download.
+ *   - the library installs no signal handlers and never calls back into the host runtime.
+ *   - one handle = one simulation = one GPU; a handle must not be used from two threads at once.
+ */
+#ifndef SPHMI_H
+#define SPHMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHMI_ABI_VERSION 1
+
+/* status codes */
+enum {
+    SPHMI_OK              = 0,
+    SPHMI_ERR_ARGUMENT    = 1,  /* bad config / null pointer / unsupported model tag          */
+    SPHMI_ERR_DEVICE      = 2,  /* HIP runtime failure (text in sphmi_last_error)              */
+    SPHMI_ERR_NUMERIC     = 3,  /* NaN / non-positive dt produced by the time-step criterion   */
+    SPHMI_ERR_DOMAIN      = 4,  /* bounding cell grid exceeds the configured cell budget       */
+    SPHMI_ERR_STATE       = 5   /* call sequence error (e.g. advance before upload)            */
+};
+
+/* model tags; values mirror the reference's dispatch types */
+enum { SPHMI_KERNEL_WENDLAND_C2 = 0 };                      /* src/SPHKernels.jl:13,75-87        */
+enum { SPHMI_VISC_ZERO = 0, SPHMI_VISC_ARTIFICIAL = 1 };    /* src/SPHViscosityModels.jl:51-74   */
+enum { SPHMI_DDT_NONE = 0, SPHMI_DDT_LINEAR = 2 };          /* src/SPHDensityDiffusionModels.jl:100-136 */
+enum { SPHMI_MDBC_NONE = 0, SPHMI_MDBC_SIMPLE = 1 };        /* src/SimulationMetaDataConfiguration.jl:20-22 */
+/* ParticleType values, src/SimulationGeometry.jl:10-14 */
+enum { SPHMI_FLUID = 1, SPHMI_FIXED = 2, SPHMI_MOVING = 3 };
+
+/*
+ * Parameter block = the fields of SimulationConstants (src/SimulationConstantsConfiguration.jl:36-52)
+ * and SPHKernelInstance (src/SPHKernels.jl:30-72) passed by value, plus the type parameters of
+ * SimulationMetaData{D,T,SMode,KMode,BMode,LMode} (src/SimulationMetaDataConfiguration.jl:28-33)
+ * and the model tag types as enums.
+ */
+typedef struct sphmi_config {
+    int32_t struct_size;         /* = sizeof(sphmi_config); ABI guard                            */
+    int32_t abi_version;         /* = SPHMI_ABI_VERSION                                          */
+    int32_t dims;                /* Dimensions: 2 or 3                                           */
+    int32_t host_float_bytes;    /* FloatType of the host arrays: 4 or 8                         */
+    int32_t device_float_bytes;  /* arithmetic type of the kernels: 4 or 8                       */
+    int32_t kernel;              /* SPHMI_KERNEL_*                                               */
+    int32_t viscosity;           /* SPHMI_VISC_*                                                 */
+    int32_t density_diffusion;   /* SPHMI_DDT_*                                                  */
+    int32_t mdbc;                /* SPHMI_MDBC_*                                                 */
+    int32_t device;              /* HIP device ordinal                                           */
+    int32_t reserved0;
+    int32_t reserved1;
+    int64_t n_particles;         /* length(SimParticles)                                         */
+    int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
+    /* SimulationConstants */
+    double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;
+    /* SPHKernelInstance */
+    double k, h, h_inv, H, H_inv, H2, alphaD, eta2;
+} sphmi_config;
+
+/* What the reference's SimulationLoop leaves in SimMetaData (src/SPHCellList.jl:679-685,:759). */
+typedef struct sphmi_progress {
+    int64_t iteration;        /* SimMetaData.Iteration                                            */
+    int64_t steps_done;       /* steps executed by this call                                      */
+    int64_t n_rebuilds;       /* UpdateNeighbors! executions since create                         */
+    int64_t index_counter;    /* SimMetaData.IndexCounter = 1 + number of occupied cells          */
+    double  total_time;       /* SimMetaData.TotalTime                                            */
+    double  last_dt;          /* SimMetaData.CurrentTimeStep                                      */
+    double  delta_x;          /* the loop-local Δx accumulator (src/SPHCellList.jl:739,744,760)   */
+} sphmi_progress;
+
+typedef struct sphmi_handle sphmi_handle;
+
+/* Library identification: "sphmi <abi> hip gfx950 ..." — static string. */
+const char* sphmi_backend_info(void);
+
+/* Text of the last error on this handle (or of the last failed sphmi_create when h == NULL). */
+const char* sphmi_last_error(const sphmi_handle* h);
+
+/* Allocate device state for cfg->n_particles particles.  Replaces the allocations at
+ * src/SPHCellList.jl:825,837,840-844 (support arrays, per-thread copies, ParticleRanges,
+ * UniqueCells, CellDict, sort scratch). */
+int sphmi_create(const sphmi_config* cfg, sphmi_handle** out);
+int sphmi_destroy(sphmi_handle* h);
+
+/*
+ * Copy the SimParticles fields the hot path reads (src/PreProcess.jl:114) to the device.
+ * position / velocity / acceleration / ghost_points: N*D host floats (AoS); density: N host floats;
+ * type: N ParticleType bytes; id: N Int64; group_marker: N UInt64 (may be NULL);
+ * ghost_points may be NULL when mdbc == SPHMI_MDBC_NONE.  GravityFactor / MotionLimiter are
+ * derived from `type` exactly as src/PreProcess.jl:78-98 does.
+ * Also resets Positionₙ⁺ to zero as AllocateSupportDataStructures does (src/PreProcess.jl:131).
+ */
+int sphmi_upload(sphmi_handle* h,
+                 const void* position, const void* velocity, const void* acceleration,
+                 const void* density, const uint8_t* type, const int64_t* id,
+                 const uint64_t* group_marker, const void* ghost_points);
+
+/* Set / read SimMetaData.Iteration and SimMetaData.TotalTime (they live in the host struct). */
+int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
+
+/*
+ * One SimulationLoop call (src/SPHCellList.jl:727-805): reset Δx = 1 + h, then step
+ * `while TotalTime <= t_target`.  max_steps < 0 means unbounded; otherwise the loop also stops
+ * after max_steps steps (used by tests and by the benchmark's fixed-step window).
+ */
+int sphmi_advance(sphmi_handle* h, double t_target, int64_t max_steps, sphmi_progress* out);
+
+/*
+ * Copy particle state back in the engine's current (cell-sorted) order — the same order the
+ * reference leaves SimParticles in, because its sort! permutes every field (src/SPHCellList.jl:142).
+ * Any pointer may be NULL to skip that field.  cells: N*D Int64 (Particles.Cells).
+ */
+int sphmi_download(sphmi_handle* h,
+                   void* position, void* velocity, void* acceleration,
+                   void* density, void* pressure,
+                   int64_t* id, uint8_t* type, uint64_t* group_marker,
+                   void* ghost_points, int64_t* cells);
+
+/*
+ * Parity hook: rebuild the cell list for the current positions, run Pressure! and ONE
+ * NeighborLoop!+ReductionStep! (src/SPHCellList.jl:771,774-775) on the current state and return
+ * dρdtI (N) and Acceleration (N*D, no gravity) in cell-sorted order; also sorts the particles
+ * (as UpdateNeighbors! does) but does not advance time.  apply_mdbc != 0 additionally runs
+ * ApplyMDBCBeforeHalf! (:772) between Pressure! and the pair loop.
+ */
+int sphmi_forces_once(sphmi_handle* h, int apply_mdbc, void* drhodt, void* acceleration);
+
+/* Occupied cells in sort order: cells_out receives (index_counter-1)*D Int64 values
+ * (UniqueCells[2:IndexCounter], src/SPHCellList.jl:148-157); n_out the count. */
+int sphmi_unique_cells(sphmi_handle* h, int64_t* cells_out, int64_t capacity, int64_t* n_out);
+
+/*
+ * Per-phase device seconds accumulated since create, under the reference's TimerOutputs labels
+ * (src/SPHCellList.jl:748-800).  names_out receives pointers to static strings.
+ */
+int sphmi_timers(sphmi_handle* h, int32_t capacity, const char** names_out, double* seconds_out,
+                 int64_t* calls_out, int32_t* n_out);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------- */
+/* Average duration in ms (HIP events on the engine's stream) of the neighbour+force kernel over the
+ * launches since the last reset, and the number of launches. */
+int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
+
+/* ---- domain-decomposition hooks (one process per GPU) --------- */
+/* Raw device pointers of the packed neighbour stream so the host can post halo send/recv on them. */
+int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHMI_H */

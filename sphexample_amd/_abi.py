@@ -1,0 +1,192 @@
+"""ctypes view of include/sphmi.h (structs + a thin call-marshalling base class).
+
+``SphmiConfig`` / ``SphmiProgress`` must stay field-for-field identical to the C structs;
+``tests/test_abi.py`` cross-checks the sizes against the compiled library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from .config import (NoMDBC, SimpleMDBC, SimulationConstants, SimulationMetaData, SPHDensityDiffusion,
+                     SPHKernelInstance, SPHViscosity)
+
+ABI_VERSION = 1
+
+OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NUMERIC, ERR_DOMAIN, ERR_STATE = range(6)
+
+
+class SphmiConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("abi_version", C.c_int32), ("dims", C.c_int32),
+        ("host_float_bytes", C.c_int32), ("device_float_bytes", C.c_int32), ("kernel", C.c_int32),
+        ("viscosity", C.c_int32), ("density_diffusion", C.c_int32), ("mdbc", C.c_int32),
+        ("device", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("n_particles", C.c_int64), ("max_cells", C.c_int64),
+        ("rho0", C.c_double), ("dx", C.c_double), ("m0", C.c_double), ("alpha", C.c_double),
+        ("g", C.c_double), ("c0", C.c_double), ("gamma", C.c_double), ("delta_phi", C.c_double),
+        ("CFL", C.c_double), ("Cb", C.c_double), ("nu0", C.c_double),
+        ("k", C.c_double), ("h", C.c_double), ("h_inv", C.c_double), ("H", C.c_double),
+        ("H_inv", C.c_double), ("H2", C.c_double), ("alphaD", C.c_double), ("eta2", C.c_double),
+    ]
+
+
+class SphmiProgress(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int64), ("steps_done", C.c_int64), ("n_rebuilds", C.c_int64),
+        ("index_counter", C.c_int64), ("total_time", C.c_double), ("last_dt", C.c_double),
+        ("delta_x", C.c_double),
+    ]
+
+
+class SphmiError(RuntimeError):
+    def __init__(self, status: int, text: str):
+        super().__init__(f"sphmi status {status}: {text}")
+        self.status = status
+
+
+def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: SPHKernelInstance,
+                SimMetaData: SimulationMetaData, SimViscosity: SPHViscosity,
+                SimDensityDiffusion: SPHDensityDiffusion, *, device_float_bytes: int = 4,
+                host_float_bytes: int = 8, device: int = 0, max_cells: int = 0) -> SphmiConfig:
+    """Flatten the reference's configuration objects into the C parameter block.
+
+    Model tags the engine does not implement raise here, which is where the Julia shim falls back
+    to the stock CPU path."""
+    for tag, what in ((SimViscosity, "viscosity"), (SimDensityDiffusion, "density diffusion")):
+        if getattr(tag, "abi_value", None) is None:
+            raise NotImplementedError(f"{type(tag).__name__}: {what} model not implemented by the engine")
+    if SimMetaData.SMode.__name__ != "NoShifting" or SimMetaData.KMode.__name__ != "NoKernelOutput":
+        raise NotImplementedError("PlanarShifting / StoreKernelOutput are not implemented by the engine")
+    c = SphmiConfig()
+    c.struct_size = C.sizeof(SphmiConfig)
+    c.abi_version = ABI_VERSION
+    c.dims = SimMetaData.Dimensions
+    c.host_float_bytes = host_float_bytes
+    c.device_float_bytes = device_float_bytes
+    c.kernel = SimKernel.kernel.abi_value
+    c.viscosity = SimViscosity.abi_value
+    c.density_diffusion = SimDensityDiffusion.abi_value
+    c.mdbc = 1 if SimMetaData.BMode is SimpleMDBC else 0
+    c.device = device
+    c.n_particles = n_particles
+    c.max_cells = max_cells
+    for k in ("rho0", "dx", "m0", "alpha", "g", "c0", "gamma", "delta_phi", "CFL", "Cb", "nu0"):
+        setattr(c, k, getattr(SimConstants, k))
+    for k in ("k", "h", "h_inv", "H", "H_inv", "H2", "alphaD", "eta2"):
+        setattr(c, k, getattr(SimKernel, k))
+    return c
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Backend:
+    """Call marshalling shared by the HIP engine binding and (in tests) the oracle binding.
+
+    A backend is `lib` + symbol `prefix`; every entry point has the signature declared in
+    include/sphmi.h."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, cfg: SphmiConfig):
+        self._lib, self._p = lib, prefix
+        self.cfg = cfg
+        self.N, self.D = int(cfg.n_particles), int(cfg.dims)
+        self._ft = np.float64 if cfg.host_float_bytes == 8 else np.float32
+        f = self._fn
+        f("last_error").restype = C.c_char_p
+        f("last_error").argtypes = [C.c_void_p]
+        self._h = C.c_void_p()
+        f("create").argtypes = [C.POINTER(SphmiConfig), C.POINTER(C.c_void_p)]
+        rc = f("create")(C.byref(cfg), C.byref(self._h))
+        if rc != OK:
+            raise SphmiError(rc, (f("last_error")(None) or b"").decode())
+        f("destroy").argtypes = [C.c_void_p]
+        f("upload").argtypes = [C.c_void_p] * 9
+        f("set_clock").argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        f("advance").argtypes = [C.c_void_p, C.c_double, C.c_int64, C.POINTER(SphmiProgress)]
+        f("download").argtypes = [C.c_void_p] * 11
+        f("forces_once").argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        f("unique_cells").argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise SphmiError(rc, (self._fn("last_error")(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self._fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data movement ----------------------------------------------------------------------
+    def _f(self, a, shape):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=self._ft)
+        assert a.shape == shape, (a.shape, shape)
+        return a
+
+    def upload(self, Position, Velocity, Acceleration, Density, Type, ID, GroupMarker=None,
+               GhostPoints=None):
+        N, D = self.N, self.D
+        keep = [self._f(Position, (N, D)), self._f(Velocity, (N, D)), self._f(Acceleration, (N, D)),
+                self._f(Density, (N,)), np.ascontiguousarray(Type, dtype=np.uint8),
+                np.ascontiguousarray(ID, dtype=np.int64),
+                None if GroupMarker is None else np.ascontiguousarray(GroupMarker, dtype=np.uint64),
+                self._f(GhostPoints, (N, D))]
+        self._check(self._fn("upload")(self._h, *[_ptr(a) for a in keep]))
+
+    def upload_particles(self, p):
+        self.upload(p.Position, p.Velocity, p.Acceleration, p.Density, p.Type, p.ID, p.GroupMarker,
+                    p.GhostPoints if self.cfg.mdbc else None)
+
+    def set_clock(self, iteration: int, total_time: float):
+        self._check(self._fn("set_clock")(self._h, iteration, total_time))
+
+    def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
+        prog = SphmiProgress()
+        self._check(self._fn("advance")(self._h, t_target, max_steps, C.byref(prog)))
+        return prog
+
+    def download(self, fields=("Position", "Velocity", "Acceleration", "Density", "Pressure", "ID",
+                               "Type", "GroupMarker", "GhostPoints", "Cells")) -> dict:
+        N, D = self.N, self.D
+        spec = {
+            "Position": ((N, D), self._ft), "Velocity": ((N, D), self._ft),
+            "Acceleration": ((N, D), self._ft), "Density": ((N,), self._ft),
+            "Pressure": ((N,), self._ft), "ID": ((N,), np.int64), "Type": ((N,), np.uint8),
+            "GroupMarker": ((N,), np.uint64), "GhostPoints": ((N, D), self._ft),
+            "Cells": ((N, D), np.int64),
+        }
+        out = {k: (np.empty(*spec[k]) if k in fields else None) for k in spec}
+        self._check(self._fn("download")(self._h, *[_ptr(out[k]) for k in spec]))
+        return {k: v for k, v in out.items() if v is not None}
+
+    def download_into(self, p) -> None:
+        """Write the engine state back into a SimParticles (what the reference's in-place loop leaves)."""
+        for k, v in self.download().items():
+            setattr(p, k, v)
+
+    def forces_once(self, apply_mdbc: bool = False):
+        drho = np.empty(self.N, dtype=self._ft)
+        acc = np.empty((self.N, self.D), dtype=self._ft)
+        self._check(self._fn("forces_once")(self._h, int(apply_mdbc), _ptr(drho), _ptr(acc)))
+        return drho, acc
+
+    def unique_cells(self) -> np.ndarray:
+        n = C.c_int64()
+        self._check(self._fn("unique_cells")(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, self.D), dtype=np.int64)
+        self._check(self._fn("unique_cells")(self._h, _ptr(out), n.value, C.byref(n)))
+        return out

@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+INPUT = os.path.join(GOLDEN, "input")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _geoms(dims, bound, fluid):
+    from sphexample_amd import Fixed, Fluid, Geometry
+    return [Geometry(CSVFile=os.path.join(INPUT, bound), GroupMarker=1, Type=Fixed, Dimensions=dims),
+            Geometry(CSVFile=os.path.join(INPUT, fluid), GroupMarker=2, Type=Fluid, Dimensions=dims)]
+
+
+def load_dam_break_2d():
+    from sphexample_amd import AllocateDataStructures
+    from sphexample_amd.cases import setup_dam_break_2d
+    return AllocateDataStructures(_geoms(2, "DamBreak2d_Dp0.02_Bound.csv", "DamBreak2d_Dp0.02_Fluid.csv")), setup_dam_break_2d()
+
+
+def load_still_wedge():
+    from sphexample_amd import AllocateDataStructures, LoadMDBCNormals
+    from sphexample_amd.cases import setup_still_wedge_mdbc
+    p = AllocateDataStructures(_geoms(2, "StillWedge_Dp0.02_Bound.csv", "StillWedge_Dp0.02_Fluid.csv"))
+    LoadMDBCNormals(p, os.path.join(INPUT, "StillWedge_Dp0.02_GhostNodes_Correct.csv"))
+    return p, setup_still_wedge_mdbc()
+
+
+def load_dam_break_3d_shipped():
+    from sphexample_amd import AllocateDataStructures
+    from sphexample_amd.cases import setup_dam_break_3d
+    return AllocateDataStructures(_geoms(3, "DamBreak3d_Dp0.02_Bound.csv.gz", "DamBreak3d_Dp0.02_Fluid.csv.gz")), setup_dam_break_3d(0.02)
+
+
+@pytest.fixture(scope="session")
+def dam_break_2d():
+    return load_dam_break_2d()
+
+
+@pytest.fixture(scope="session")
+def still_wedge():
+    return load_still_wedge()
+
+
+@pytest.fixture(scope="session")
+def dam_break_3d_shipped():
+    return load_dam_break_3d_shipped()
+
+
+def perturbed(p, seed=0, vel_scale=0.3, rho_scale=2.0, pos_scale=0.0):
+    """Deterministic non-trivial state: random velocities / density offsets on top of a layout."""
+    rng = np.random.default_rng(seed)
+    q = p.copy()
+    fluid = q.Type == 1
+    q.Velocity[fluid] = rng.uniform(-vel_scale, vel_scale, size=q.Velocity[fluid].shape)
+    q.Density = q.Density + rng.uniform(0, rho_scale, size=q.Density.shape)
+    if pos_scale:
+        q.Position[fluid] += rng.uniform(-pos_scale, pos_scale, size=q.Position[fluid].shape)
+    return q
