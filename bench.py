@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py — particle-updates/s of the SPH hot path on the 3-D dam break (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W                        (N = 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full time step of the hot path (cell-list upkeep + both neighbour passes with the
+fused predictor / corrector + the Δt/Δx reductions) over every particle.  Inputs are generated on the
+host and uploaded BEFORE the timed region; the timed region is exactly K steps bracketed by a barrier +
+torch.cuda.synchronize() on both sides; the reported time is the max over ranks.
+
+Workload: BASELINE config 3 — synthetic 3-D dam break at dp = 0.00425 (≈1.06 M particles), fp32
+kernels, parameters of example/Dambreak3d.jl.  For N > 1 the lattice is refined so that every GPU keeps
+≈1.06 M particles (weak scaling; N = 8 is BASELINE config 4, dp = 0.002125, ≈7.7 M particles).
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel (k_neighbor_force): ALGORITHMIC bytes per launch ÷ its average launch
+                 duration (HIP events on the engine's stream) against the 8 TB/s HBM peak.
+                 Algorithmic bytes: (11·D+5)·4+2 = 154 B per particle-update = 77 B per
+                 particle per launch (two launches per update).  The kernel is VALU-bound by design
+                 (≈1.1 k distance tests + ≈174 pair evaluations per particle per launch), so `frac` is
+                 small; `valu` reports the companion figure against the fp32 vector peak.
+  cpu_baseline — the CPU oracle (OpenMP restatement of the reference algorithm, fp64, "port") timed on
+                 this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: peak FP32 vector
+BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
+FLOP_PER_UPDATE_3D = 4.5e4       # SURVEY.md §8d estimate (2 passes × (≈1120 × 8 + ≈174 × 78))
+
+
+def cpu_baseline(dp=0.0085, steps=24):
+    """Bounded CPU sample: same case at dp = 0.0085 (the reference example's own resolution,
+    ≈159 k particles), `steps` steps after a 2-step warm-up, all host cores."""
+    from oracle.oracle import Oracle, make_oracle
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    cores = os.cpu_count() or 1
+    threads = min(cores, Oracle.max_threads())
+    p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
+    o = make_oracle(p, s, threads=threads)
+    o.advance(1e9, max_steps=2)
+    t0 = time.perf_counter()
+    pr = o.advance(1e9, max_steps=steps)
+    dt = time.perf_counter() - t0
+    return {"value": len(p) * pr.steps_done / dt, "unit": "particle-updates/s", "cores": threads,
+            "kind": "port",
+            "sample": f"3-D dam break dp={dp} (N={len(p)}), {pr.steps_done} steps, fp64 OpenMP restatement "
+                      f"of the reference algorithm (oracle/sph_oracle.c), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dp", type=float, default=None, help="override lattice spacing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libsphmi has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    dp1 = 0.00425
+    dp = args.dp or dp1 / (world ** (1.0 / 3.0))
+    setup = setup_dam_break_3d(dp)
+
+    if world == 1:
+        from sphexample_amd.engine import make_engine
+        particles = dam_break_3d(dp)
+        n_total = len(particles)
+        eng = make_engine(particles, setup, device_float_bytes=4, device=local_rank)
+        barrier = lambda: None  # noqa: E731
+        reduce_max = lambda x: x  # noqa: E731
+    else:
+        import torch.distributed as dist
+        from sphexample_amd.distributed import make_distributed_engine
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        eng, n_total = make_distributed_engine(dp, setup, rank, world, local_rank)
+        barrier = dist.barrier
+
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+    eng.advance(1e9, max_steps=args.warmup)
+    eng.force_kernel_stats(reset=True)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prog = eng.advance(1e9, max_steps=args.steps)
+    torch.cuda.synchronize(); barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    assert prog.steps_done == args.steps
+    kern_ms, kern_launches = eng.force_kernel_stats()
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        n_local = n_total / world
+        alg_bytes_launch = BYTES_PER_UPDATE_3D_FP32 / 2.0 * n_local
+        achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "particle-updates/sec (3D dam-break)", "value": value, "unit": "particle-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D dam-break dp={dp:.6g}, N={n_total} particles, "
+                                   f"example/Dambreak3d.jl parameters, fp32 kernels",
+                       "particles": n_total, "particles_per_gpu": n_local,
+                       "parallelism": "single GPU" if world == 1 else f"x-slab domain decomposition x{world}, 1-cell halo",
+                       "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "valu": {"achieved_tflops": FLOP_PER_UPDATE_3D / 2.0 * n_local / (kern_ms * 1e-3) / 1e12
+                                  if kern_ms > 0 else 0.0, "peak_tflops": FP32_PEAK_TFLOPS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

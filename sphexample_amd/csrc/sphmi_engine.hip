@@ -1,0 +1,619 @@
+// sphmi_engine.hip — host side of libsphmi.so: device state, the per-step launch sequence that
+// replaces the reference's SimulationLoop (src/SPHCellList.jl:727-805) and the C ABI of
+// include/sphmi.h.  gfx950 only; no CPU fallback: every entry point fails with SPHMI_ERR_DEVICE when
+// HIP reports no usable device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sphmi.h"
+#include "sphmi_kernels.h"
+#include "sphmi_rebuild.h"
+
+namespace sphmi {
+
+struct EngineError : std::runtime_error {
+    int status;
+    EngineError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+#define HC(expr)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            throw EngineError(SPHMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static thread_local std::string g_create_error;
+
+// Phase labels follow the reference's TimerOutputs sections (src/SPHCellList.jl:748-800).
+enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT };
+static const char* kPhaseNames[PH_COUNT] = {
+    "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
+    "05 First NeighborLoop (+06/07 half step)", "08 Second NeighborLoop (+09/10/11 full step)"};
+
+struct EngineBase {
+    sphmi_config cfg{};
+    std::string err;
+    int64_t iteration = 0, n_rebuilds = 0, index_counter = 0;
+    double total_time = 0, last_dt = 0, delta_x = 0;
+    bool uploaded = false;
+    virtual ~EngineBase() {}
+    virtual void upload(const void*, const void*, const void*, const void*, const uint8_t*, const int64_t*,
+                        const uint64_t*, const void*) = 0;
+    virtual void advance(double t_target, int64_t max_steps, sphmi_progress* out) = 0;
+    virtual void download(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
+    virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
+    virtual void unique_cells(int64_t* out, int64_t cap, int64_t* n) = 0;
+    virtual void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) = 0;
+    virtual void force_stats(int reset, double* avg_ms, int64_t* launches) = 0;
+    virtual void device_ptrs(void** pk0, void** pk1, int64_t* n) = 0;
+};
+
+template <class T>
+struct Engine final : EngineBase {
+    using V4 = typename Vec4<T>::type;
+    int N = 0, D = 0;
+    hipStream_t stream = nullptr;
+    // state sets: 0..2 rotate through the roles A (state n), H (half step), B (state n+1 / permute target)
+    V4 *pk0[3] = {}, *pk1[3] = {};
+    int iA = 0, iH = 1, iB = 2;
+    V4 *acc[2] = {}, *ghost[2] = {};
+    uint8_t* type[2] = {};
+    long long* id[2] = {};
+    unsigned long long* grp[2] = {};
+    int* key[2] = {};
+    int cur = 0;                       // which of the [2] copies is live
+    int *slot = nullptr, *tmp_idx = nullptr, *perm = nullptr;
+    int *count = nullptr, *cstart = nullptr, *tsum = nullptr;
+    int64_t cell_cap = 0;
+    int *bbox_d = nullptr, *misc_d = nullptr;              // misc: [0] nonempty, [1] scan total
+    unsigned long long* red_d = nullptr;
+    int *bbox_h = nullptr, *misc_h = nullptr;
+    unsigned long long* red_h = nullptr;
+    GridDesc grid{};
+    bool have_grid = false, stepped = false, nonempty_pending = false;
+    // timing
+    struct Ev { hipEvent_t a, b; int phase; };
+    std::vector<Ev> ev_pool, ev_pending;
+    double ph_secs[PH_COUNT] = {};
+    int64_t ph_calls[PH_COUNT] = {};
+    double force_ms = 0; int64_t force_launches = 0;
+
+    explicit Engine(const sphmi_config& c) {
+        cfg = c;
+        N = (int)c.n_particles;
+        D = c.dims;
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            throw EngineError(SPHMI_ERR_DEVICE, "no HIP device available (libsphmi has no CPU fallback)");
+        if (c.device < 0 || c.device >= ndev) throw EngineError(SPHMI_ERR_ARGUMENT, "device ordinal out of range");
+        HC(hipSetDevice(c.device));
+        HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        const size_t n = (size_t)N;
+        for (int k = 0; k < 3; ++k) { HC(hipMalloc(&pk0[k], n * sizeof(V4))); HC(hipMalloc(&pk1[k], n * sizeof(V4))); }
+        for (int k = 0; k < 2; ++k) {
+            HC(hipMalloc(&acc[k], n * sizeof(V4)));
+            HC(hipMalloc(&ghost[k], n * sizeof(V4)));
+            HC(hipMalloc(&type[k], n));
+            HC(hipMalloc(&id[k], n * 8));
+            HC(hipMalloc(&grp[k], n * 8));
+            HC(hipMalloc(&key[k], n * 4));
+        }
+        HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
+        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 4 * 8));
+        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
+    }
+    ~Engine() override {
+        (void)hipSetDevice(cfg.device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& e : ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto& e : ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (int k = 0; k < 3; ++k) { (void)hipFree(pk0[k]); (void)hipFree(pk1[k]); }
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]);
+            (void)hipFree(grp[k]); (void)hipFree(key[k]);
+        }
+        (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
+        (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
+        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
+        (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    // ---- timing helpers ---------------------------------------------------------------------
+    Ev begin_phase(int phase) {
+        Ev e;
+        if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); }
+        else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
+        e.phase = phase;
+        HC(hipEventRecord(e.a, stream));
+        return e;
+    }
+    void end_phase(Ev e) { HC(hipEventRecord(e.b, stream)); ev_pending.push_back(e); }
+    void collect_events() {   // call only after a stream sync
+        for (auto& e : ev_pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                ph_secs[e.phase] += ms * 1e-3;
+                ph_calls[e.phase] += 1;
+                if (e.phase == PH_PASS1 || e.phase == PH_PASS2) { force_ms += ms; force_launches += 1; }
+            }
+            ev_pool.push_back(e);
+        }
+        ev_pending.clear();
+    }
+
+    static double decode(unsigned long long bits) {
+        if constexpr (sizeof(T) == 4) { uint32_t u = (uint32_t)bits; float f; memcpy(&f, &u, 4); return (double)f; }
+        else { double d; memcpy(&d, &bits, 8); return d; }
+    }
+
+    ForceParams<T> force_params(int src, int a, int out, double dt) const {
+        ForceParams<T> P{};
+        P.src0 = pk0[src]; P.src1 = pk1[src];
+        P.a0 = pk0[a]; P.a1 = pk1[a];
+        P.out0 = pk0[out]; P.out1 = pk1[out];
+        P.accbuf = acc[cur];
+        P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
+        P.red = red_d;
+        P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
+        P.nblocks = (N + kWave - 1) / kWave;
+        P.visc = cfg.viscosity == SPHMI_VISC_ARTIFICIAL;
+        P.ddt = cfg.density_diffusion == SPHMI_DDT_LINEAR;
+        P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
+        P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
+        P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
+        P.m0 = (T)cfg.m0;
+        P.Kddt = (T)(cfg.delta_phi * cfg.h * cfg.c0 * cfg.m0);
+        P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
+        P.eta2 = (T)cfg.eta2;
+        P.Kv2 = (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h);
+        P.rho0 = (T)cfg.rho0; P.inv_rho0 = (T)(1.0 / cfg.rho0);
+        P.g = (T)cfg.g;
+        P.Cbe = (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0);
+        return P;
+    }
+
+    template <int PASS> void launch_force(const ForceParams<T>& P) {
+        dim3 g(P.nblocks), b(kWave);
+        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS>), g, b, 0, stream, P);
+        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS>), g, b, 0, stream, P);
+        HC(hipGetLastError());
+    }
+
+    // ---- UpdateNeighbors! -------------------------------------------------------------------
+    void rebuild() {
+        Ev ev = begin_phase(PH_REBUILD);
+        const int nb256 = (N + 255) / 256;
+        const int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
+        memcpy(bbox_h, init, sizeof(init));
+        HC(hipMemcpyAsync(bbox_d, bbox_h, sizeof(init), hipMemcpyHostToDevice, stream));
+        if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, bbox_d);
+        else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, bbox_d);
+        HC(hipGetLastError());
+        HC(hipMemcpyAsync(bbox_h, bbox_d, 6 * 4, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+        int64_t ncell = 1;
+        for (int d = 0; d < 3; ++d) {
+            if (d < D) {
+                int64_t n = (int64_t)bbox_h[3 + d] - (int64_t)bbox_h[d] + 1;
+                if (n <= 0 || n > (1ll << 30)) throw EngineError(SPHMI_ERR_NUMERIC, "non-finite particle position in cell hash");
+                grid.gmin[d] = bbox_h[d];
+                grid.np[d] = (int)n + 2;
+            } else { grid.gmin[d] = 0; grid.np[d] = 1; }
+            ncell *= grid.np[d];
+        }
+        const int64_t budget = cfg.max_cells > 0 ? cfg.max_cells : (1ll << 27);
+        if (ncell > budget) {
+            char buf[200];
+            snprintf(buf, sizeof(buf), "bounding cell grid %d x %d x %d = %lld cells exceeds max_cells = %lld "
+                     "(a particle left the domain?)", grid.np[0], grid.np[1], grid.np[2], (long long)ncell, (long long)budget);
+            throw EngineError(SPHMI_ERR_DOMAIN, buf);
+        }
+        grid.ncell = (int)ncell;
+        if (ncell + 1 > cell_cap) {
+            (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
+            cell_cap = (ncell + 1) + (ncell + 1) / 4;
+            HC(hipMalloc(&count, cell_cap * 4)); HC(hipMalloc(&cstart, cell_cap * 4));
+            HC(hipMalloc(&tsum, ((cell_cap + kScanTile - 1) / kScanTile + 1) * 4));
+        }
+        HC(hipMemsetAsync(count, 0, (size_t)(ncell + 1) * 4, stream));
+        HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream));
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, grid, count, key[cur], slot);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, grid, count, key[cur], slot);
+        const int ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
+        hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, count, cstart, (int)ncell, tsum, misc_d);
+        hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, misc_d + 1);
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, stream, cstart, (int)ncell, tsum, misc_d + 1);
+        hipLaunchKernelGGL(k_scatter, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, tmp_idx);
+        hipLaunchKernelGGL(k_rankfix, dim3(nb256), dim3(256), 0, stream, N, key[cur], cstart, tmp_idx, perm);
+        PermuteArgs<T> A{};
+        const int nxt = cur ^ 1;
+        A.pk0_in = pk0[iA]; A.pk1_in = pk1[iA]; A.acc_in = acc[cur]; A.ghost_in = ghost[cur];
+        A.pk0_out = pk0[iB]; A.pk1_out = pk1[iB]; A.acc_out = acc[nxt]; A.ghost_out = ghost[nxt];
+        A.type_in = type[cur]; A.type_out = type[nxt];
+        A.id_in = id[cur]; A.id_out = id[nxt];
+        A.grp_in = grp[cur]; A.grp_out = grp[nxt];
+        A.key_in = key[cur]; A.key_out = key[nxt];
+        A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE;
+        hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
+        HC(hipGetLastError());
+        std::swap(iA, iB);
+        cur = nxt;
+        HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
+        nonempty_pending = true;
+        have_grid = true;
+        n_rebuilds += 1;
+        end_phase(ev);
+    }
+
+    void run_mdbc() {
+        Ev ev = begin_phase(PH_MDBC);
+        MdbcParams<T> M{};
+        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
+        M.H_inv = (T)cfg.H_inv; M.H2 = (T)cfg.H2; M.h_inv = (T)cfg.h_inv; M.h = (T)cfg.h;
+        M.alphaD = (T)cfg.alphaD; M.m0 = (T)cfg.m0; M.rho0 = (T)cfg.rho0;
+        dim3 g((N + 63) / 64), b(64);
+        if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
+        else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
+        HC(hipGetLastError());
+        end_phase(ev);
+    }
+
+    void sync_and_collect() {
+        HC(hipStreamSynchronize(stream));
+        collect_events();
+        if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
+    }
+
+    // ---- one iteration of the while loop at src/SPHCellList.jl:742-802 -------------------------
+    void step_once() {
+        Ev ev = begin_phase(PH_TIMESTEP);
+        HC(hipMemcpyAsync(red_h, red_d, 4 * 8, hipMemcpyDeviceToHost, stream));
+        end_phase(ev);
+        sync_and_collect();
+        if (red_h[3]) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
+        const double maxdisp = std::sqrt(decode(red_h[0]));
+        const double visc = decode(red_h[1]);
+        const double amax = std::sqrt(decode(red_h[2]));
+        delta_x += 4.0 * maxdisp;                                            // update_delta_x!, :706-724
+        const double dt1 = std::sqrt(cfg.h / amax);                          // Δt, src/TimeStepping.jl:30-43
+        const double dt2 = cfg.h / (cfg.c0 + visc);
+        const double dt = cfg.CFL * std::min(dt1, dt2);
+        if (!(dt > 0.0) || std::isnan(dt) || std::isnan(delta_x)) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "non-positive or NaN dt (%g) at iteration %lld (visc %g, |a|max %g, Δx %g)",
+                     dt, (long long)iteration, visc, amax, delta_x);
+            throw EngineError(SPHMI_ERR_NUMERIC, buf);
+        }
+        if (delta_x >= cfg.h) { rebuild(); delta_x = 0.0; }                   // :758-762
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();                        // :772 (Pressure! of :771 is in pk1.w)
+        Ev e1 = begin_phase(PH_PASS1);
+        launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));          // :774-781
+        end_phase(e1);
+        Ev e2 = begin_phase(PH_PASS2);
+        launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));          // :789-798
+        end_phase(e2);
+        std::swap(iA, iB);
+        stepped = true;
+        iteration += 1; last_dt = dt; total_time += dt;                       // UpdateMetaData!, :679-685
+    }
+
+    void fill(sphmi_progress* p, int64_t steps) {
+        if (!p) return;
+        p->iteration = iteration; p->steps_done = steps; p->n_rebuilds = n_rebuilds;
+        p->index_counter = index_counter; p->total_time = total_time; p->last_dt = last_dt; p->delta_x = delta_x;
+    }
+
+    void advance(double t_target, int64_t max_steps, sphmi_progress* out) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_advance before sphmi_upload");
+        HC(hipSetDevice(cfg.device));
+        delta_x = 1.0 + cfg.h;                                                // :739
+        int64_t steps = 0;
+        try {
+            while (total_time <= t_target && (max_steps < 0 || steps < max_steps)) { step_once(); ++steps; }
+            sync_and_collect();
+        } catch (...) { fill(out, steps); throw; }
+        fill(out, steps);
+    }
+
+    // ---- upload / download --------------------------------------------------------------------
+    template <class H> void pack_host(const void* position, const void* velocity, const void* acceleration,
+                                      const void* density, const uint8_t* ty, const void* ghost_points,
+                                      std::vector<V4>& h0, std::vector<V4>& h1, std::vector<V4>& ha, std::vector<V4>& hg) {
+        const H* x = (const H*)position; const H* v = (const H*)velocity; const H* a = (const H*)acceleration;
+        const H* r = (const H*)density; const H* g = (const H*)ghost_points;
+        for (int i = 0; i < N; ++i) {
+            V4 p0{}, p1{}, pa{}, pg{};
+            p0.x = (T)x[i * D]; p0.y = (T)x[i * D + 1]; p0.z = D == 3 ? (T)x[i * D + 2] : T(0);
+            p0.w = ty[i] == SPHMI_FLUID ? (T)r[i] : -(T)r[i];
+            p1.x = (T)v[i * D]; p1.y = (T)v[i * D + 1]; p1.z = D == 3 ? (T)v[i * D + 2] : T(0); p1.w = 0;
+            if (a) { pa.x = (T)a[i * D]; pa.y = (T)a[i * D + 1]; pa.z = D == 3 ? (T)a[i * D + 2] : T(0); }
+            if (g) {
+                pg.x = (T)g[i * D]; pg.y = (T)g[i * D + 1]; pg.z = D == 3 ? (T)g[i * D + 2] : T(0);
+                bool nz = false;
+                for (int d = 0; d < D; ++d) nz |= g[i * D + d] != H(0);
+                pg.w = nz ? T(1) : T(0);
+            }
+            h0[i] = p0; h1[i] = p1; ha[i] = pa; hg[i] = pg;
+        }
+    }
+
+    void upload(const void* position, const void* velocity, const void* acceleration, const void* density,
+                const uint8_t* ty, const int64_t* ids, const uint64_t* groups, const void* ghost_points) override {
+        if (!position || !velocity || !density || !ty || !ids) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: null array");
+        HC(hipSetDevice(cfg.device));
+        for (int i = 0; i < N; ++i) {
+            if (ty[i] < 1 || ty[i] > 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: ParticleType must be 1, 2 or 3");
+        }
+        std::vector<V4> h0(N), h1(N), ha(N), hg(N);
+        if (cfg.host_float_bytes == 8) pack_host<double>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg);
+        else pack_host<float>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg);
+        for (int i = 0; i < N; ++i)
+            if (!(std::fabs((double)h0[i].w) > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
+        iA = 0; iH = 1; iB = 2; cur = 0;
+        const size_t n = (size_t)N;
+        HC(hipMemcpyAsync(pk0[iA], h0.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(pk1[iA], h1.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(acc[cur], ha.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(ghost[cur], hg.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(type[cur], ty, n, hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(id[cur], ids, n * 8, hipMemcpyHostToDevice, stream));
+        if (groups) HC(hipMemcpyAsync(grp[cur], groups, n * 8, hipMemcpyHostToDevice, stream));
+        else HC(hipMemsetAsync(grp[cur], 0, n * 8, stream));
+        HC(hipMemsetAsync(key[cur], 0, n * 4, stream));
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+        const int nb256 = (N + 255) / 256;
+        // Pressure! (src/SPHCellList.jl:835) and the reductions Δt / update_delta_x! will read first
+        hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
+                           (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
+        hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N,
+                           (T)cfg.h, (T)cfg.eta2, red_d);
+        HC(hipGetLastError());
+        HC(hipStreamSynchronize(stream));
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
+    }
+
+    template <class H> static void unpack3(const std::vector<V4>& s, H* out, int N, int D) {
+        for (int i = 0; i < N; ++i) {
+            out[i * D] = (H)s[i].x; out[i * D + 1] = (H)s[i].y;
+            if (D == 3) out[i * D + 2] = (H)s[i].z;
+        }
+    }
+
+    void download(void* position, void* velocity, void* acceleration, void* density, void* pressure,
+                  int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
+        HC(hipSetDevice(cfg.device));
+        HC(hipStreamSynchronize(stream));
+        const size_t n = (size_t)N;
+        std::vector<V4> h0(N), h1(N), tmp(N);
+        HC(hipMemcpy(h0.data(), pk0[iA], n * sizeof(V4), hipMemcpyDeviceToHost));
+        HC(hipMemcpy(h1.data(), pk1[iA], n * sizeof(V4), hipMemcpyDeviceToHost));
+        const bool h8 = cfg.host_float_bytes == 8;
+        if (position) { if (h8) unpack3(h0, (double*)position, N, D); else unpack3(h0, (float*)position, N, D); }
+        if (velocity) { if (h8) unpack3(h1, (double*)velocity, N, D); else unpack3(h1, (float*)velocity, N, D); }
+        if (density) for (int i = 0; i < N; ++i) { double r = std::fabs((double)h0[i].w); if (h8) ((double*)density)[i] = r; else ((float*)density)[i] = (float)r; }
+        if (pressure) {
+            // SimParticles.Pressure holds Pressure!(ρₙ⁺) of the last step (src/SPHCellList.jl:789); before
+            // any step it is the initial Pressure!(ρ) of :835.
+            if (stepped) {
+                HC(hipMemcpy(tmp.data(), pk0[iH], n * sizeof(V4), hipMemcpyDeviceToHost));
+                const T rho0 = (T)cfg.rho0, inv0 = (T)(1.0 / cfg.rho0), Cbe = (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0);
+                for (int i = 0; i < N; ++i) {
+                    T rr = sizeof(T) == 8 ? tmp[i].w / rho0 : tmp[i].w * inv0;
+                    T r2 = rr * rr, r4 = r2 * r2;
+                    double p = (double)(Cbe * (r4 * r2 * rr - T(1)));
+                    if (h8) ((double*)pressure)[i] = p; else ((float*)pressure)[i] = (float)p;
+                }
+            } else {
+                for (int i = 0; i < N; ++i) { if (h8) ((double*)pressure)[i] = (double)h1[i].w; else ((float*)pressure)[i] = (float)h1[i].w; }
+            }
+        }
+        if (acceleration) {
+            HC(hipMemcpy(tmp.data(), acc[cur], n * sizeof(V4), hipMemcpyDeviceToHost));
+            if (h8) unpack3(tmp, (double*)acceleration, N, D); else unpack3(tmp, (float*)acceleration, N, D);
+        }
+        if (ghost_points) {
+            HC(hipMemcpy(tmp.data(), ghost[cur], n * sizeof(V4), hipMemcpyDeviceToHost));
+            if (h8) unpack3(tmp, (double*)ghost_points, N, D); else unpack3(tmp, (float*)ghost_points, N, D);
+        }
+        if (ids) HC(hipMemcpy(ids, id[cur], n * 8, hipMemcpyDeviceToHost));
+        if (ty) HC(hipMemcpy(ty, type[cur], n, hipMemcpyDeviceToHost));
+        if (groups) HC(hipMemcpy(groups, grp[cur], n * 8, hipMemcpyDeviceToHost));
+        if (cells) {
+            if (!have_grid) { memset(cells, 0, n * D * 8); }
+            else {
+                std::vector<int> k(N);
+                HC(hipMemcpy(k.data(), key[cur], n * 4, hipMemcpyDeviceToHost));
+                for (int i = 0; i < N; ++i) {
+                    int kk = k[i];
+                    int cx = kk % grid.np[0]; kk /= grid.np[0];
+                    int cy = kk % grid.np[1]; int cz = kk / grid.np[1];
+                    cells[(size_t)i * D] = (int64_t)cx - 1 + grid.gmin[0];
+                    cells[(size_t)i * D + 1] = (int64_t)cy - 1 + grid.gmin[1];
+                    if (D == 3) cells[(size_t)i * D + 2] = (int64_t)cz - 1 + grid.gmin[2];
+                }
+            }
+        }
+    }
+
+    void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once before sphmi_upload");
+        HC(hipSetDevice(cfg.device));
+        rebuild();
+        const int nb256 = (N + 255) / 256;
+        hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
+                           (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
+        if (apply_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();
+        // the forces-only pass writes {a, dρ/dt} into a scratch set so SimParticles.Acceleration survives
+        ForceParams<T> P = force_params(iA, iA, iH, 0.0);
+        P.accbuf = pk0[iB];
+        Ev e1 = begin_phase(PH_PASS1);
+        launch_force<PASS_FORCES_ONLY>(P);
+        end_phase(e1);
+        sync_and_collect();
+        std::vector<V4> tmp(N);
+        HC(hipMemcpy(tmp.data(), pk0[iB], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        const bool h8 = cfg.host_float_bytes == 8;
+        if (acceleration) { if (h8) unpack3(tmp, (double*)acceleration, N, D); else unpack3(tmp, (float*)acceleration, N, D); }
+        if (drhodt) for (int i = 0; i < N; ++i) { if (h8) ((double*)drhodt)[i] = (double)tmp[i].w; else ((float*)drhodt)[i] = (float)tmp[i].w; }
+    }
+
+    void unique_cells(int64_t* out, int64_t cap, int64_t* n_out) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipStreamSynchronize(stream));
+        if (!have_grid) { if (n_out) *n_out = 0; return; }
+        std::vector<int> k(N);
+        HC(hipMemcpy(k.data(), key[cur], (size_t)N * 4, hipMemcpyDeviceToHost));
+        std::vector<int> u;
+        for (int i = 0; i < N; ++i) if (i == 0 || k[i] != k[i - 1]) u.push_back(k[i]);
+        if (n_out) *n_out = (int64_t)u.size();
+        if (!out) return;
+        if (cap < (int64_t)u.size()) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_unique_cells: capacity too small");
+        for (size_t i = 0; i < u.size(); ++i) {
+            int kk = u[i];
+            int cx = kk % grid.np[0]; kk /= grid.np[0];
+            int cy = kk % grid.np[1]; int cz = kk / grid.np[1];
+            out[i * D] = (int64_t)cx - 1 + grid.gmin[0];
+            out[i * D + 1] = (int64_t)cy - 1 + grid.gmin[1];
+            if (D == 3) out[i * D + 2] = (int64_t)cz - 1 + grid.gmin[2];
+        }
+    }
+
+    void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
+        if (n) *n = PH_COUNT;
+        for (int i = 0; i < PH_COUNT && i < cap; ++i) {
+            if (names) names[i] = kPhaseNames[i];
+            if (secs) secs[i] = ph_secs[i];
+            if (calls) calls[i] = ph_calls[i];
+        }
+    }
+    void force_stats(int reset, double* avg_ms, int64_t* launches) override {
+        if (avg_ms) *avg_ms = force_launches ? force_ms / (double)force_launches : 0.0;
+        if (launches) *launches = force_launches;
+        if (reset) { force_ms = 0; force_launches = 0; }
+    }
+    void device_ptrs(void** p0, void** p1, int64_t* n) override {
+        if (p0) *p0 = pk0[iA];
+        if (p1) *p1 = pk1[iA];
+        if (n) *n = N;
+    }
+};
+
+}  // namespace sphmi
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+struct sphmi_handle { sphmi::EngineBase* e; };
+
+#define SPHMI_GUARD(h, body)                                                        \
+    if (!(h) || !(h)->e) return SPHMI_ERR_ARGUMENT;                                 \
+    try { body; return SPHMI_OK; }                                                  \
+    catch (const sphmi::EngineError& x) { (h)->e->err = x.what(); return x.status; } \
+    catch (const std::exception& x) { (h)->e->err = x.what(); return SPHMI_ERR_DEVICE; }
+
+extern "C" {
+
+const char* sphmi_backend_info(void) {
+    return "sphmi abi 1 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+           "counting-sort cell list, mDBC | no CPU fallback";
+}
+
+const char* sphmi_last_error(const sphmi_handle* h) {
+    if (!h || !h->e) return sphmi::g_create_error.c_str();
+    return h->e->err.c_str();
+}
+
+int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
+    using namespace sphmi;
+    auto fail = [&](int st, const std::string& m) { g_create_error = m; return st; };
+    if (!cfg || !out) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(sphmi_config) || cfg->abi_version != SPHMI_ABI_VERSION)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: struct_size / abi_version mismatch");
+    if (cfg->dims != 2 && cfg->dims != 3) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: dims must be 2 or 3");
+    if ((cfg->host_float_bytes != 4 && cfg->host_float_bytes != 8) ||
+        (cfg->device_float_bytes != 4 && cfg->device_float_bytes != 8))
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: float_bytes must be 4 or 8");
+    if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 30))
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^30]");
+    if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: only WendlandC2 is implemented");
+    if (cfg->viscosity != SPHMI_VISC_ZERO && cfg->viscosity != SPHMI_VISC_ARTIFICIAL)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: viscosity model not implemented");
+    if (cfg->density_diffusion != SPHMI_DDT_NONE && cfg->density_diffusion != SPHMI_DDT_LINEAR)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: density diffusion model not implemented");
+    if (cfg->mdbc != SPHMI_MDBC_NONE && cfg->mdbc != SPHMI_MDBC_SIMPLE)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: mdbc mode not implemented");
+    if (!(cfg->h > 0) || !(cfg->H > 0) || !(cfg->rho0 > 0) || !(cfg->m0 > 0) || !(cfg->c0 > 0) || !(cfg->CFL > 0))
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: h, H, rho0, m0, c0, CFL must be positive");
+    try {
+        sphmi_handle* h = new sphmi_handle{nullptr};
+        if (cfg->device_float_bytes == 4) h->e = new Engine<float>(*cfg);
+        else h->e = new Engine<double>(*cfg);
+        *out = h;
+        return SPHMI_OK;
+    } catch (const EngineError& x) { return fail(x.status, x.what()); }
+    catch (const std::exception& x) { return fail(SPHMI_ERR_DEVICE, x.what()); }
+}
+
+int sphmi_destroy(sphmi_handle* h) {
+    if (!h) return SPHMI_OK;
+    delete h->e;
+    delete h;
+    return SPHMI_OK;
+}
+
+int sphmi_upload(sphmi_handle* h, const void* position, const void* velocity, const void* acceleration,
+                 const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker,
+                 const void* ghost_points) {
+    SPHMI_GUARD(h, h->e->upload(position, velocity, acceleration, density, type, id, group_marker, ghost_points));
+}
+
+int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time) {
+    SPHMI_GUARD(h, (h->e->iteration = iteration, h->e->total_time = total_time));
+}
+
+int sphmi_advance(sphmi_handle* h, double t_target, int64_t max_steps, sphmi_progress* out) {
+    SPHMI_GUARD(h, h->e->advance(t_target, max_steps, out));
+}
+
+int sphmi_download(sphmi_handle* h, void* position, void* velocity, void* acceleration, void* density,
+                   void* pressure, int64_t* id, uint8_t* type, uint64_t* group_marker, void* ghost_points,
+                   int64_t* cells) {
+    SPHMI_GUARD(h, h->e->download(position, velocity, acceleration, density, pressure, id, type, group_marker,
+                                  ghost_points, cells));
+}
+
+int sphmi_forces_once(sphmi_handle* h, int apply_mdbc, void* drhodt, void* acceleration) {
+    SPHMI_GUARD(h, h->e->forces_once(apply_mdbc, drhodt, acceleration));
+}
+
+int sphmi_unique_cells(sphmi_handle* h, int64_t* cells_out, int64_t capacity, int64_t* n_out) {
+    SPHMI_GUARD(h, h->e->unique_cells(cells_out, capacity, n_out));
+}
+
+int sphmi_timers(sphmi_handle* h, int32_t capacity, const char** names_out, double* seconds_out,
+                 int64_t* calls_out, int32_t* n_out) {
+    SPHMI_GUARD(h, h->e->timers(capacity, names_out, seconds_out, calls_out, n_out));
+}
+
+int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out) {
+    SPHMI_GUARD(h, h->e->force_stats(reset, avg_ms_out, launches_out));
+}
+
+int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local) {
+    SPHMI_GUARD(h, h->e->device_ptrs(pk0, pk1, n_local));
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+// sphmi_rebuild.h — cell-list build (UpdateNeighbors!, src/SPHCellList.jl:138-163), mDBC
+// (src/SPHCellList.jl:219-266, 319-365, 598-622) and the start-up reductions, as gfx950 kernels.
+//
+// The reference sorts a 17-field StructArray with a stable comparison sort and keeps a
+// Dict{CartesianIndex,Int}.  Here: particle → padded linear cell id (x fastest, matching
+// CartesianIndex order "last axis most significant"), histogram with atomics, exclusive scan to
+// cell_start over the dense bounding grid (replaces ParticleRanges + CellDict), unordered scatter,
+// then an in-cell rank fix that restores the STABLE order (rank = number of cell mates with a
+// smaller previous index), and one gather pass that permutes every state array.
+#pragma once
+#include "sphmi_kernels.h"
+
+namespace sphmi {
+
+// map_floor, src/SPHCellList.jl:56-61: round half away from zero, trunc(|x|·H⁻¹ + 0.5) with the
+// multiply-add fused (Julia's muladd lowers to an fma on every FMA-capable CPU).
+template <class T> __device__ __forceinline__ int map_floor(T x, T inv_cutoff) {
+    T t;
+    if constexpr (sizeof(T) == 8) t = trunc(fma(absT(x), inv_cutoff, T(0.5)));
+    else t = truncf(fmaf(absT(x), inv_cutoff, T(0.5)));
+    int c = (int)t;
+    return x < T(0) ? -c : c;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// bbox[0..2] = min cell, bbox[3..5] = max cell (ExtractCells!, :118-123, reduced)
+template <class T, int D>
+__global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type* pk0, int N, T inv_cutoff,
+                                                   int* bbox) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int ic = i < N ? i : N - 1;
+    auto p = pk0[ic];
+    int c[3] = {map_floor<T>(p.x, inv_cutoff), map_floor<T>(p.y, inv_cutoff),
+                D == 3 ? map_floor<T>(p.z, inv_cutoff) : 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int mn = wave_min_i(c[d]), mx = wave_max_i(c[d]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&bbox[d], mn);
+            atomicMax(&bbox[3 + d], mx);
+        }
+    }
+}
+
+struct GridDesc {
+    int gmin[3];      // cell coordinate of padded index 1
+    int np[3];        // padded dims (n + 2)
+    int ncell;        // np[0]*np[1]*np[2]
+};
+
+template <class T, int D>
+__global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type* pk0, int N, T inv_cutoff,
+                                                    GridDesc g, int* count, int* key, int* slot) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    auto p = pk0[i];
+    int cx = map_floor<T>(p.x, inv_cutoff) - g.gmin[0] + 1;
+    int cy = map_floor<T>(p.y, inv_cutoff) - g.gmin[1] + 1;
+    int cz = D == 3 ? map_floor<T>(p.z, inv_cutoff) - g.gmin[2] + 1 : 0;
+    int k = cx + g.np[0] * (cy + g.np[1] * cz);
+    key[i] = k;
+    slot[i] = atomicAdd(&count[k], 1);
+}
+
+// ---- exclusive scan over the cell histogram (3 launches) ------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanPer = 16;
+constexpr int kScanTile = kScanThreads * kScanPer;
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_tile(const int* in, int* out, int n, int* tsum,
+                                                            int* nonempty) {
+    __shared__ int s_w[kScanThreads / 64];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    int v[kScanPer];
+    int sum = 0, nz = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        int idx = base + k;
+        int x = idx < n ? in[idx] : 0;
+        v[k] = sum;
+        sum += x;
+        nz += x != 0;
+    }
+    // wave inclusive scan of the per-thread sums
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(inc, o, 64);
+        if ((threadIdx.x & 63) >= o) inc += u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nz += __shfl_xor(nz, o, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) s_w[w] = inc;
+    if ((threadIdx.x & 63) == 0 && nz) atomicAdd(nonempty, nz);
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += s_w[k];
+    const int excl = woff + inc - sum;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        int idx = base + k;
+        if (idx < n) out[idx] = v[k] + excl;
+    }
+    if (threadIdx.x == kScanThreads - 1) tsum[blockIdx.x] = woff + inc;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tsums(int* tsum, int ntiles, int* total_out) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < ntiles; b0 += 1024) {
+        int idx = b0 + threadIdx.x;
+        int x = idx < ntiles ? tsum[idx] : 0;
+        int inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int u = __shfl_up(inc, o, 64);
+            if ((threadIdx.x & 63) >= o) inc += u;
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) s_w[w] = inc;
+        __syncthreads();
+        int woff = s_carry;
+        for (int k = 0; k < w; ++k) woff += s_w[k];
+        if (idx < ntiles) tsum[idx] = woff + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_add(int* out, int n, const int* tsum, const int* total) {
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    const int off = tsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        int idx = base + k;
+        if (idx < n) out[idx] += off;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+__global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const int* slot, const int* cstart,
+                                                 int* tmp_idx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) tmp_idx[cstart[key[i]] + slot[i]] = i;
+}
+
+// stable in-cell order: rank = #{cell mates whose previous index is smaller}
+__global__ void __launch_bounds__(256) k_rankfix(int N, const int* key, const int* cstart, const int* tmp_idx,
+                                                 int* perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int k = key[i];
+    const int s = cstart[k], e = cstart[k + 1];
+    int rank = 0;
+    for (int q = s; q < e; ++q) rank += tmp_idx[q] < i;
+    perm[s + rank] = i;
+}
+
+template <class T>
+struct PermuteArgs {
+    using V4 = typename Vec4<T>::type;
+    const V4 *pk0_in, *pk1_in, *acc_in, *ghost_in;
+    V4 *pk0_out, *pk1_out, *acc_out, *ghost_out;
+    const uint8_t* type_in; uint8_t* type_out;
+    const long long* id_in; long long* id_out;
+    const unsigned long long* grp_in; unsigned long long* grp_out;
+    const int* key_in; int* key_out;
+    const int* perm;
+    int N, has_ghost;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.N) return;
+    const int i = A.perm[p];
+    A.pk0_out[p] = A.pk0_in[i];
+    A.pk1_out[p] = A.pk1_in[i];
+    A.acc_out[p] = A.acc_in[i];
+    if (A.has_ghost) A.ghost_out[p] = A.ghost_in[i];
+    A.type_out[p] = A.type_in[i];
+    A.id_out[p] = A.id_in[i];
+    A.grp_out[p] = A.grp_in[i];
+    A.key_out[p] = A.key_in[i];
+}
+
+// Pressure! (src/SimulationEquations.jl:18-24) on a state set: pk1.w = EOS(|pk0.w|)
+template <class T>
+__global__ void __launch_bounds__(256) k_eos(const typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+                                             int N, T rho0, T inv_rho0, T Cbe) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    auto v = pk1[i];
+    v.w = eos7<T>(absT(pk0[i].w), rho0, inv_rho0, Cbe);
+    pk1[i] = v;
+}
+
+// ---- start-up reductions (Δt on the uploaded state; Positionₙ⁺ = 0 → |x|) ---------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_init_reduce(const typename Vec4<T>::type* pk0,
+                                                     const typename Vec4<T>::type* pk1,
+                                                     const typename Vec4<T>::type* acc, int N, T h, T eta2,
+                                                     unsigned long long* red) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    T disp2 = 0, vis = 0, a2 = 0;
+    if (i < N) {
+        auto x = pk0[i]; auto v = pk1[i]; auto a = acc[i];
+        const T rr = x.x * x.x + x.y * x.y + x.z * x.z;
+        disp2 = rr;
+        vis = absT(h * (v.x * x.x + v.y * x.y + v.z * x.z) / (rr + eta2));
+        a2 = a.x * a.x + a.y * a.y + a.z * a.z;
+    }
+    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_bits(&red[0], disp2);
+        atomic_max_bits(&red[1], vis);
+        atomic_max_bits(&red[2], a2);
+    }
+}
+
+// ---- mDBC -------------------------------------------------------------------------------------
+template <class T> struct MdbcParams {
+    using V4 = typename Vec4<T>::type;
+    V4* pk0;               // state A: ρ of boundary particles is rewritten in place
+    const V4* ghost;       // { g, flag }  flag != 0 ⇔ !iszero(GhostPoint)
+    const int* cstart;
+    GridDesc g;
+    unsigned long long* red;   // red[3]: non-positive density flag
+    int N;
+    T H_inv, H2, h_inv, h, alphaD, m0, rho0;
+};
+
+template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22) {
+    return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+}
+
+template <class T, int D>
+__global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
+    constexpr int P = D + 1;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.N) return;
+    const auto gq = M.ghost[i];
+    if (gq.w == T(0)) return;
+    const T g[3] = {gq.x, gq.y, gq.z};
+    int gc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gc[d] = d < D ? map_floor<T>(g[d], M.H_inv) - M.g.gmin[d] + 1 : 0;
+    T b[P], A[P][P];   // A[r][c]
+#pragma unroll
+    for (int r = 0; r < P; ++r) { b[r] = 0;
+#pragma unroll
+        for (int c = 0; c < P; ++c) A[r][c] = 0; }
+    const int nz = D == 3 ? 3 : 1;
+    for (int sz = 0; sz < nz; ++sz)
+        for (int sy = 0; sy < 3; ++sy) {
+            // the three x-adjacent cells of a row are one contiguous range; clip to the padded grid
+            const int cy = gc[1] + sy - 1, cz = D == 3 ? gc[2] + sz - 1 : 0;
+            if (cy < 0 || cy >= M.g.np[1] || cz < 0 || cz >= M.g.np[2]) continue;
+            int x0 = gc[0] - 1, x1 = gc[0] + 1;
+            if (x0 < 0) x0 = 0;
+            if (x1 > M.g.np[0] - 1) x1 = M.g.np[0] - 1;
+            if (x0 > x1) continue;
+            const int row = M.g.np[0] * (cy + M.g.np[1] * cz);
+            const int s = M.cstart[row + x0], e = M.cstart[row + x1 + 1];
+            for (int j = s; j < e; ++j) {
+                const auto n0 = M.pk0[j];
+                if (!(n0.w > T(0))) continue;                 // ParticleType[j] == Fluid
+                const T xij[3] = {g[0] - n0.x, g[1] - n0.y, D == 3 ? g[2] - n0.z : T(0)};
+                const T r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
+                if (!(r2 <= M.H2)) continue;
+                T q = fast_sqrt(r2) * M.h_inv;
+                q = q > T(2) ? T(2) : q;
+                const T t1 = T(1) - q / T(2);
+                const T t2 = t1 * t1;
+                const T Wij = M.alphaD * (t2 * t2) * (T(2) * q + T(1));      // src/SPHKernels.jl:75-78
+                const T tq = q - T(2);
+                const T fac = M.alphaD * T(5) * (tq * tq * tq) / (T(8) * M.h * M.h);
+                const T Vj = M.m0 / n0.w;
+                T fc[P];
+                fc[0] = Vj * Wij;
+                b[0] += M.m0 * Wij;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const T gw = fac * xij[d];
+                    fc[d + 1] = Vj * gw;
+                    b[d + 1] += M.m0 * gw;
+                }
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    A[r][0] += fc[r];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) A[r][k + 1] += (-xij[k]) * fc[r];
+                }
+            }
+        }
+    // ApplyMDBCCorrection, src/SPHCellList.jl:598-622
+    T det;
+    if constexpr (P == 3) {
+        det = det3<T>(A[0][0], A[0][1], A[0][2], A[1][0], A[1][1], A[1][2], A[2][0], A[2][1], A[2][2]);
+    } else {
+        det = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            T m[3][3];
+            int cc = 0;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                if (c2 == c) continue;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) m[r - 1][cc] = A[r][c2];
+                cc++;
+            }
+            const T d3 = det3<T>(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
+            det += ((c & 1) ? T(-1) : T(1)) * A[0][c] * d3;
+        }
+    }
+    auto me = M.pk0[i];
+    T newrho = absT(me.w);
+    bool write = false;
+    if (absT(det) >= T(1e-3)) {
+        // Gaussian elimination with partial pivoting on [A | b] (same order as the oracle)
+        T Mx[P][P + 1];
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+#pragma unroll
+            for (int c = 0; c < P; ++c) Mx[r][c] = A[r][c];
+            Mx[r][P] = b[r];
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            int p = k;
+            T best = absT(Mx[k][k]);
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) if (absT(Mx[r][k]) > best) { best = absT(Mx[r][k]); p = r; }
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) {
+                if (r == p) {
+#pragma unroll
+                    for (int c = 0; c <= P; ++c) { T t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
+                }
+            }
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) {
+                const T f = Mx[r][k] / Mx[k][k];
+#pragma unroll
+                for (int c = k; c <= P; ++c) Mx[r][c] -= f * Mx[k][c];
+            }
+        }
+        T s[P];
+#pragma unroll
+        for (int r = P - 1; r >= 0; --r) {
+            T acc = Mx[r][P];
+#pragma unroll
+            for (int c = r + 1; c < P; ++c) acc -= Mx[r][c] * s[c];
+            s[r] = acc / Mx[r][r];
+        }
+        const T xi[3] = {me.x, me.y, me.z};
+        T v1 = s[0];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v1 += s[d + 1] * (xi[d] - g[d]);
+        newrho = (v1 != v1) ? M.rho0 : v1;
+        write = true;
+    } else if (A[0][0] > T(0)) {
+        const T v = b[0] / A[0][0];
+        newrho = (v != v) ? M.rho0 : v;
+        write = true;
+    }
+    if (write) {
+        // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
+        if (!(newrho > T(0))) atomicOr(&M.red[3], 1ull);
+        me.w = me.w > T(0) ? newrho : -newrho;
+        M.pk0[i] = me;
+    }
+}
+
+}  // namespace sphmi

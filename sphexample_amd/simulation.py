@@ -1,0 +1,57 @@
+"""``RunSimulation`` — host-side mirror of the reference's driver loop around the hot path.
+
+Restates the bookkeeping of /root/reference/src/SPHCellList.jl:808-930 that surrounds
+``SimulationLoop``: load mDBC normals (:827), output counter starts at 1 (:849), one engine
+``advance`` per output interval (:883) with ``next_output_time`` (:687-698), stop when
+``TotalTime > SimulationTime`` (:909).  VTKHDF output, logging and ParaView glue are out of scope
+(SURVEY.md §2 rows 11-13); ``on_output`` receives the particles at every output time instead.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+from ._abi import make_config
+from .config import (SimulationConstants, SimulationMetaData, SPHDensityDiffusion, SPHKernelInstance,
+                     SPHViscosity, next_output_time)
+from .engine import Engine
+from .preprocess import LoadMDBCNormals, SimParticles
+
+
+def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConstants: SimulationConstants,
+                  SimKernel: SPHKernelInstance, SimLogger=None, SimParticles: SimParticles,
+                  SimViscosity: SPHViscosity, SimDensityDiffusion: SPHDensityDiffusion,
+                  ParticleNormalsPath: Optional[str] = None,
+                  on_output: Optional[Callable[[SimulationMetaData, SimParticles], None]] = None,
+                  device_float_bytes: int = 4, device: int = 0, backend_factory=None) -> List[float]:
+    """Same keyword signature as the reference (src/SPHCellList.jl:808-817); returns the list of
+    time steps the reference collects in ``TimeSteps`` (:823,:884).  ``SimParticles`` is updated in
+    place at every output time, in the engine's cell-sorted order, as the reference's is."""
+    if SimMetaData.BMode.__name__ == "SimpleMDBC":
+        LoadMDBCNormals(SimParticles, ParticleNormalsPath)                       # :827
+    host_bytes = SimParticles.Position.dtype.itemsize
+    cfg = make_config(len(SimParticles), SimConstants, SimKernel, SimMetaData, SimViscosity,
+                      SimDensityDiffusion, device_float_bytes=device_float_bytes,
+                      host_float_bytes=host_bytes, device=device)
+    eng = (backend_factory or Engine)(cfg)
+    eng.upload_particles(SimParticles)
+    eng.set_clock(SimMetaData.Iteration, SimMetaData.TotalTime)
+    time_steps: List[float] = []
+    SimMetaData.OutputIterationCounter = 1                                       # :849
+    if on_output:
+        on_output(SimMetaData, SimParticles)                                     # :850
+    while True:                                                                  # :881
+        prog = eng.advance(next_output_time(SimMetaData))                        # :883
+        SimMetaData.Iteration = prog.iteration
+        SimMetaData.CurrentTimeStep = prog.last_dt
+        SimMetaData.TotalTime = prog.total_time
+        SimMetaData.IndexCounter = prog.index_counter
+        time_steps.append(prog.last_dt)                                          # :884
+        SimMetaData.OutputIterationCounter += 1                                  # :888
+        if on_output:
+            eng.download_into(SimParticles)
+            on_output(SimMetaData, SimParticles)                                 # :891-894
+        if SimMetaData.TotalTime > SimMetaData.SimulationTime:                   # :909
+            eng.download_into(SimParticles)
+            break
+    eng.close()
+    return time_steps
