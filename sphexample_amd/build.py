@@ -27,17 +27,22 @@ def is_stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not is_stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """extra_flags / $SPHMI_CXXFLAGS carry experiment switches such as -DSPHMI_KSLOTS=16."""
+    out = out or LIB
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("SPHMI_CXXFLAGS", "").split())
+    if not force and not is_stale() and out == LIB and not extra_flags:
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+           # the SLP vectoriser packs the distance tests into v_pk_*_f32 + v_mov shuffles (slower here)
+           "-fno-slp-vectorize",
            *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace sphmi {
 
@@ -32,8 +33,37 @@ template <> struct Vec4<float>  { using type = float4;  };
 template <> struct Vec4<double> { using type = double4; };
 
 constexpr int kWave = 64;
-constexpr int kSlots = 32;        // mask slots (64 candidates each) buffered in LDS per wave
-constexpr int kChunkGroup = 4;    // candidate chunks held in registers at once
+#ifndef SPHMI_KSLOTS
+#define SPHMI_KSLOTS 32
+#endif
+#ifndef SPHMI_ABL_NO_TLOOP
+#define SPHMI_ABL_NO_TLOOP 0
+#endif
+#ifndef SPHMI_ABL_RL
+#define SPHMI_ABL_RL 0
+#endif
+#ifndef SPHMI_ABL_WL
+#define SPHMI_ABL_WL 0
+#endif
+#ifndef SPHMI_ABL_NO_CONSUME
+#define SPHMI_ABL_NO_CONSUME 0
+#endif
+#ifndef SPHMI_PIPE
+#define SPHMI_PIPE 0
+#endif
+#ifndef SPHMI_ABL_NO_P2
+#define SPHMI_ABL_NO_P2 0
+#endif
+#ifndef SPHMI_RING_ROWS
+#define SPHMI_RING_ROWS 4
+#endif
+#ifndef SPHMI_CHUNKS
+#define SPHMI_CHUNKS 2
+#endif
+constexpr int kChunkGroup = SPHMI_CHUNKS;   // candidate chunks (64 each) per cell row held in registers / LDS slots
+
+static_assert(kChunkGroup == 1 || kChunkGroup == 2 || kChunkGroup == 4, "SPHMI_CHUNKS must be 1, 2 or 4");
+constexpr int kLogChunks = kChunkGroup == 4 ? 2 : (kChunkGroup == 2 ? 1 : 0);
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 
@@ -68,15 +98,44 @@ __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float  absT(float x)  { return __builtin_fabsf(x); }
 __device__ __forceinline__ double absT(double x) { return __builtin_fabs(x); }
 
-// v_writelane_b32 pair: lo[lane] = vlo, hi[lane] = vhi (vlo, vhi, lane wave-uniform).  clang exposes
-// no builtin for it.  On gfx9-class encodings a VOP3 may read one SGPR only, so the lane select goes
-// through M0; M0 is compiler-reserved, hence saved and restored inside the statement.
-__device__ __forceinline__ void writelane2(int& lo, int& hi, int vlo, int vhi, int lane) {
+// v_writelane_b32: dst[lane] = value (value, lane wave-uniform).  clang exposes no builtin for it.
+// On gfx9-class encodings a VOP3 may read one SGPR only, so the lane select goes through M0; M0 is
+// compiler-reserved, hence saved and restored inside the statement (one statement per target lane
+// covers the masks of all NCH candidate chunks).
+template <int NCH>
+__device__ __forceinline__ void writelanes(int (&lo)[NCH], int (&hi)[NCH], const int (&vlo)[NCH],
+                                           const int (&vhi)[NCH], int lane) {
     int keep;
-    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-        "v_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-        : "+v"(lo), "+v"(hi), "=&s"(keep)
-        : "s"(vlo), "s"(vhi), "s"(lane));
+    if constexpr (NCH == 1) {
+        asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+            : "+v"(lo[0]), "+v"(hi[0]), "=&s"(keep)
+            : "s"(vlo[0]), "s"(vhi[0]), "s"(lane));
+    } else if constexpr (NCH == 2) {
+        asm("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+            "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0\n\ts_mov_b32 m0, %4"
+            : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "=&s"(keep)
+            : "s"(vlo[0]), "s"(vhi[0]), "s"(vlo[1]), "s"(vhi[1]), "s"(lane));
+    } else if constexpr (NCH == 3) {
+        asm("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %13\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\t"
+            "v_writelane_b32 %2, %9, m0\n\tv_writelane_b32 %3, %10, m0\n\t"
+            "v_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0\n\ts_mov_b32 m0, %6"
+            : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "=&s"(keep)
+            : "s"(vlo[0]), "s"(vhi[0]), "s"(vlo[1]), "s"(vhi[1]), "s"(vlo[2]), "s"(vhi[2]), "s"(lane));
+    } else {
+        static_assert(NCH == 4, "writelanes: 1..4 chunks");
+        asm("s_mov_b32 %8, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %9, m0\n\tv_writelane_b32 %1, %10, m0\n\t"
+            "v_writelane_b32 %2, %11, m0\n\tv_writelane_b32 %3, %12, m0\n\t"
+            "v_writelane_b32 %4, %13, m0\n\tv_writelane_b32 %5, %14, m0\n\t"
+            "v_writelane_b32 %6, %15, m0\n\tv_writelane_b32 %7, %16, m0\n\ts_mov_b32 m0, %8"
+            : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]),
+              "+v"(hi[3]), "=&s"(keep)
+            : "s"(vlo[0]), "s"(vhi[0]), "s"(vlo[1]), "s"(vhi[1]), "s"(vlo[2]), "s"(vhi[2]), "s"(vlo[3]),
+              "s"(vhi[3]), "s"(lane));
+    }
 }
 
 __device__ __forceinline__ int rl_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -107,11 +166,16 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
     }
     return v;
 }
+// max-reduction of non-negative values through their bit patterns (monotone for v ≥ 0; NaN sorts last).
+// Almost every wave is below the running maximum already: test before paying for the atomic.
 __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, float v) {
-    atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
+    unsigned int* q = reinterpret_cast<unsigned int*>(p);
+    const unsigned int b = __float_as_uint(v);
+    if (b > __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q, b);
 }
 __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v) {
-    atomicMax(p, (unsigned long long)__double_as_longlong(v));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -122,8 +186,11 @@ __global__ void __launch_bounds__(kWave)
 k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    __shared__ unsigned long long s_mask[kSlots * kWave];
-    __shared__ int s_base[kSlots];
+    constexpr int RB = SPHMI_RING_ROWS;                    // cell rows buffered in the LDS ring
+    static_assert((RB & (RB - 1)) == 0 && (kChunkGroup & (kChunkGroup - 1)) == 0, "ring geometry: powers of two");
+    constexpr int NSLOT = RB * kChunkGroup;
+    __shared__ unsigned long long s_mask[NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
+    __shared__ int s_rowbase[RB * kWave];                  // [row % RB][lane] candidate index of bit 0, chunk 0
 
     const int lane = threadIdx.x;
     // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
@@ -159,134 +226,235 @@ k_neighbor_force(const ForceParams<T> P) {
     const T inv_rhon_a = (PASS == PASS_CORRECTOR) ? fast_rcp(rhon_a) : inv_rho_a;
     const T rm_a = rho_a * P.m0;
 
-    const int key_a = P.key[ac];
-    const int cs_a = P.cstart[key_a], ce_a = P.cstart[key_a + 1];
+    const int key_a = valid ? P.key[ac] : -1;
+    const int cs_a = P.cstart[valid ? key_a : 0], ce_a = P.cstart[valid ? key_a + 1 : 0];
     const int last_lane = min(kWave - 1, P.N - 1 - t0);
 
-    T drho = 0, ax = 0, ay = 0, az = 0;
-    int nslots = 0;
+    // Lanes are sorted by cell: a "run" = the lanes of one cell.  All targets of a run share the same
+    // candidate range per cell row, so the distance tests need no per-target range check, and a local
+    // origin (the run's first particle) makes the expanded form |c|² − 2c·t + |t|² safe in fp32.
+    const int key_prev = __shfl_up(key_a, 1, kWave);
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || key_a != key_prev));
+    const int r0_l = 63 - __builtin_clzll((heads & (~0ull >> (63 - lane))) | 1ull);
+    const T oxl = __shfl(xa, r0_l, kWave), oyl = __shfl(ya, r0_l, kWave), ozl = __shfl(za, r0_l, kWave);
+    const T txl = xa - oxl, tyl = ya - oyl, tzl = za - ozl;
+    // accept  |c − t|² ≤ H²(1+ε)  ⇔  |c|² − 2c·t ≤ H²(1+ε) − |t|² ; the exact test is redone in phase 2
+    const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
+    const T thr = P.H2 * T(1.0 + 1.0 / 1024.0) - (txl * txl + tyl * tyl + tzl * tzl);
 
-    // ---- phase 2: walk the buffered accept masks -------------------------------------------
-    auto drain = [&]() {
-        __syncthreads();
-        int s = 0, base = 0;
-        unsigned long long m = 0;
-        while (true) {
-            while (m == 0 && s < nslots) {
-                m = s_mask[s * kWave + lane];
-                base = s_base[s];
-                ++s;
-            }
-            if (m == 0) break;
-            const int j = base + __builtin_ctzll(m);
-            m &= m - 1;
-            const V4 n0 = P.src0[j];
-            const V4 n1 = P.src1[j];
-            const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
-            const T r2 = dx * dx + dy * dy + dz * dz;
-            T rho_b, rhon_b, P_b, s_b;
-            if constexpr (PASS == PASS_CORRECTOR) {
-                rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w;
-                P_b = eos7<T>(rho_b, P.rho0, P.inv_rho0, P.Cbe);
-            } else {
-                rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
-            }
-            // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280)
-            const T r = fast_sqrt(r2);
-            T qq = r * P.h_inv;
-            qq = qq > T(2) ? T(2) : qq;
-            const T tq = qq - T(2);
-            const T fac = P.Cgw * (tq * tq * tq);
-            const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
-            const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
-            const T inv_rho_b = fast_rcp(rho_b);
-            // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
-            drho += rm_a * inv_rho_b * (fac * vdx);
-            const T inv_r2e = fast_rcp(r2 + P.eta2);
-            if (P.ddt) {
-                // LinearDensityDiffusion, src/SPHDensityDiffusionModels.jl:116-133; orientation rule
-                // of SURVEY §8(a)-Q4: target plays "i" iff j sorts before its cell, or after it inside it
-                const T dlast = (D == 3) ? dz : dy;
-                const T drn = (rhon_b - rhon_a) - P.linfac * dlast;
-                const T psigw = T(-2) * drn * fac * r2 * inv_r2e;
-                const bool a_is_i = (j < cs_a) || (j > a && j < ce_a);
-                T inv_sel;
-                if constexpr (PASS == PASS_CORRECTOR) inv_sel = a_is_i ? fast_rcp(rhon_b) : inv_rhon_a;
-                else inv_sel = a_is_i ? inv_rho_b : inv_rho_a;
-                const T Dv = P.Kddt * inv_sel * psigw;
-                drho += (fluid_a && s_b > T(0)) ? Dv : T(0);
-            }
-            // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
-            T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
-            if (P.visc) {
-                // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
-                const T vneg = vdx < T(0) ? vdx : T(0);
-                coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
-            }
-            coef *= fac;
-            ax += coef * dx; ay += coef * dy; az += coef * dz;
+    T drho = 0, ax = 0, ay = 0, az = 0;
+
+    // ---- pair physics for one accepted neighbour j ------------------------------------------
+    auto pair = [&](const int j, const V4& n0, const V4& n1) {
+        const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
+        const T r2 = dx * dx + dy * dy + dz * dz;
+        T rho_b, rhon_b, P_b, s_b;
+        if constexpr (PASS == PASS_CORRECTOR) {
+            rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w;
+            P_b = eos7<T>(rho_b, P.rho0, P.inv_rho0, P.Cbe);
+        } else {
+            rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
         }
-        nslots = 0;
+        // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280);
+        // the phase-1 mask is slightly generous, the exact r² ≤ H² test of :275 is applied here
+        const T r = fast_sqrt(r2);
+        T qq = r * P.h_inv;
+        qq = qq > T(2) ? T(2) : qq;
+        const T tq = qq - T(2);
+        T fac = P.Cgw * (tq * tq * tq);
+        fac = r2 <= P.H2 ? fac : T(0);
+        const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
+        const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
+        const T inv_rho_b = fast_rcp(rho_b);
+        // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
+        drho += rm_a * inv_rho_b * (fac * vdx);
+        const T inv_r2e = fast_rcp(r2 + P.eta2);
+        if (P.ddt) {
+            // LinearDensityDiffusion, src/SPHDensityDiffusionModels.jl:116-133; orientation rule
+            // of SURVEY §8(a)-Q4: target plays "i" iff j sorts before its cell, or after it inside it
+            const T dlast = (D == 3) ? dz : dy;
+            const T drn = (rhon_b - rhon_a) - P.linfac * dlast;
+            const T psigw = T(-2) * drn * fac * r2 * inv_r2e;
+            const bool a_is_i = (j < cs_a) || (j > a && j < ce_a);
+            T inv_sel;
+            if constexpr (PASS == PASS_CORRECTOR) inv_sel = a_is_i ? fast_rcp(rhon_b) : inv_rhon_a;
+            else inv_sel = a_is_i ? inv_rho_b : inv_rho_a;
+            const T Dv = P.Kddt * inv_sel * psigw;
+            drho += (fluid_a && s_b > T(0)) ? Dv : T(0);
+        }
+        // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
+        T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
+        if (P.visc) {
+            // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
+            const T vneg = vdx < T(0) ? vdx : T(0);
+            coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
+        }
+        coef *= fac;
+        ax += coef * dx; ay += coef * dy; az += coef * dz;
+    };
+
+    // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
+    // The masks of the last RB cell rows live in an LDS ring ([row % RB][chunk][lane]).  Lanes consume
+    // at their own pace: a lane with few neighbours in the old rows runs ahead into the newer ones
+    // instead of idling, and a row slot is only recycled once EVERY lane is through with it.
+    int cs = 0;                      // next slot (absolute: row * K + chunk) this lane will fetch
+    int cbase = 0;                   // candidate index of bit 0 of the current mask
+    unsigned long long cm = 0;       // unconsumed bits of the current mask
+#if SPHMI_PIPE
+    // one gathered pair in flight per lane: { pj, p0, p1 } was taken from slot pslot and is evaluated one
+    // iteration later, so the gather latency overlaps the previous pair's arithmetic
+    bool phave = false;
+    int pj = 0, pslot = 0;
+    V4 p0{}, p1{};
+#endif
+    // consume until every lane has finished all slots below `upto` (slots < produced are readable)
+    auto consume = [&](const int upto, const int produced) {
+#if SPHMI_ABL_NO_CONSUME
+        ax += T(s_mask[lane] & 1);
+        return;
+#endif
+        __syncthreads();
+        while (true) {
+            const bool empty = cm == 0;
+            // a lane still owes old work if it has not fetched all slots < upto, or is inside one of them
+            bool owes = (cs < upto) | (!empty & (cs <= upto));
+#if SPHMI_PIPE
+            owes |= phave & (pslot < upto);
+#endif
+            if (!__builtin_amdgcn_ballot_w64(owes)) break;
+            if (empty & (cs < produced)) {
+                cm = s_mask[(cs & (NSLOT - 1)) * kWave + lane];
+                cbase = s_rowbase[((cs >> kLogChunks) & (RB - 1)) * kWave + lane] + ((cs & (kChunkGroup - 1)) << 6);
+                ++cs;
+            }
+#if SPHMI_PIPE
+            const bool chave = phave;
+            const int cj = pj;
+            const V4 c0 = p0, c1 = p1;
+            phave = cm != 0;
+            if (phave) {
+                pj = cbase + __builtin_ctzll(cm);
+                cm &= cm - 1;
+                pslot = cs - 1;
+                p0 = P.src0[pj];
+                p1 = P.src1[pj];
+            }
+            if (chave) pair(cj, c0, c1);
+#else
+            if (cm != 0) {
+                const int j = cbase + __builtin_ctzll(cm);
+                cm &= cm - 1;
+#if SPHMI_ABL_NO_P2
+                ax += T(j);
+#else
+                const V4 n0 = P.src0[j];
+                const V4 n1 = P.src1[j];
+                pair(j, n0, n1);
+#endif
+            }
+#endif
+        }
         __syncthreads();
     };
 
-    // ---- phase 1: accept masks, one cell row (3 x-adjacent cells per target) at a time ------
+    // ---- phase 1: accept masks --------------------------------------------------------------
+    // For one run and one cell row: NCH candidate chunks (one candidate per lane each, coalesced
+    // loads) live in registers while the run's targets are broadcast through SGPRs; the 64-bit compare
+    // result of target t IS its accept mask and is lane-transposed into lane t's registers.
+    auto scan = [&](auto nch_tag, const int gb, const int hi, const int r0, const int r1,
+                    int (&mlo)[kChunkGroup], int (&mhi)[kChunkGroup]) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        const T ox = rl(xa, r0), oy = rl(ya, r0), oz = rl(za, r0);
+        T cx[NCH], cy[NCH], cz[NCH], cc[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = gb + k * kWave + lane;
+            if (c < hi) {
+                const V4 cpk = P.src0[c];
+                cx[k] = cpk.x - ox; cy[k] = cpk.y - oy; cz[k] = cpk.z - oz;
+                cc[k] = cx[k] * cx[k] + cy[k] * cy[k] + cz[k] * cz[k];
+            } else {
+                cx[k] = T(0); cy[k] = T(0); cz[k] = T(0); cc[k] = T(1e30);
+            }
+        }
+        int wlo[NCH], whi[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { wlo[k] = mlo[k]; whi[k] = mhi[k]; }
+#if SPHMI_ABL_NO_TLOOP
+        for (int t = r0; t < r0; ++t) {
+#else
+#pragma unroll 2
+        for (int t = r0; t < r1; ++t) {
+#endif
+#if SPHMI_ABL_RL
+            const T sx = rl(m2x, r0) + T(t), sy = rl(m2y, r0), sz = rl(m2z, r0), st = rl(thr, r0);
+#else
+            const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
+#endif
+            int blo[NCH], bhi[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                T d = cx[k] * sx + cc[k];
+                d = cy[k] * sy + d;
+                d = cz[k] * sz + d;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d <= st);
+                blo[k] = (int)(unsigned)(bal & 0xffffffffull);
+                bhi[k] = (int)(unsigned)(bal >> 32);
+            }
+#if SPHMI_ABL_WL == 2
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { wlo[k] |= (lane == 0) ? blo[k] : 0; whi[k] ^= (lane == 1) ? bhi[k] : 0; }
+#elif SPHMI_ABL_WL == 1
+            writelanes<NCH>(wlo, whi, blo, bhi, 0);
+#else
+            writelanes<NCH>(wlo, whi, blo, bhi, t);
+#endif
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { mlo[k] = wlo[k]; mhi[k] = whi[k]; }
+    };
+
 #pragma unroll 1
-    for (int seg = 0; seg < NSEG; ++seg) {
-        const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
-                                 : (seg - 1) * P.nxp;
-        const int lo_l = valid ? P.cstart[key_a + off - 1] : 0x7fffffff;
-        const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
-        // keys are sorted, cstart is monotone: the union of the lanes' ranges is [lo(first), hi(last))
-        const int LO = rl_i(lo_l, 0);
-        const int HI = rl_i(hi_l, last_lane);
+    for (int g = 0;; ++g) {          // chunk-group passes: g > 0 only when a row range exceeds K·64 candidates
+        bool more = false;
+        cs = 0; cm = 0;   // (the pair pipeline is empty here: the previous pass was drained)
 #pragma unroll 1
-        for (int gbase = LO; gbase < HI; gbase += kChunkGroup * kWave) {
-            const int rem = HI - gbase;
-            const int nch = rem >= kChunkGroup * kWave ? kChunkGroup : (rem + kWave - 1) / kWave;
-            if (nslots + nch > kSlots) drain();
-            T cx[kChunkGroup], cy[kChunkGroup], cz[kChunkGroup];
+        for (int seg = 0; seg < NSEG; ++seg) {
+            // recycle ring position seg % RB: every lane must be through row seg − RB
+            if (seg >= RB) consume((seg - RB + 1) * kChunkGroup, seg * kChunkGroup);
+            const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
+                                     : (seg - 1) * P.nxp;
+            const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
+            const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
             int mlo[kChunkGroup], mhi[kChunkGroup];
 #pragma unroll
-            for (int k = 0; k < kChunkGroup; ++k) {
-                const int c = gbase + k * kWave + lane;
-                mlo[k] = 0; mhi[k] = 0;
-                if (k < nch && c < HI) {
-                    const V4 cpk = P.src0[c];
-                    cx[k] = cpk.x; cy[k] = cpk.y; cz[k] = cpk.z;
-                } else {
-                    cx[k] = T(1e30); cy[k] = T(1e30); cz[k] = T(1e30);
+            for (int k = 0; k < kChunkGroup; ++k) { mlo[k] = 0; mhi[k] = 0; }
+#pragma unroll 1
+            for (int r0 = 0; r0 <= last_lane;) {
+                const unsigned long long rest = heads >> r0 >> 1;          // heads after r0
+                const int r1 = rest ? r0 + 1 + __builtin_ctzll(rest) : last_lane + 1;
+                const int lo = rl_i(lo_l, r0), hi = rl_i(hi_l, r0);
+                const int gb = lo + g * kChunkGroup * kWave;
+                const int rem = hi - gb;
+                if (rem > 0) {
+                    if (rem > kChunkGroup * kWave) more = true;
+                    const int nch = rem >= kChunkGroup * kWave ? kChunkGroup : (rem + kWave - 1) / kWave;
+                    if (nch == 1) scan(std::integral_constant<int, 1>{}, gb, hi, r0, r1, mlo, mhi);
+                    if constexpr (kChunkGroup >= 2) if (nch == 2) scan(std::integral_constant<int, 2>{}, gb, hi, r0, r1, mlo, mhi);
+                    if constexpr (kChunkGroup >= 3) if (nch == 3) scan(std::integral_constant<int, 3>{}, gb, hi, r0, r1, mlo, mhi);
+                    if constexpr (kChunkGroup >= 4) if (nch == 4) scan(std::integral_constant<int, 4>{}, gb, hi, r0, r1, mlo, mhi);
                 }
+                r0 = r1;
             }
-#pragma unroll 4
-            for (int t = 0; t <= last_lane; ++t) {
-                const T tx = rl(xa, t), ty = rl(ya, t), tz = rl(za, t);
-                const int tlo = rl_i(lo_l, t);
-                const unsigned tw = (unsigned)(rl_i(hi_l, t) - tlo);
+            s_rowbase[(seg % RB) * kWave + lane] = lo_l + g * kChunkGroup * kWave;
 #pragma unroll
-                for (int k = 0; k < kChunkGroup; ++k) {
-                    if (k < nch) {
-                        const T ex = cx[k] - tx, ey = cy[k] - ty, ez = cz[k] - tz;
-                        const T r2 = ex * ex + ey * ey + ez * ez;
-                        const int c = gbase + k * kWave + lane;
-                        const bool in = (r2 <= P.H2) && ((unsigned)(c - tlo) < tw);
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
-                        writelane2(mlo[k], mhi[k], (int)(unsigned)(bal & 0xffffffffull), (int)(unsigned)(bal >> 32), t);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kChunkGroup; ++k) {
-                if (k < nch) {
-                    s_mask[(nslots + k) * kWave + lane] =
-                        ((unsigned long long)(unsigned)mhi[k] << 32) | (unsigned)mlo[k];
-                    if (lane == 0) s_base[nslots + k] = gbase + k * kWave;
-                }
-            }
-            nslots += nch;
+            for (int k = 0; k < kChunkGroup; ++k)
+                s_mask[((seg % RB) * kChunkGroup + k) * kWave + lane] =
+                    ((unsigned long long)(unsigned)mhi[k] << 32) | (unsigned)mlo[k];
         }
+        consume(NSEG * kChunkGroup, NSEG * kChunkGroup);
+        if (!more) break;
     }
-    drain();
 
     // ---- epilogue ---------------------------------------------------------------------------
     const uint8_t ty_a = P.type[ac];

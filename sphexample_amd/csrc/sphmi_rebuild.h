@@ -46,8 +46,9 @@ __global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type*
     for (int d = 0; d < 3; ++d) {
         int mn = wave_min_i(c[d]), mx = wave_max_i(c[d]);
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bbox[d], mn);
-            atomicMax(&bbox[3 + d], mx);
+            // almost every wave is inside the box already: test before paying for the atomic
+            if (mn < __hip_atomic_load(&bbox[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bbox[d], mn);
+            if (mx > __hip_atomic_load(&bbox[3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bbox[3 + d], mx);
         }
     }
 }

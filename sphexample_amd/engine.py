@@ -20,8 +20,8 @@ def load_library(rebuild_if_stale: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if rebuild_if_stale and _build.is_stale():
+    path = os.environ.get("SPHMI_LIB") or _build.LIB     # SPHMI_LIB: experiment builds (tools/sweep.py)
+    if path == _build.LIB and rebuild_if_stale and _build.is_stale():
         try:
             _build.build()
         except Exception as exc:  # no hipcc on the box: fall through to whatever is on disk
