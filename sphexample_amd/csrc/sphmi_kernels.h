@@ -58,7 +58,7 @@ constexpr int kWave = 64;
 #define SPHMI_RING_ROWS 4
 #endif
 #ifndef SPHMI_CHUNKS
-#define SPHMI_CHUNKS 2
+#define SPHMI_CHUNKS 4
 #endif
 constexpr int kChunkGroup = SPHMI_CHUNKS;   // candidate chunks (64 each) per cell row held in registers / LDS slots
 
@@ -181,25 +181,64 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 // ------------------------------------------------------------------------------------------
 // The neighbour + force kernel.
 // ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// v_permlane32_swap: returns { {p.lower, q.lower}, {p.upper, q.upper} } — the lane pattern both MFMA
+// operands want ("lanes 0-31: component k of item l, lanes 32-63: component k+1 of item l-32").
+__device__ __forceinline__ void swap_halves(float& p, float& q) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+    p = __uint_as_float(r[0]); q = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_halves(unsigned& p, unsigned& q) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(p, q, false, false);
+    p = r[0]; q = r[1];
+}
+
+#ifndef SPHMI_XCD_CHUNK
+#define SPHMI_XCD_CHUNK 0
+#endif
+#ifndef SPHMI_ABL_GATHER
+#define SPHMI_ABL_GATHER 0
+#endif
+#ifndef SPHMI_MIN_WAVES
+#define SPHMI_MIN_WAVES 1
+#endif
 template <class T, int D, int PASS>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kWave, SPHMI_MIN_WAVES)
 k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int RB = SPHMI_RING_ROWS;                    // cell rows buffered in the LDS ring
-    static_assert((RB & (RB - 1)) == 0 && (kChunkGroup & (kChunkGroup - 1)) == 0, "ring geometry: powers of two");
-    constexpr int NSLOT = RB * kChunkGroup;
+    constexpr int K = kChunkGroup;                         // 64-candidate chunks per row and pass
+    static_assert((RB & (RB - 1)) == 0 && (K & (K - 1)) == 0, "ring geometry: powers of two");
+    constexpr int NSLOT = RB * K;
     __shared__ unsigned long long s_mask[NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
-    __shared__ int s_rowbase[RB * kWave];                  // [row % RB][lane] candidate index of bit 0, chunk 0
+    __shared__ int s_lo[RB * kWave];                       // [row % RB][lane] the lane's own 3-cell range in that row
+    __shared__ int s_hi[RB * kWave];
+    __shared__ int s_gb[RB];                               // [row % RB] candidate index of bit 0 of chunk 0
 
     const int lane = threadIdx.x;
-    // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
-    // run of target tiles so neighbouring tiles (which share their source rows) share one L2.
+    // XCD-aware tile order.  The dispatcher places block b on XCD b % 8.  Tiles are handed out in
+    // chunks of SPHMI_XCD_CHUNK consecutive tiles per XCD, round-robin: inside a chunk neighbouring tiles
+    // (which share their source rows) share one L2, while the chunks interleave the cheap (boundary /
+    // surface) and expensive (fluid bulk) regions of the z-major sorted particle array over all 8 XCDs.
     int b = blockIdx.x;
+#if SPHMI_XCD_CHUNK > 0
+    {
+        constexpr int CH = SPHMI_XCD_CHUNK;
+        const int full = (P.nblocks / (8 * CH)) * (8 * CH);
+        if (b < full) {
+            const int x = b & 7, i = b >> 3;             // i-th block of XCD x
+            b = ((i / CH) * 8 + x) * CH + (i % CH);
+        }
+    }
+#elif SPHMI_XCD_CHUNK == 0
     {
         const int nb = P.nblocks, per = nb >> 3;
         if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
     }
+#endif
     const int t0 = b * kWave;
     const int a = t0 + lane;
     const bool valid = a < P.N;
@@ -226,26 +265,29 @@ k_neighbor_force(const ForceParams<T> P) {
     const T inv_rhon_a = (PASS == PASS_CORRECTOR) ? fast_rcp(rhon_a) : inv_rho_a;
     const T rm_a = rho_a * P.m0;
 
-    const int key_a = valid ? P.key[ac] : -1;
-    const int cs_a = P.cstart[valid ? key_a : 0], ce_a = P.cstart[valid ? key_a + 1 : 0];
+    const int key_a = P.key[ac];
+    const int cs_a = P.cstart[key_a], ce_a = P.cstart[key_a + 1];
     const int last_lane = min(kWave - 1, P.N - 1 - t0);
 
-    // Lanes are sorted by cell: a "run" = the lanes of one cell.  All targets of a run share the same
-    // candidate range per cell row, so the distance tests need no per-target range check, and a local
-    // origin (the run's first particle) makes the expanded form |c|² − 2c·t + |t|² safe in fp32.
-    const int key_prev = __shfl_up(key_a, 1, kWave);
-    const unsigned long long heads = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || key_a != key_prev));
-    const int r0_l = 63 - __builtin_clzll((heads & (~0ull >> (63 - lane))) | 1ull);
-    const T oxl = __shfl(xa, r0_l, kWave), oyl = __shfl(ya, r0_l, kWave), ozl = __shfl(za, r0_l, kWave);
-    const T txl = xa - oxl, tyl = ya - oyl, tzl = za - ozl;
-    // accept  |c − t|² ≤ H²(1+ε)  ⇔  |c|² − 2c·t ≤ H²(1+ε) − |t|² ; the exact test is redone in phase 2
+    // Phase 1 works in tile-local coordinates (origin = the tile's first particle) and in the expanded
+    // form  |c − t|² − H'² = |c|² − 2c·t + (|t|² − H'²)  with a slightly generous cut-off
+    // H'² = H²(1+ε); ε covers the fp32 cancellation error of the expanded form (≈ 4·2⁻²⁴·R², R = largest
+    // local coordinate).  Phase 2 redoes the exact r² ≤ H² test of src/SPHCellList.jl:275.
+    const T ox = rl(xa, 0), oy = rl(ya, 0), oz = rl(za, 0);
+    const T txl = xa - ox, tyl = ya - oy, tzl = za - oz;
+    const T tt = txl * txl + tyl * tyl + tzl * tzl;
+    T thr;
+    {
+        const T Rm = fast_sqrt(wave_max(valid ? tt : T(0))) + T(3) * P.h * T(2);
+        const T eps = T(1e-5) + T(1e-6) * (Rm * Rm) / P.H2;
+        thr = valid ? P.H2 * (T(1) + eps) - tt : T(-1e30);
+    }
     const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
-    const T thr = P.H2 * T(1.0 + 1.0 / 1024.0) - (txl * txl + tyl * tyl + tzl * tzl);
 
     T drho = 0, ax = 0, ay = 0, az = 0;
 
     // ---- pair physics for one accepted neighbour j ------------------------------------------
-    auto pair = [&](const int j, const V4& n0, const V4& n1) {
+    auto pair = [&](const int j, const V4& n0, const V4& n1, const bool in_range) {
         const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
         const T r2 = dx * dx + dy * dy + dz * dz;
         T rho_b, rhon_b, P_b, s_b;
@@ -255,14 +297,15 @@ k_neighbor_force(const ForceParams<T> P) {
         } else {
             rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
         }
-        // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280);
-        // the phase-1 mask is slightly generous, the exact r² ≤ H² test of :275 is applied here
+        // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280).
+        // The phase-1 mask is slightly generous and tile-wide: the exact r² ≤ H² test (:275) and the
+        // "candidate lies in MY three cells of this row" test of the reference's stale cell list are here.
         const T r = fast_sqrt(r2);
         T qq = r * P.h_inv;
         qq = qq > T(2) ? T(2) : qq;
         const T tq = qq - T(2);
         T fac = P.Cgw * (tq * tq * tq);
-        fac = r2 <= P.H2 ? fac : T(0);
+        fac = (r2 <= P.H2 && in_range) ? fac : T(0);
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
         const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
@@ -294,165 +337,185 @@ k_neighbor_force(const ForceParams<T> P) {
     };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
-    // The masks of the last RB cell rows live in an LDS ring ([row % RB][chunk][lane]).  Lanes consume
-    // at their own pace: a lane with few neighbours in the old rows runs ahead into the newer ones
-    // instead of idling, and a row slot is only recycled once EVERY lane is through with it.
+    // The masks of the last RB cell rows live in an LDS ring.  Lanes consume at their own pace: a lane
+    // with few neighbours in the old rows runs ahead into the newer ones instead of idling, and a ring
+    // row is only recycled once EVERY lane is through with it.
     int cs = 0;                      // next slot (absolute: row * K + chunk) this lane will fetch
-    int cbase = 0;                   // candidate index of bit 0 of the current mask
-    unsigned long long cm = 0;       // unconsumed bits of the current mask
+    int cbase = 0, clo = 0;          // candidate index of bit 0 of the current mask; own range start
 #if SPHMI_PIPE
-    // one gathered pair in flight per lane: { pj, p0, p1 } was taken from slot pslot and is evaluated one
-    // iteration later, so the gather latency overlaps the previous pair's arithmetic
-    bool phave = false;
-    int pj = 0, pslot = 0;
+    bool phave = false, pin = false; // one gathered neighbour in flight per lane
+    int pj = 0;
     V4 p0{}, p1{};
 #endif
-    // consume until every lane has finished all slots below `upto` (slots < produced are readable)
+    unsigned cwid = 0;               // own range width in the current row
+    unsigned long long cm = 0;       // unconsumed bits of the current mask
     auto consume = [&](const int upto, const int produced) {
 #if SPHMI_ABL_NO_CONSUME
-        ax += T(s_mask[lane] & 1);
+        ax += T(s_mask[lane] & 1) + T(s_lo[lane] + s_hi[lane] + s_gb[0]);
         return;
 #endif
         __syncthreads();
+        // a lane still owes old work if it has not fetched all slots < upto, or is inside one of them
+        auto any_owes = [&]() -> bool {
+            const bool owes = (cs < upto) | ((cm != 0) & (cs <= upto));
+            return __builtin_amdgcn_ballot_w64(owes) != 0;
+        };
+        auto refill = [&]() {
+            const bool need = (cm == 0) & (cs < produced);
+            const int rr = (cs >> kLogChunks) & (RB - 1);
+            const unsigned long long nm = s_mask[(cs & (NSLOT - 1)) * kWave + lane];
+            const int nlo = s_lo[rr * kWave + lane];
+            const int nhi = s_hi[rr * kWave + lane];
+            const int ngb = s_gb[rr] + ((cs & (K - 1)) << 6);
+            cm = need ? nm : cm;
+            cbase = need ? ngb : cbase;
+            clo = need ? nlo : clo;
+            cwid = need ? (unsigned)(nhi - nlo) : cwid;
+            cs += need ? 1 : 0;
+        };
+#if SPHMI_PIPE
+        // software pipeline: the gather of the next accepted neighbour is in flight while the previous
+        // one is evaluated.  Lanes fetch new bits only while some lane still owes old work, so the
+        // pipeline drains (one extra iteration) instead of running ahead through the whole ring.
         while (true) {
-            const bool empty = cm == 0;
-            // a lane still owes old work if it has not fetched all slots < upto, or is inside one of them
-            bool owes = (cs < upto) | (!empty & (cs <= upto));
-#if SPHMI_PIPE
-            owes |= phave & (pslot < upto);
-#endif
-            if (!__builtin_amdgcn_ballot_w64(owes)) break;
-            if (empty & (cs < produced)) {
-                cm = s_mask[(cs & (NSLOT - 1)) * kWave + lane];
-                cbase = s_rowbase[((cs >> kLogChunks) & (RB - 1)) * kWave + lane] + ((cs & (kChunkGroup - 1)) << 6);
-                ++cs;
+            const bool anyowes = any_owes();
+            if (!anyowes && !__builtin_amdgcn_ballot_w64(phave)) break;
+            bool nhave = false;
+            int nj = 0; bool nin = false;
+            V4 nn0{}, nn1{};
+            if (anyowes) {
+                refill();
+                if (cm != 0) {
+                    nj = cbase + __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    nn0 = P.src0[nj];
+                    nn1 = P.src1[nj];
+                    nin = (unsigned)(nj - clo) < cwid;
+                    nhave = true;
+                }
             }
-#if SPHMI_PIPE
-            const bool chave = phave;
-            const int cj = pj;
-            const V4 c0 = p0, c1 = p1;
-            phave = cm != 0;
-            if (phave) {
-                pj = cbase + __builtin_ctzll(cm);
-                cm &= cm - 1;
-                pslot = cs - 1;
-                p0 = P.src0[pj];
-                p1 = P.src1[pj];
-            }
-            if (chave) pair(cj, c0, c1);
+            if (phave) pair(pj, p0, p1, pin);
+            phave = nhave; pj = nj; pin = nin; p0 = nn0; p1 = nn1;
+        }
 #else
+        bool go = any_owes();
+        while (go) {
+            refill();
             if (cm != 0) {
                 const int j = cbase + __builtin_ctzll(cm);
                 cm &= cm - 1;
 #if SPHMI_ABL_NO_P2
                 ax += T(j);
 #else
+#if SPHMI_ABL_GATHER == 1      /* coalesced stand-in: every lane reads its own packet */
+                const V4 n0 = P.src0[ac + (j & 0)];
+                const V4 n1 = P.src1[ac + (j & 0)];
+#elif SPHMI_ABL_GATHER == 2    /* only pk0 gathered */
+                const V4 n0 = P.src0[j];
+                const V4 n1 = q1;
+#else
                 const V4 n0 = P.src0[j];
                 const V4 n1 = P.src1[j];
-                pair(j, n0, n1);
+#endif
+                pair(j, n0, n1, (unsigned)(j - clo) < cwid);
 #endif
             }
-#endif
+            go = any_owes();
         }
+#endif
         __syncthreads();
     };
 
-    // ---- phase 1: accept masks --------------------------------------------------------------
-    // For one run and one cell row: NCH candidate chunks (one candidate per lane each, coalesced
-    // loads) live in registers while the run's targets are broadcast through SGPRs; the 64-bit compare
-    // result of target t IS its accept mask and is lane-transposed into lane t's registers.
-    auto scan = [&](auto nch_tag, const int gb, const int hi, const int r0, const int r1,
-                    int (&mlo)[kChunkGroup], int (&mhi)[kChunkGroup]) {
-        constexpr int NCH = decltype(nch_tag)::value;
-        const T ox = rl(xa, r0), oy = rl(ya, r0), oz = rl(za, r0);
-        T cx[NCH], cy[NCH], cz[NCH], cc[NCH];
+    // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
+    // per lane (= per target).  fp32: the 64×64 matrix |c−t|² − H'² comes from the matrix cores
+    // (v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain): A = candidates × (cx, cy, cz, |c|², 1, 0),
+    // B = (−2tx, −2ty, −2tz, 1, |t|²−H'², 0) × targets.  A lane ends up with the 16 results of ITS target
+    // column for 16 candidate rows per 32×32 block; their sign bits are shifted into a word with
+    // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
+    // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
+    const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+    float B0[2], B1[2], B2[2], A2 = 0.f;
+    if constexpr (sizeof(T) == 4) {
+        B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
+        B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
+        B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
+        A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
+    }
+    auto scan_chunk = [&](const int cb, const int HI, const int slot) -> unsigned long long {
+        if constexpr (sizeof(T) == 4) {
+            const int c = cb + bperm;
+            const bool cv = c < HI;
+            const V4 cpk = P.src0[cv ? c : cb];
+            float A0[2], A1[2];
+            A0[0] = cpk.x - ox; A0[1] = cpk.y - oy; A1[0] = cpk.z - oz;
+            A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
+            swap_halves(A0[0], A0[1]);                              // [C]: {k0: cx | k1: cy}
+            swap_halves(A1[0], A1[1]);                              //      {k2: cz | k3: |c|²}
+            unsigned W[2] = {0u, 0u};
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int c = gb + k * kWave + lane;
-            if (c < hi) {
-                const V4 cpk = P.src0[c];
-                cx[k] = cpk.x - ox; cy[k] = cpk.y - oy; cz[k] = cpk.z - oz;
-                cc[k] = cx[k] * cx[k] + cy[k] * cy[k] + cz[k] * cz[k];
-            } else {
-                cx[k] = T(0); cy[k] = T(0); cz[k] = T(0); cc[k] = T(1e30);
+            for (int C = 1; C >= 0; --C) {
+#pragma unroll
+                for (int Tb = 0; Tb < 2; ++Tb) {
+                    f32x16 d = {0};
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[Tb], d, 0, 0, 0);
+#pragma unroll
+                    for (int r = 15; r >= 0; --r)
+                        W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
+                }
             }
-        }
-        int wlo[NCH], whi[NCH];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) { wlo[k] = mlo[k]; whi[k] = mhi[k]; }
-#if SPHMI_ABL_NO_TLOOP
-        for (int t = r0; t < r0; ++t) {
-#else
-#pragma unroll 2
-        for (int t = r0; t < r1; ++t) {
-#endif
-#if SPHMI_ABL_RL
-            const T sx = rl(m2x, r0) + T(t), sy = rl(m2y, r0), sz = rl(m2z, r0), st = rl(thr, r0);
-#else
-            const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
-#endif
-            int blo[NCH], bhi[NCH];
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                T d = cx[k] * sx + cc[k];
-                d = cy[k] * sy + d;
-                d = cz[k] * sz + d;
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d <= st);
-                blo[k] = (int)(unsigned)(bal & 0xffffffffull);
-                bhi[k] = (int)(unsigned)(bal >> 32);
+            swap_halves(W[0], W[1]);
+            return ((unsigned long long)W[1] << 32) | W[0];
+        } else {
+            // fp64 build: same matrix on the vector ALU, one target per iteration through SGPRs
+            const int c = cb + lane;
+            const bool cv = c < HI;
+            const V4 cpk = P.src0[cv ? c : cb];
+            const T cx = cpk.x - ox, cy = cpk.y - oy, cz = cpk.z - oz;
+            const T cc = cv ? cx * cx + cy * cy + cz * cz : T(1e300);
+            unsigned long long m = 0;
+#pragma unroll 1
+            for (int t = 0; t <= last_lane; ++t) {
+                const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
+                const T d = cz * sz + (cy * sy + (cx * sx + cc));
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d < st);
+                m = (lane == t) ? bal : m;
             }
-#if SPHMI_ABL_WL == 2
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) { wlo[k] |= (lane == 0) ? blo[k] : 0; whi[k] ^= (lane == 1) ? bhi[k] : 0; }
-#elif SPHMI_ABL_WL == 1
-            writelanes<NCH>(wlo, whi, blo, bhi, 0);
-#else
-            writelanes<NCH>(wlo, whi, blo, bhi, t);
-#endif
+            return m;
         }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) { mlo[k] = wlo[k]; mhi[k] = whi[k]; }
     };
 
 #pragma unroll 1
-    for (int g = 0;; ++g) {          // chunk-group passes: g > 0 only when a row range exceeds K·64 candidates
+    for (int g = 0;; ++g) {          // chunk-group passes: g > 0 only when a row holds more than K·64 candidates
         bool more = false;
-        cs = 0; cm = 0;   // (the pair pipeline is empty here: the previous pass was drained)
+        cs = 0; cm = 0;
 #pragma unroll 1
         for (int seg = 0; seg < NSEG; ++seg) {
             // recycle ring position seg % RB: every lane must be through row seg − RB
-            if (seg >= RB) consume((seg - RB + 1) * kChunkGroup, seg * kChunkGroup);
+            if (seg >= RB) consume((seg - RB + 1) * K, seg * K);
             const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
                                      : (seg - 1) * P.nxp;
+            // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
             const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
             const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
-            int mlo[kChunkGroup], mhi[kChunkGroup];
+            // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
+            const int gb = rl_i(lo_l, 0) + g * K * kWave;
+            const int HI = rl_i(hi_l, last_lane);
+            const int rem = HI - gb;
+            if (rem > K * kWave) more = true;
+            const int rr = seg & (RB - 1);
 #pragma unroll
-            for (int k = 0; k < kChunkGroup; ++k) { mlo[k] = 0; mhi[k] = 0; }
-#pragma unroll 1
-            for (int r0 = 0; r0 <= last_lane;) {
-                const unsigned long long rest = heads >> r0 >> 1;          // heads after r0
-                const int r1 = rest ? r0 + 1 + __builtin_ctzll(rest) : last_lane + 1;
-                const int lo = rl_i(lo_l, r0), hi = rl_i(hi_l, r0);
-                const int gb = lo + g * kChunkGroup * kWave;
-                const int rem = hi - gb;
-                if (rem > 0) {
-                    if (rem > kChunkGroup * kWave) more = true;
-                    const int nch = rem >= kChunkGroup * kWave ? kChunkGroup : (rem + kWave - 1) / kWave;
-                    if (nch == 1) scan(std::integral_constant<int, 1>{}, gb, hi, r0, r1, mlo, mhi);
-                    if constexpr (kChunkGroup >= 2) if (nch == 2) scan(std::integral_constant<int, 2>{}, gb, hi, r0, r1, mlo, mhi);
-                    if constexpr (kChunkGroup >= 3) if (nch == 3) scan(std::integral_constant<int, 3>{}, gb, hi, r0, r1, mlo, mhi);
-                    if constexpr (kChunkGroup >= 4) if (nch == 4) scan(std::integral_constant<int, 4>{}, gb, hi, r0, r1, mlo, mhi);
-                }
-                r0 = r1;
+            for (int k = 0; k < K; ++k) {
+                unsigned long long m = 0;
+                if (k * kWave < rem) m = scan_chunk(gb + k * kWave, HI, rr * K + k);
+                s_mask[(rr * K + k) * kWave + lane] = m;
             }
-            s_rowbase[(seg % RB) * kWave + lane] = lo_l + g * kChunkGroup * kWave;
-#pragma unroll
-            for (int k = 0; k < kChunkGroup; ++k)
-                s_mask[((seg % RB) * kChunkGroup + k) * kWave + lane] =
-                    ((unsigned long long)(unsigned)mhi[k] << 32) | (unsigned)mlo[k];
+            s_lo[rr * kWave + lane] = lo_l;
+            s_hi[rr * kWave + lane] = hi_l;
+            if (lane == 0) s_gb[rr] = gb;
         }
-        consume(NSEG * kChunkGroup, NSEG * kChunkGroup);
+        consume(NSEG * K, NSEG * K);
         if (!more) break;
     }
 
