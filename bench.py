@@ -14,7 +14,7 @@ kernels, parameters of example/Dambreak3d.jl.  For N > 1 the lattice is refined 
 ≈1.06 M particles (weak scaling; N = 8 is BASELINE config 4, dp = 0.002125, ≈7.7 M particles).
 
 Extra objects on the JSON line:
-  roofline     — dominant kernel (k_pair_pass): ALGORITHMIC bytes per launch ÷ its average launch
+  roofline     — dominant kernel (k_neighbor_force): ALGORITHMIC bytes per launch ÷ its average launch
                  duration (HIP events on the engine's stream) against the 8 TB/s HBM peak.
                  Algorithmic bytes: (11·D+5)·4+2 = 154 B per particle-update = 77 B per
                  particle per launch (two launches per update).  The kernel is VALU-bound by design
@@ -127,7 +127,7 @@ def main():
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_pair_pass", "avg_launch_ms": kern_ms, "launches": kern_launches,
+                         "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "valu": {"achieved_tflops": FLOP_PER_UPDATE_3D / 2.0 * n_local / (kern_ms * 1e-3) / 1e12
                                   if kern_ms > 0 else 0.0, "peak_tflops": FP32_PEAK_TFLOPS}},

@@ -34,11 +34,10 @@ struct EngineError : std::runtime_error {
 static thread_local std::string g_create_error;
 
 // Phase labels follow the reference's TimerOutputs sections (src/SPHCellList.jl:748-800).
-enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MASKS, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT };
+enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT };
 static const char* kPhaseNames[PH_COUNT] = {
-    "01 Update TimeStep", "02a Actual Calculate IndexCounter", "05a Neighbour masks (shared by 05 and 08)",
-    "04 Apply MDBC before Half TimeStep", "05 First NeighborLoop (+06/07 half step)",
-    "08 Second NeighborLoop (+09/10/11 full step)"};
+    "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
+    "05 First NeighborLoop (+06/07 half step)", "08 Second NeighborLoop (+09/10/11 full step)"};
 
 struct EngineBase {
     sphmi_config cfg{};
@@ -77,13 +76,10 @@ struct Engine final : EngineBase {
     int64_t cell_cap = 0;
     int *bbox_d = nullptr, *misc_d = nullptr;              // misc: [0] nonempty, [1] scan total
     unsigned long long* red_d = nullptr;
-    unsigned long long* masks = nullptr;                   // [tile][row][chunk][lane] accept masks
-    size_t masks_cap = 0;                                  // in 64-bit words
-    int kr = 4;                                            // chunks (64 candidates) stored per cell row
     int *bbox_h = nullptr, *misc_h = nullptr;
     unsigned long long* red_h = nullptr;
     GridDesc grid{};
-    bool have_grid = false, stepped = false;
+    bool have_grid = false, stepped = false, nonempty_pending = false;
     // timing
     struct Ev { hipEvent_t a, b; int phase; };
     std::vector<Ev> ev_pool, ev_pending;
@@ -113,8 +109,8 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&key[k], n * 4));
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
-        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, RED_COUNT * 8));
-        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, RED_COUNT * 8));
+        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 4 * 8));
+        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
     ~Engine() override {
         (void)hipSetDevice(cfg.device);
@@ -128,7 +124,7 @@ struct Engine final : EngineBase {
         }
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
-        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d); (void)hipFree(masks);
+        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -169,7 +165,6 @@ struct Engine final : EngineBase {
         P.accbuf = acc[cur];
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_d;
-        P.masks = masks; P.kr = kr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
         P.nblocks = (N + kWave - 1) / kWave;
         P.visc = cfg.viscosity == SPHMI_VISC_ARTIFICIAL;
@@ -190,25 +185,9 @@ struct Engine final : EngineBase {
 
     template <int PASS> void launch_force(const ForceParams<T>& P) {
         dim3 g(P.nblocks), b(kWave);
-        if (D == 3) hipLaunchKernelGGL((k_pair_pass<T, 3, PASS>), g, b, 0, stream, P);
-        else        hipLaunchKernelGGL((k_pair_pass<T, 2, PASS>), g, b, 0, stream, P);
+        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS>), g, b, 0, stream, P);
+        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS>), g, b, 0, stream, P);
         HC(hipGetLastError());
-    }
-
-    // Neighbour masks for the positions in set `src`, generous by `skin` (absolute distance).
-    void build_masks(int src, double skin) {
-        Ev ev = begin_phase(PH_MASKS);
-        MaskParams<T> M{};
-        M.src0 = pk0[src]; M.key = key[cur]; M.cstart = cstart; M.masks = masks; M.red = red_d;
-        M.N = N; M.nxp = grid.np[0]; M.nxyp = grid.np[0] * grid.np[1];
-        M.nblocks = (N + kWave - 1) / kWave;
-        M.kr = kr;
-        M.H2 = (T)cfg.H2; M.Hs2 = (T)((cfg.H + skin) * (cfg.H + skin)); M.h = (T)cfg.h;
-        dim3 g(M.nblocks), b(kWave);
-        if (D == 3) hipLaunchKernelGGL((k_neighbor_masks<T, 3>), g, b, 0, stream, M);
-        else        hipLaunchKernelGGL((k_neighbor_masks<T, 2>), g, b, 0, stream, M);
-        HC(hipGetLastError());
-        end_phase(ev);
     }
 
     // ---- UpdateNeighbors! -------------------------------------------------------------------
@@ -270,24 +249,8 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
         std::swap(iA, iB);
         cur = nxt;
-        // widest candidate range any tile sees in one cell row → chunks per row of the mask layout
-        {
-            const int ntile = (N + kWave - 1) / kWave;
-            const int nseg = D == 3 ? 9 : 3;
-            if (D == 3) hipLaunchKernelGGL((k_max_row_range<3>), dim3(nb256), dim3(256), 0, stream, key[cur], cstart, N, grid.np[0], grid.np[0] * grid.np[1], misc_d + 2);
-            else        hipLaunchKernelGGL((k_max_row_range<2>), dim3(nb256), dim3(256), 0, stream, key[cur], cstart, N, grid.np[0], grid.np[0] * grid.np[1], misc_d + 2);
-            HC(hipGetLastError());
-            HC(hipMemcpyAsync(misc_h, misc_d, 3 * 4, hipMemcpyDeviceToHost, stream));
-            HC(hipStreamSynchronize(stream));
-            index_counter = (int64_t)misc_h[0] + 1;
-            kr = std::max(1, (misc_h[2] + kWave - 1) / kWave);
-            const size_t need = (size_t)ntile * nseg * kr * kWave;
-            if (need > masks_cap) {
-                (void)hipFree(masks); masks = nullptr;
-                masks_cap = need + need / 8;
-                HC(hipMalloc(&masks, masks_cap * 8));
-            }
-        }
+        HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
+        nonempty_pending = true;
         have_grid = true;
         n_rebuilds += 1;
         end_phase(ev);
@@ -309,20 +272,19 @@ struct Engine final : EngineBase {
     void sync_and_collect() {
         HC(hipStreamSynchronize(stream));
         collect_events();
-
+        if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
     }
 
     // ---- one iteration of the while loop at src/SPHCellList.jl:742-802 -------------------------
     void step_once() {
         Ev ev = begin_phase(PH_TIMESTEP);
-        HC(hipMemcpyAsync(red_h, red_d, RED_COUNT * 8, hipMemcpyDeviceToHost, stream));
+        HC(hipMemcpyAsync(red_h, red_d, 4 * 8, hipMemcpyDeviceToHost, stream));
         end_phase(ev);
         sync_and_collect();
-        if (red_h[RED_BADRHO]) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
-        const double maxdisp = std::sqrt(decode(red_h[RED_DISP2]));
-        const double visc = decode(red_h[RED_VISC]);
-        const double amax = std::sqrt(decode(red_h[RED_ACC2]));
-        const double vmax = std::sqrt(decode(red_h[RED_VEL2]));
+        if (red_h[3]) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
+        const double maxdisp = std::sqrt(decode(red_h[0]));
+        const double visc = decode(red_h[1]);
+        const double amax = std::sqrt(decode(red_h[2]));
         delta_x += 4.0 * maxdisp;                                            // update_delta_x!, :706-724
         const double dt1 = std::sqrt(cfg.h / amax);                          // Δt, src/TimeStepping.jl:30-43
         const double dt2 = cfg.h / (cfg.c0 + visc);
@@ -334,18 +296,11 @@ struct Engine final : EngineBase {
             throw EngineError(SPHMI_ERR_NUMERIC, buf);
         }
         if (delta_x >= cfg.h) { rebuild(); delta_x = 0.0; }                   // :758-762
-        HC(hipMemsetAsync(red_d, 0, RED_COUNT * 8, stream));
-        // One mask build serves both passes: between them every particle moves by v·dt/2, so two
-        // particles approach by at most vmax·dt; a skin of that size keeps the masks a superset for the
-        // corrector.  (The pair pass applies the exact r² ≤ H² test, so the skin never changes a result.)
-        const double skin = vmax * dt * (1.0 + 1e-3) + 1e-6 * cfg.H;
-        const bool shared_masks = skin <= 0.1 * cfg.H && !std::isnan(skin);
-        build_masks(iA, shared_masks ? skin : 0.0);
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
         if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();                        // :772 (Pressure! of :771 is in pk1.w)
         Ev e1 = begin_phase(PH_PASS1);
         launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));          // :774-781
         end_phase(e1);
-        if (!shared_masks) build_masks(iH, 0.0);
         Ev e2 = begin_phase(PH_PASS2);
         launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));          // :789-798
         end_phase(e2);
@@ -417,7 +372,7 @@ struct Engine final : EngineBase {
         if (groups) HC(hipMemcpyAsync(grp[cur], groups, n * 8, hipMemcpyHostToDevice, stream));
         else HC(hipMemsetAsync(grp[cur], 0, n * 8, stream));
         HC(hipMemsetAsync(key[cur], 0, n * 4, stream));
-        HC(hipMemsetAsync(red_d, 0, RED_COUNT * 8, stream));
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
         const int nb256 = (N + 255) / 256;
         // Pressure! (src/SPHCellList.jl:835) and the reductions Δt / update_delta_x! will read first
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
@@ -502,7 +457,6 @@ struct Engine final : EngineBase {
                            (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
         if (apply_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();
         // the forces-only pass writes {a, dρ/dt} into a scratch set so SimParticles.Acceleration survives
-        build_masks(iA, 0.0);
         ForceParams<T> P = force_params(iA, iA, iH, 0.0);
         P.accbuf = pk0[iB];
         Ev e1 = begin_phase(PH_PASS1);
@@ -573,8 +527,8 @@ struct sphmi_handle { sphmi::EngineBase* e; };
 extern "C" {
 
 const char* sphmi_backend_info(void) {
-    return "sphmi abi 1 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_masks (fp32: MFMA distance matrix) + "
-           "pair_pass<fp32|fp64, 2D|3D>, counting-sort cell list, mDBC | no CPU fallback";
+    return "sphmi abi 1 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+           "counting-sort cell list, mDBC | no CPU fallback";
 }
 
 const char* sphmi_last_error(const sphmi_handle* h) {

@@ -5,28 +5,29 @@
 //   pk1[i] = { vx, vy, vz, P }  (state set "A"/"B")   or   { v⁺, ρⁿ·s } (half-step set "H")
 // 2-D runs keep z = vz = 0 and use component D−1 as the gravity / hydrostatic axis.
 //
-// Two kernels replace NeighborLoop! + ComputeInteractions! + ReductionStep! + HalfTimeStep /
+// k_neighbor_force replaces NeighborLoop! + ComputeInteractions! + ReductionStep! + HalfTimeStep /
 // FullTimeStep + LimitDensityAtBoundary! + DensityEpsi! + Pressure! + the Δt / Δx reductions of the
 // reference (src/SPHCellList.jl:168-217, 268-317, 367-381, 624-652, 706-724;
-// src/SimulationEquations.jl:9-42; src/TimeStepping.jl:24-46).  The unit of work is a TILE = 64
-// consecutive sorted particles = one wave.
+// src/SimulationEquations.jl:9-42; src/TimeStepping.jl:24-46) with ONE launch per pass.
 //
-//   k_neighbor_masks  (once per step)  "who can be within H".  For each of the 3^(D-1) cell rows
-//       around the tile, the three x-adjacent cells of every target are one contiguous particle range
-//       (x is the fastest sort axis); the union over the tile is scanned in 64-candidate chunks, one
-//       candidate per lane, loaded coalesced.  fp32: the 64×64 matrix |c−t|² − H'² of a chunk comes from
-//       the matrix cores (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain); every lane ends up with the
-//       results of ITS target, packs their sign bits with v_alignbit and stores a 64-bit accept mask per
-//       (row, chunk) to HBM.  H' = H + skin is slightly generous so that the same masks serve the
-//       predictor pass (positions xⁿ) and the corrector pass (positions xⁿ + vⁿ·dt/2).
-//   k_pair_pass  (predictor, corrector)  "pair physics".  Every lane walks the set bits of its own
-//       masks at its own pace, gathers the accepted neighbour packets, redoes the exact r² ≤ H² test and
-//       accumulates dρ/dt and acceleration — no divergence on the accept branch, no atomics, no LDS,
-//       every output written once — then runs the fused predictor or corrector and the wave-level
-//       max-reductions for Δt / Δx.
+// Mapping (one TILE = 64 consecutive sorted target particles = one wave = one workgroup):
+//   phase 1  "who is within H".  For each of the 3^(D-1) cell rows around the tile the three x-adjacent
+//            cells of every target are one contiguous particle range (x is the fastest sort axis); the
+//            union over the tile is scanned in 64-candidate chunks, one candidate per lane, loaded
+//            coalesced.  fp32: the 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores
+//            (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain); every lane ends up with the results of ITS
+//            target, packs their sign bits with v_alignbit and holds a 64-bit accept mask per chunk.
+//            fp64: the same matrix on the vector ALU, targets broadcast through SGPRs.
+//   phase 2  "pair physics".  The masks of the last few rows sit in an LDS ring; every lane walks the set
+//            bits of its own masks at its own pace, gathers the accepted neighbour packets, redoes the
+//            exact r² ≤ H² test and accumulates dρ/dt and acceleration — no divergence on the accept
+//            branch, no atomics, each output written once.
+//   epilogue predictor or corrector fused in; wave-level max-reductions for Δt / Δx.
+// Measured history and the experiments behind these choices: DESIGN.md §kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace sphmi {
 
@@ -35,27 +36,44 @@ template <> struct Vec4<float>  { using type = float4;  };
 template <> struct Vec4<double> { using type = double4; };
 
 constexpr int kWave = 64;
-constexpr int kMaxSeg = 9;
-
-#ifndef SPHMI_XCD_CONTIG
-#define SPHMI_XCD_CONTIG 1
+#ifndef SPHMI_ABL_NO_CONSUME
+#define SPHMI_ABL_NO_CONSUME 0
+#endif
+#ifndef SPHMI_ABL_NO_P2
+#define SPHMI_ABL_NO_P2 0
 #endif
 #ifndef SPHMI_RING_ROWS
-#define SPHMI_RING_ROWS 2
+#define SPHMI_RING_ROWS 4
 #endif
-#ifndef SPHMI_RING_CAP
-#define SPHMI_RING_CAP 256
+#ifndef SPHMI_CHUNKS
+#define SPHMI_CHUNKS 4
 #endif
-#ifndef SPHMI_ABL_GATHER
-#define SPHMI_ABL_GATHER 0
-#endif
-#ifndef SPHMI_ABL_NO_PAIR
-#define SPHMI_ABL_NO_PAIR 0
-#endif
+constexpr int kChunkGroup = SPHMI_CHUNKS;   // candidate chunks (64 each) per cell row held in registers / LDS slots
+
+static_assert(kChunkGroup == 1 || kChunkGroup == 2 || kChunkGroup == 4, "SPHMI_CHUNKS must be 1, 2 or 4");
+constexpr int kLogChunks = kChunkGroup == 4 ? 2 : (kChunkGroup == 2 ? 1 : 0);
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
-// reduction slots (bit patterns of non-negative values, see atomic_max_bits)
-enum { RED_DISP2 = 0, RED_VISC = 1, RED_ACC2 = 2, RED_BADRHO = 3, RED_VEL2 = 4, RED_MAXREM = 5, RED_COUNT = 8 };
+
+template <class T>
+struct ForceParams {
+    using V4 = typename Vec4<T>::type;
+    const V4* src0;      // neighbour stream packet 0 (A for pass 1, H for pass 2)
+    const V4* src1;      // neighbour stream packet 1
+    const V4* a0;        // state A (corrector epilogue)
+    const V4* a1;
+    V4* out0;            // H (predictor) or B (corrector)
+    V4* out1;
+    V4* accbuf;          // { a, dρ/dt }
+    const int* key;      // padded linear cell id of every sorted particle
+    const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
+    const uint8_t* type;
+    unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
+    int N, nxp, nxyp, nblocks;
+    int visc, ddt;
+    T dt, dt2;
+    T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
+};
 
 // ------------------------------------------------------------------------------------------
 // small helpers
@@ -108,6 +126,9 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
     if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
 }
 
+// ------------------------------------------------------------------------------------------
+// The neighbour + force kernel.
+// ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -122,199 +143,30 @@ __device__ __forceinline__ void swap_halves(unsigned& p, unsigned& q) {
     p = r[0]; q = r[1];
 }
 
-// XCD-aware tile order.  The dispatcher places block b on XCD b % 8; every XCD gets one contiguous
-// run of tiles so that neighbouring tiles (which share their source rows) share one L2.  Measured on
-// the 1 M-particle dam break: contiguous 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
-__device__ __forceinline__ int tile_of_block(int b, int nblocks) {
-#if SPHMI_XCD_CONTIG
-    const int per = nblocks >> 3;
-    if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
-#endif
-    return b;
-}
-
-// candidate range of `seg`-th cell row around a particle with padded cell id `key`: the three x-adjacent
-// cells are one contiguous index range [cstart[key+off−1], cstart[key+off+2])
-template <int D> __device__ __forceinline__ int row_offset(int seg, int nxp, int nxyp) {
-    return (D == 3) ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
-}
-
-// ==========================================================================================
-// K1: neighbour masks
-// ==========================================================================================
-template <class T>
-struct MaskParams {
-    using V4 = typename Vec4<T>::type;
-    const V4* src0;             // positions the masks are built from
-    const int* key;             // padded linear cell id of every sorted particle
-    const int* cstart;          // exclusive scan of cell counts, ncell+1 entries
-    unsigned long long* masks;  // [tile][row][chunk][lane]
-    unsigned long long* red;
-    int N, nxp, nxyp, nblocks;
-    int kr;                     // chunks (64 candidates each) stored per row
-    T H2;                       // exact cut-off²
-    T Hs2;                      // (H + skin)²
-    T h;
-};
-
-template <class T, int D>
-__global__ void __launch_bounds__(kWave)
-k_neighbor_masks(const MaskParams<T> P) {
-    using V4 = typename Vec4<T>::type;
-    constexpr int NSEG = (D == 3) ? 9 : 3;
-    const int lane = threadIdx.x;
-    const int tile = tile_of_block(blockIdx.x, P.nblocks);
-    const int t0 = tile * kWave;
-    const int a = t0 + lane;
-    const bool valid = a < P.N;
-    const int ac = valid ? a : P.N - 1;
-    const int last_lane = min(kWave - 1, P.N - 1 - t0);
-
-    const V4 q0 = P.src0[ac];
-    const T xa = q0.x, ya = q0.y, za = q0.z;
-    const int key_a = P.key[ac];
-
-    // Tile-local coordinates (origin = the tile's first particle) and the expanded form
-    //   |c − t|² − H'² = |c|² − 2c·t + (|t|² − H'²),   H'² = (H + skin)²·(1 + ε);
-    // ε covers the fp32 cancellation error of the expanded form (≈ 4·2⁻²⁴·R², R = largest local
-    // coordinate).  The pair pass redoes the exact r² ≤ H² test of src/SPHCellList.jl:275.
-    const T ox = rl(xa, 0), oy = rl(ya, 0), oz = rl(za, 0);
-    const T txl = xa - ox, tyl = ya - oy, tzl = za - oz;
-    const T tt = txl * txl + tyl * tyl + tzl * tzl;
-    T thr;
-    {
-        const T Rm = fast_sqrt(wave_max(valid ? tt : T(0))) + T(6) * P.h;
-        const T eps = T(1e-5) + T(1e-6) * (Rm * Rm) / P.H2;
-        thr = valid ? P.Hs2 * (T(1) + eps) - tt : T(-1e30);
-    }
-    const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
-
-    // fp32: MFMA operands.  A = candidates × (cx, cy, cz, |c|², 1, 0),  B = (−2tx, −2ty, −2tz, 1,
-    // |t|²−H'², 0) × targets, three K=2 steps per 32×32 block.  A lane ends up with the 16 results of ITS
-    // target column for 16 candidate rows per block; sign bit set ⇔ accepted.  The candidates are loaded
-    // lane-permuted (bperm) so that bit b of the final mask is candidate cb + b.
-    const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
-    float B0[2] = {0.f, 0.f}, B1[2] = {0.f, 0.f}, B2[2] = {0.f, 0.f}, A2 = 0.f;
-    if constexpr (sizeof(T) == 4) {
-        B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [target block]: {k0: −2tx | k1: −2ty}
-        B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //                 {k2: −2tz | k3: 1}
-        B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //                 {k4: |t|²−H'² | k5: 0}
-        A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates:     {k4: 1 | k5: 0}
-    }
-
-    auto scan_chunk = [&](const int cb, const int HI) -> unsigned long long {
-        if constexpr (sizeof(T) == 4) {
-            const int c = cb + bperm;
-            const bool cv = c < HI;
-            const V4 cpk = P.src0[cv ? c : cb];
-            float A0[2], A1[2];
-            A0[0] = cpk.x - ox; A0[1] = cpk.y - oy; A1[0] = cpk.z - oz;
-            A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
-            swap_halves(A0[0], A0[1]);                              // [candidate block]: {k0: cx | k1: cy}
-            swap_halves(A1[0], A1[1]);                              //                    {k2: cz | k3: |c|²}
-            unsigned W[2] = {0u, 0u};
-#pragma unroll
-            for (int C = 1; C >= 0; --C) {
-#pragma unroll
-                for (int Tb = 0; Tb < 2; ++Tb) {
-                    f32x16 d = {0};
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[Tb], d, 0, 0, 0);
-#pragma unroll
-                    for (int r = 15; r >= 0; --r)
-                        W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
-                }
-            }
-            swap_halves(W[0], W[1]);
-            return ((unsigned long long)W[1] << 32) | W[0];
-        } else {
-            // fp64 build: the same matrix on the vector ALU, one target per iteration through SGPRs
-            const int c = cb + lane;
-            const bool cv = c < HI;
-            const V4 cpk = P.src0[cv ? c : cb];
-            const T cx = cpk.x - ox, cy = cpk.y - oy, cz = cpk.z - oz;
-            const T cc = cv ? cx * cx + cy * cy + cz * cz : T(1e300);
-            unsigned long long m = 0;
-#pragma unroll 1
-            for (int t = 0; t <= last_lane; ++t) {
-                const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
-                const T d = cz * sz + (cy * sy + (cx * sx + cc));
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d < st);
-                m = (lane == t) ? bal : m;
-            }
-            return m;
-        }
-    };
-
-    // Lanes are sorted by cell: a "run" = the lanes of one cell.  All targets of a run share the same
-    // candidate range in every cell row, so a chunk scanned for a run needs no per-target range test; the
-    // other lanes of the tile simply ignore that chunk's result.  (Scanning the UNION range of the tile
-    // instead would be cheaper for bulk fluid but explodes on sparse wall tiles whose runs lie far apart.)
-    const int key_prev = __shfl_up(key_a, 1, kWave);
-    const unsigned long long heads = __builtin_amdgcn_ballot_w64(valid && (lane == 0 || key_a != key_prev));
-
-    unsigned long long* out = P.masks + (size_t)tile * NSEG * P.kr * kWave + lane;
-#pragma unroll 1
-    for (int seg = 0; seg < NSEG; ++seg) {
-        const int off = row_offset<D>(seg, P.nxp, P.nxyp);
-        const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
-        const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
-#pragma unroll 1
-        for (int k = 0; k < P.kr; ++k) {
-            unsigned long long m = 0;
-#pragma unroll 1
-            for (int r0 = 0; r0 <= last_lane;) {
-                const unsigned long long rest = heads >> r0 >> 1;          // heads after r0
-                const int r1 = rest ? r0 + 1 + __builtin_ctzll(rest) : last_lane + 1;
-                const int cb = rl_i(lo_l, r0) + k * kWave;
-                const int hi = rl_i(hi_l, r0);
-                if (cb < hi) {
-                    const unsigned long long mr = scan_chunk(cb, hi);
-                    m = (lane >= r0 && lane < r1) ? mr : m;
-                }
-                r0 = r1;
-            }
-            out[(size_t)(seg * P.kr + k) * kWave] = m;
-        }
-    }
-}
-
-// ==========================================================================================
-// K2: pair pass
-// ==========================================================================================
-template <class T>
-struct ForceParams {
-    using V4 = typename Vec4<T>::type;
-    const V4* src0;      // neighbour stream packet 0 (A for pass 1, H for pass 2)
-    const V4* src1;      // neighbour stream packet 1
-    const V4* a0;        // state A (corrector epilogue)
-    const V4* a1;
-    V4* out0;            // H (predictor) or B (corrector)
-    V4* out1;
-    V4* accbuf;          // { a, dρ/dt }
-    const int* key;
-    const int* cstart;
-    const uint8_t* type;
-    const unsigned long long* masks;
-    unsigned long long* red;
-    int N, nxp, nxyp, nblocks;
-    int kr;
-    int visc, ddt;
-    T dt, dt2;
-    T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
-};
-
 template <class T, int D, int PASS>
 __global__ void __launch_bounds__(kWave)
-k_pair_pass(const ForceParams<T> P) {
+k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    __shared__ int s_lo[kMaxSeg * kWave];   // [row][lane] first candidate of the lane's three cells in that row
+    constexpr int RB = SPHMI_RING_ROWS;                    // cell rows buffered in the LDS ring
+    constexpr int K = kChunkGroup;                         // 64-candidate chunks per row and pass
+    static_assert((RB & (RB - 1)) == 0 && (K & (K - 1)) == 0, "ring geometry: powers of two");
+    constexpr int NSLOT = RB * K;
+    __shared__ unsigned long long s_mask[NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
+    __shared__ int s_lo[RB * kWave];                       // [row % RB][lane] the lane's own 3-cell range in that row
+    __shared__ int s_hi[RB * kWave];
+    __shared__ int s_gb[RB];                               // [row % RB] candidate index of bit 0 of chunk 0
 
     const int lane = threadIdx.x;
-    const int tile = tile_of_block(blockIdx.x, P.nblocks);
-    const int t0 = tile * kWave;
+    // XCD-aware tile order.  The dispatcher places block b on XCD b % 8; every XCD gets one contiguous
+    // run of tiles so that neighbouring tiles (which share their source rows) share one L2.  Measured on
+    // the 1 M-particle dam break: contiguous 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
+    int b = blockIdx.x;
+    {
+        const int nb = P.nblocks, per = nb >> 3;
+        if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
+    const int t0 = b * kWave;
     const int a = t0 + lane;
     const bool valid = a < P.N;
     const int ac = valid ? a : P.N - 1;
@@ -342,15 +194,27 @@ k_pair_pass(const ForceParams<T> P) {
 
     const int key_a = P.key[ac];
     const int cs_a = P.cstart[key_a], ce_a = P.cstart[key_a + 1];
-#pragma unroll
-    for (int seg = 0; seg < NSEG; ++seg)
-        s_lo[seg * kWave + lane] = P.cstart[key_a + row_offset<D>(seg, P.nxp, P.nxyp) - 1];
-    __syncthreads();
+    const int last_lane = min(kWave - 1, P.N - 1 - t0);
+
+    // Phase 1 works in tile-local coordinates (origin = the tile's first particle) and in the expanded
+    // form  |c − t|² − H'² = |c|² − 2c·t + (|t|² − H'²)  with a slightly generous cut-off
+    // H'² = H²(1+ε); ε covers the fp32 cancellation error of the expanded form (≈ 4·2⁻²⁴·R², R = largest
+    // local coordinate).  Phase 2 redoes the exact r² ≤ H² test of src/SPHCellList.jl:275.
+    const T ox = rl(xa, 0), oy = rl(ya, 0), oz = rl(za, 0);
+    const T txl = xa - ox, tyl = ya - oy, tzl = za - oz;
+    const T tt = txl * txl + tyl * tyl + tzl * tzl;
+    T thr;
+    {
+        const T Rm = fast_sqrt(wave_max(valid ? tt : T(0))) + T(3) * P.h * T(2);
+        const T eps = T(1e-5) + T(1e-6) * (Rm * Rm) / P.H2;
+        thr = valid ? P.H2 * (T(1) + eps) - tt : T(-1e30);
+    }
+    const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
 
     T drho = 0, ax = 0, ay = 0, az = 0;
 
     // ---- pair physics for one accepted neighbour j ------------------------------------------
-    auto pair = [&](const int j, const V4& n0, const V4& n1) {
+    auto pair = [&](const int j, const V4& n0, const V4& n1, const bool in_range) {
         const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
         const T r2 = dx * dx + dy * dy + dz * dz;
         T rho_b, rhon_b, P_b, s_b;
@@ -361,13 +225,14 @@ k_pair_pass(const ForceParams<T> P) {
             rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
         }
         // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280).
-        // The masks are slightly generous: the exact r² ≤ H² test (:275) is applied here.
+        // The phase-1 mask is slightly generous and tile-wide: the exact r² ≤ H² test (:275) and the
+        // "candidate lies in MY three cells of this row" test of the reference's stale cell list are here.
         const T r = fast_sqrt(r2);
         T qq = r * P.h_inv;
         qq = qq > T(2) ? T(2) : qq;
         const T tq = qq - T(2);
         T fac = P.Cgw * (tq * tq * tq);
-        fac = r2 <= P.H2 ? fac : T(0);
+        fac = (r2 <= P.H2 && in_range) ? fac : T(0);
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
         const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
@@ -398,99 +263,148 @@ k_pair_pass(const ForceParams<T> P) {
         ax += coef * dx; ay += coef * dy; az += coef * dz;
     };
 
-    // ---- every lane walks the set bits of its own masks --------------------------------------
-    // Uncoalesced 16-byte gathers run at ≈16 B/clk per CU through the texture addresser — measured,
-    // they were 80 % of this kernel (0.94 ms → 0.19 ms without them).  So the candidate packets of the
-    // cell row being consumed are staged in LDS with coalesced loads and the per-pair gathers become
-    // ds_read_b128.  The rows sit in a ring of RB rows; lanes consume at their own pace (a lane with few
-    // neighbours in an old row runs ahead into the newer ones instead of idling) and a ring position is
-    // only refilled once EVERY lane is through with the row it held.  A row whose tile-wide candidate
-    // range exceeds the ring capacity (sparse wall tiles whose cells lie far apart) is read from global
-    // memory instead.
-    {
-        constexpr int RB = SPHMI_RING_ROWS;          // rows in the LDS ring
-        constexpr int CAP = SPHMI_RING_CAP;          // candidates per ring row
-        __shared__ V4 s_c0[RB * CAP];
-        __shared__ V4 s_c1[RB * CAP];
-        __shared__ int s_off[kMaxSeg + 1];           // per row: ring offset − first staged candidate, or INT_MIN: not staged
-
-        const unsigned long long* mp = P.masks + (size_t)tile * NSEG * P.kr * kWave + lane;
-        const int nslot = NSEG * P.kr;
-        const int last_lane = min(kWave - 1, P.N - 1 - t0);
-        int cs = 0;                      // slots fetched so far
-        int crow = 0, ck = 0;            // row / chunk of slot cs
-        int cbase = 0;                   // candidate index of bit 0 of the current mask
-        int coff = 0;                    // LDS index = candidate index + coff (INT_MIN: read global memory)
-        unsigned long long cm = 0;       // unconsumed bits of the current mask
-        unsigned long long nm = mp[0];   // mask of slot cs (prefetched)
-
-        // consume until every lane is through with all rows < upto_row; rows < staged_rows are available
-        auto consume = [&](const int upto_row, const int staged_rows) {
-            const int upto = upto_row * P.kr, avail = staged_rows * P.kr;
-            __syncthreads();
-            auto any_owes = [&]() -> bool {
-                const bool owes = (cs < upto) | ((cm != 0) & (cs <= upto));
-                return __builtin_amdgcn_ballot_w64(owes) != 0;
-            };
-            bool go = any_owes();
-            while (go) {
-                {
-                    const bool need = (cm == 0) & (cs < avail);
-                    const int rowc = crow < NSEG ? crow : 0;
-                    const int nb = s_lo[rowc * kWave + lane] + (ck << 6);
-                    const int no = s_off[rowc];
-                    cm = need ? nm : cm;
-                    cbase = need ? nb : cbase;
-                    coff = need ? no : coff;
-                    cs += need ? 1 : 0;
-                    ck += need ? 1 : 0;
-                    const bool wrap = ck == P.kr;
-                    crow += wrap ? 1 : 0;
-                    ck = wrap ? 0 : ck;
-                    if (need & (cs < nslot)) nm = mp[(size_t)cs * kWave];
-                }
-                if (cm != 0) {
-                    const int j = cbase + __builtin_ctzll(cm);
-                    cm &= cm - 1;
-#if SPHMI_ABL_NO_PAIR
-                    ax += T(j + coff);
-#else
-                    V4 n0, n1;
-#if SPHMI_ABL_GATHER == 2
-                    n0 = q0; n1 = q1; n0.x += T(j + coff);
-#elif SPHMI_ABL_GATHER == 3
-                    n0 = s_c0[(j + coff) & 63]; n1 = s_c1[lane];
-#else
-                    if (coff != INT32_MIN) { n0 = s_c0[j + coff]; n1 = s_c1[j + coff]; }
-                    else { n0 = P.src0[j]; n1 = P.src1[j]; }
+    // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
+    // The masks of the last RB cell rows live in an LDS ring.  Lanes consume at their own pace: a lane
+    // with few neighbours in the old rows runs ahead into the newer ones instead of idling, and a ring
+    // row is only recycled once EVERY lane is through with it.
+    int cs = 0;                      // next slot (absolute: row * K + chunk) this lane will fetch
+    int cbase = 0, clo = 0;          // candidate index of bit 0 of the current mask; own range start
+    unsigned cwid = 0;               // own range width in the current row
+    unsigned long long cm = 0;       // unconsumed bits of the current mask
+    auto consume = [&](const int upto, const int produced) {
+#if SPHMI_ABL_NO_CONSUME
+        ax += T(s_mask[lane] & 1) + T(s_lo[lane] + s_hi[lane] + s_gb[0]);
+        return;
 #endif
-                    pair(j, n0, n1);
-#endif
-                }
-                go = any_owes();
-            }
-            __syncthreads();
+        __syncthreads();
+        // a lane still owes old work if it has not fetched all slots < upto, or is inside one of them
+        auto any_owes = [&]() -> bool {
+            const bool owes = (cs < upto) | ((cm != 0) & (cs <= upto));
+            return __builtin_amdgcn_ballot_w64(owes) != 0;
         };
+        auto refill = [&]() {
+            const bool need = (cm == 0) & (cs < produced);
+            const int rr = (cs >> kLogChunks) & (RB - 1);
+            const unsigned long long nm = s_mask[(cs & (NSLOT - 1)) * kWave + lane];
+            const int nlo = s_lo[rr * kWave + lane];
+            const int nhi = s_hi[rr * kWave + lane];
+            const int ngb = s_gb[rr] + ((cs & (K - 1)) << 6);
+            cm = need ? nm : cm;
+            cbase = need ? ngb : cbase;
+            clo = need ? nlo : clo;
+            cwid = need ? (unsigned)(nhi - nlo) : cwid;
+            cs += need ? 1 : 0;
+        };
+        bool go = any_owes();
+        while (go) {
+            refill();
+            if (cm != 0) {
+                const int j = cbase + __builtin_ctzll(cm);
+                cm &= cm - 1;
+#if SPHMI_ABL_NO_P2
+                ax += T(j);
+#else
+                const V4 n0 = P.src0[j];
+                const V4 n1 = P.src1[j];
+                pair(j, n0, n1, (unsigned)(j - clo) < cwid);
+#endif
+            }
+            go = any_owes();
+        }
+        __syncthreads();
+    };
 
-#pragma unroll 1
-        for (int row = 0; row < NSEG; ++row) {
-            if (row >= RB) consume(row - RB + 1, row);
-            // stage the tile-wide candidate range of this row: [lo(first lane), hi(last lane))
-            const int off = row_offset<D>(row, P.nxp, P.nxyp);
-            const int LO = P.cstart[rl_i(key_a, 0) + off - 1];
-            const int HI = P.cstart[rl_i(key_a, last_lane) + off + 2];
-            const int n = HI - LO;
-            const int rpos = (row % RB) * CAP;
-            if (n <= CAP) {
-#pragma unroll 1
-                for (int i = lane; i < n; i += kWave) {
-                    s_c0[rpos + i] = P.src0[LO + i];
-                    s_c1[rpos + i] = P.src1[LO + i];
+    // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
+    // per lane (= per target).  fp32: the 64×64 matrix |c−t|² − H'² comes from the matrix cores
+    // (v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain): A = candidates × (cx, cy, cz, |c|², 1, 0),
+    // B = (−2tx, −2ty, −2tz, 1, |t|²−H'², 0) × targets.  A lane ends up with the 16 results of ITS target
+    // column for 16 candidate rows per 32×32 block; their sign bits are shifted into a word with
+    // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
+    // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
+    const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+    float B0[2], B1[2], B2[2], A2 = 0.f;
+    if constexpr (sizeof(T) == 4) {
+        B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
+        B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
+        B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
+        A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
+    }
+    auto scan_chunk = [&](const int cb, const int HI, const int slot) -> unsigned long long {
+        if constexpr (sizeof(T) == 4) {
+            const int c = cb + bperm;
+            const bool cv = c < HI;
+            const V4 cpk = P.src0[cv ? c : cb];
+            float A0[2], A1[2];
+            A0[0] = cpk.x - ox; A0[1] = cpk.y - oy; A1[0] = cpk.z - oz;
+            A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
+            swap_halves(A0[0], A0[1]);                              // [C]: {k0: cx | k1: cy}
+            swap_halves(A1[0], A1[1]);                              //      {k2: cz | k3: |c|²}
+            unsigned W[2] = {0u, 0u};
+#pragma unroll
+            for (int C = 1; C >= 0; --C) {
+#pragma unroll
+                for (int Tb = 0; Tb < 2; ++Tb) {
+                    f32x16 d = {0};
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[Tb], d, 0, 0, 0);
+#pragma unroll
+                    for (int r = 15; r >= 0; --r)
+                        W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
                 }
             }
-            if (lane == 0) s_off[row] = n <= CAP ? rpos - LO : INT32_MIN;
+            swap_halves(W[0], W[1]);
+            return ((unsigned long long)W[1] << 32) | W[0];
+        } else {
+            // fp64 build: same matrix on the vector ALU, one target per iteration through SGPRs
+            const int c = cb + lane;
+            const bool cv = c < HI;
+            const V4 cpk = P.src0[cv ? c : cb];
+            const T cx = cpk.x - ox, cy = cpk.y - oy, cz = cpk.z - oz;
+            const T cc = cv ? cx * cx + cy * cy + cz * cz : T(1e300);
+            unsigned long long m = 0;
+#pragma unroll 1
+            for (int t = 0; t <= last_lane; ++t) {
+                const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
+                const T d = cz * sz + (cy * sy + (cx * sx + cc));
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d < st);
+                m = (lane == t) ? bal : m;
+            }
+            return m;
         }
-        consume(NSEG, NSEG);
+    };
+
+#pragma unroll 1
+    for (int g = 0;; ++g) {          // chunk-group passes: g > 0 only when a row holds more than K·64 candidates
+        bool more = false;
+        cs = 0; cm = 0;
+#pragma unroll 1
+        for (int seg = 0; seg < NSEG; ++seg) {
+            // recycle ring position seg % RB: every lane must be through row seg − RB
+            if (seg >= RB) consume((seg - RB + 1) * K, seg * K);
+            const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
+                                     : (seg - 1) * P.nxp;
+            // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
+            const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
+            const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
+            // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
+            const int gb = rl_i(lo_l, 0) + g * K * kWave;
+            const int HI = rl_i(hi_l, last_lane);
+            const int rem = HI - gb;
+            if (rem > K * kWave) more = true;
+            const int rr = seg & (RB - 1);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                unsigned long long m = 0;
+                if (k * kWave < rem) m = scan_chunk(gb + k * kWave, HI, rr * K + k);
+                s_mask[(rr * K + k) * kWave + lane] = m;
+            }
+            s_lo[rr * kWave + lane] = lo_l;
+            s_hi[rr * kWave + lane] = hi_l;
+            if (lane == 0) s_gb[rr] = gb;
+        }
+        consume(NSEG * K, NSEG * K);
+        if (!more) break;
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -533,24 +447,21 @@ k_pair_pass(const ForceParams<T> P) {
         if (valid) {
             P.out0[a] = o0; P.out1[a] = o1; P.accbuf[a] = oa;
             // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
-            if (!(rho_new > T(0))) atomicOr(&P.red[RED_BADRHO], 1ull);
+            if (!(rho_new > T(0))) atomicOr(&P.red[3], 1ull);
         }
-        // reductions for the NEXT step: update_delta_x! (:706-724), Δt (src/TimeStepping.jl:30-37) and
-        // max |v|² (sizes the skin of the next step's neighbour masks)
+        // reductions for the NEXT step: update_delta_x! (:706-724) and Δt (src/TimeStepping.jl:30-37)
         const T ddx = xa - o0.x, ddy = ya - o0.y, ddz = za - o0.z;     // Positionₙ⁺ − Position
         T disp2 = ddx * ddx + ddy * ddy + ddz * ddz;
         const T vr = o1.x * o0.x + o1.y * o0.y + o1.z * o0.z;
         const T rr = o0.x * o0.x + o0.y * o0.y + o0.z * o0.z;
         T vis = absT(P.h * vr / (rr + P.eta2));
         T a2 = ax * ax + ay * ay + az * az;
-        T v2 = o1.x * o1.x + o1.y * o1.y + o1.z * o1.z;
-        if (!valid) { disp2 = T(0); vis = T(0); a2 = T(0); v2 = T(0); }      // tail lanes of the last tile
-        disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2); v2 = wave_max(v2);
+        if (!valid) { disp2 = T(0); vis = T(0); a2 = T(0); }      // tail lanes of the last tile
+        disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
         if (lane == 0) {
-            atomic_max_bits(&P.red[RED_DISP2], disp2);
-            atomic_max_bits(&P.red[RED_VISC], vis);
-            atomic_max_bits(&P.red[RED_ACC2], a2);
-            atomic_max_bits(&P.red[RED_VEL2], v2);
+            atomic_max_bits(&P.red[0], disp2);
+            atomic_max_bits(&P.red[1], vis);
+            atomic_max_bits(&P.red[2], a2);
         }
     }
 }

@@ -200,28 +200,6 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     A.key_out[p] = A.key_in[i];
 }
 
-// widest 3-cell candidate range any particle sees in one cell row: sizes the mask layout (chunks per row)
-template <int D>
-__global__ void __launch_bounds__(256) k_max_row_range(const int* key, const int* cstart, int N, int nxp,
-                                                       int nxyp, int* out) {
-    constexpr int NSEG = (D == 3) ? 9 : 3;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int rem = 0;
-    if (i < N) {
-        const int k = key[i];
-        // one lane per cell is enough: only the first particle of a cell looks its rows up
-        if (i == 0 || key[i - 1] != k) {
-#pragma unroll
-            for (int seg = 0; seg < NSEG; ++seg) {
-                const int off = row_offset<D>(seg, nxp, nxyp);
-                rem = max(rem, cstart[k + off + 2] - cstart[k + off - 1]);
-            }
-        }
-    }
-    rem = wave_max_i(rem);
-    if ((threadIdx.x & 63) == 0 && rem > 0) atomicMax(out, rem);
-}
-
 // Pressure! (src/SimulationEquations.jl:18-24) on a state set: pk1.w = EOS(|pk0.w|)
 template <class T>
 __global__ void __launch_bounds__(256) k_eos(const typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
@@ -240,21 +218,19 @@ __global__ void __launch_bounds__(256) k_init_reduce(const typename Vec4<T>::typ
                                                      const typename Vec4<T>::type* acc, int N, T h, T eta2,
                                                      unsigned long long* red) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    T disp2 = 0, vis = 0, a2 = 0, v2 = 0;
+    T disp2 = 0, vis = 0, a2 = 0;
     if (i < N) {
         auto x = pk0[i]; auto v = pk1[i]; auto a = acc[i];
         const T rr = x.x * x.x + x.y * x.y + x.z * x.z;
         disp2 = rr;
         vis = absT(h * (v.x * x.x + v.y * x.y + v.z * x.z) / (rr + eta2));
         a2 = a.x * a.x + a.y * a.y + a.z * a.z;
-        v2 = v.x * v.x + v.y * v.y + v.z * v.z;
     }
-    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2); v2 = wave_max(v2);
+    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
     if ((threadIdx.x & 63) == 0) {
-        atomic_max_bits(&red[RED_DISP2], disp2);
-        atomic_max_bits(&red[RED_VISC], vis);
-        atomic_max_bits(&red[RED_ACC2], a2);
-        atomic_max_bits(&red[RED_VEL2], v2);
+        atomic_max_bits(&red[0], disp2);
+        atomic_max_bits(&red[1], vis);
+        atomic_max_bits(&red[2], a2);
     }
 }
 
@@ -407,7 +383,7 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
     }
     if (write) {
         // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
-        if (!(newrho > T(0))) atomicOr(&M.red[RED_BADRHO], 1ull);
+        if (!(newrho > T(0))) atomicOr(&M.red[3], 1ull);
         me.w = me.w > T(0) ? newrho : -newrho;
         M.pk0[i] = me;
     }
