@@ -55,12 +55,34 @@ struct EngineBase {
     virtual void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) = 0;
     virtual void force_stats(int reset, double* avg_ms, int64_t* launches) = 0;
     virtual void device_ptrs(void** pk0, void** pk1, int64_t* n) = 0;
+    virtual void reset_count() = 0;
+    // domain decomposition
+    virtual void dd_set_stream(void* s) = 0;
+    virtual void dd_upload(int64_t n, const void*, const void*, const void*, const void*, const uint8_t*,
+                           const int64_t*, const uint64_t*) = 0;
+    virtual int64_t dd_count() = 0;
+    virtual void dd_cell_x(int32_t* out_host) = 0;
+    virtual void dd_types(uint8_t* out_host) = 0;
+    virtual size_t dd_record_bytes(int64_t n) = 0;
+    virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
+    virtual void dd_kill(const int32_t* idx_dev, int64_t n) = 0;
+    virtual void dd_kill_ghosts() = 0;
+    virtual void dd_append(const void* buf_dev, int64_t n, int flag) = 0;
+    virtual void dd_rebuild() = 0;
+    virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
+    virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) = 0;
+    virtual void dd_reductions(double* out8) = 0;
+    virtual void dd_pass(int which, double dt) = 0;
+    virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) = 0;
 };
 
 template <class T>
 struct Engine final : EngineBase {
     using V4 = typename Vec4<T>::type;
-    int N = 0, D = 0;
+    int N = 0, D = 0;                  // N: live particles (≤ cap); the plain path keeps N == cap
+    int cap = 0;                       // allocated particles
+    bool own_stream = true;
+    int* cellx_d = nullptr;
     hipStream_t stream = nullptr;
     // state sets: 0..2 rotate through the roles A (state n), H (half step), B (state n+1 / permute target)
     V4 *pk0[3] = {}, *pk1[3] = {};
@@ -89,7 +111,7 @@ struct Engine final : EngineBase {
 
     explicit Engine(const sphmi_config& c) {
         cfg = c;
-        N = (int)c.n_particles;
+        N = cap = (int)c.n_particles;
         D = c.dims;
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
@@ -126,7 +148,8 @@ struct Engine final : EngineBase {
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
         (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
-        if (stream) (void)hipStreamDestroy(stream);
+        (void)hipFree(cellx_d);
+        if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 
     // ---- timing helpers ---------------------------------------------------------------------
@@ -197,8 +220,8 @@ struct Engine final : EngineBase {
         const int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
         memcpy(bbox_h, init, sizeof(init));
         HC(hipMemcpyAsync(bbox_d, bbox_h, sizeof(init), hipMemcpyHostToDevice, stream));
-        if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, bbox_d);
-        else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, bbox_d);
+        if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
+        else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
         HC(hipGetLastError());
         HC(hipMemcpyAsync(bbox_h, bbox_d, 6 * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
@@ -220,20 +243,23 @@ struct Engine final : EngineBase {
             throw EngineError(SPHMI_ERR_DOMAIN, buf);
         }
         grid.ncell = (int)ncell;
-        if (ncell + 1 > cell_cap) {
+        if (ncell + 2 > cell_cap) {
             (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
-            cell_cap = (ncell + 1) + (ncell + 1) / 4;
+            cell_cap = (ncell + 2) + (ncell + 2) / 4;
             HC(hipMalloc(&count, cell_cap * 4)); HC(hipMalloc(&cstart, cell_cap * 4));
             HC(hipMalloc(&tsum, ((cell_cap + kScanTile - 1) / kScanTile + 1) * 4));
         }
-        HC(hipMemsetAsync(count, 0, (size_t)(ncell + 1) * 4, stream));
+        HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream));
         HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream));
-        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, grid, count, key[cur], slot);
-        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, grid, count, key[cur], slot);
-        const int ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
-        hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, count, cstart, (int)ncell, tsum, misc_d);
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot);
+        // the scan runs over ncell + 1 entries: entry ncell is the graveyard of dead particles, so
+        // cstart[ncell] = number of live particles and cstart[ncell + 1] = N
+        const int nscan = (int)ncell + 1;
+        const int ntiles = (nscan + kScanTile - 1) / kScanTile;
+        hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, count, cstart, nscan, tsum, misc_d);
         hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, misc_d + 1);
-        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, stream, cstart, (int)ncell, tsum, misc_d + 1);
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, stream, cstart, nscan, tsum, misc_d + 1);
         hipLaunchKernelGGL(k_scatter, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, tmp_idx);
         hipLaunchKernelGGL(k_rankfix, dim3(nb256), dim3(256), 0, stream, N, key[cur], cstart, tmp_idx, perm);
         PermuteArgs<T> A{};
@@ -491,6 +517,131 @@ struct Engine final : EngineBase {
         }
     }
 
+
+    // ---- domain decomposition (driven per step by sphexample_amd/distributed.py) ---------------
+    void dd_set_stream(void* sp) override {
+        if (stream && own_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        stream = (hipStream_t)sp;
+        own_stream = false;
+    }
+    void dd_upload(int64_t n, const void* position, const void* velocity, const void* acceleration,
+                   const void* density, const uint8_t* ty, const int64_t* ids, const uint64_t* groups) override {
+        if (n < 1 || n > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: particle count exceeds the handle's capacity");
+        if (cfg.mdbc != SPHMI_MDBC_NONE) throw EngineError(SPHMI_ERR_ARGUMENT, "mDBC is not supported under domain decomposition yet");
+        N = (int)n;
+        upload(position, velocity, acceleration, density, ty, ids, groups, nullptr);
+    }
+    int64_t dd_count() override { return N; }
+    void reset_count() override { N = cap; }
+    void dd_cell_x(int32_t* out_host) override {
+        HC(hipSetDevice(cfg.device));
+        if (!cellx_d) HC(hipMalloc(&cellx_d, (size_t)cap * 4));
+        hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, cellx_d);
+        HC(hipGetLastError());
+        HC(hipMemcpyAsync(out_host, cellx_d, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+    }
+    void dd_types(uint8_t* out_host) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipMemcpyAsync(out_host, type[cur], (size_t)N, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+    }
+    size_t dd_record_bytes(int64_t n) override { return DdRecord<T>::bytes((size_t)n); }
+    void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) override {
+        if (n <= 0) return;
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
+                           id[cur], grp[cur], type[cur], idx_dev, (int)n, buf_dev);
+        HC(hipGetLastError());
+    }
+    void dd_kill(const int32_t* idx_dev, int64_t n) override {
+        if (n <= 0) return;
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_kill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, type[cur], idx_dev, (int)n);
+        HC(hipGetLastError());
+    }
+    void dd_kill_ghosts() override {
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_kill_ghosts, dim3((N + 255) / 256), dim3(256), 0, stream, type[cur], N);
+        HC(hipGetLastError());
+    }
+    void dd_append(const void* buf_dev, int64_t n, int flag) override {
+        if (n <= 0) return;
+        if ((int64_t)N + n > cap) throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: rank capacity exceeded (too many arrivals)");
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_append<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
+                           id[cur], grp[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
+        HC(hipGetLastError());
+        N += (int)n;
+    }
+    void dd_rebuild() override {
+        HC(hipSetDevice(cfg.device));
+        rebuild();
+        int live = 0;
+        HC(hipMemcpyAsync(&live, cstart + grid.ncell, 4, hipMemcpyDeviceToHost, stream));
+        sync_and_collect();
+        if (live < N) index_counter -= 1;      // the graveyard is not a cell
+        N = live;
+    }
+    void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) override {
+        if (n <= 0) return;
+        const int s_ = set == 0 ? iA : iH;
+        hipLaunchKernelGGL(k_halo_pack<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[s_], pk1[s_], idx_dev, (int)n, (V4*)buf_dev);
+        HC(hipGetLastError());
+    }
+    void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) override {
+        if (n <= 0) return;
+        const int s_ = set == 0 ? iA : iH;
+        hipLaunchKernelGGL(k_halo_unpack<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[s_], pk1[s_], idx_dev, (int)n, (const V4*)buf_dev);
+        HC(hipGetLastError());
+    }
+    // local reductions of the previous corrector (or of the upload), decoded; resets the device slots
+    void dd_reductions(double* out8) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipMemcpyAsync(red_h, red_d, 4 * 8, hipMemcpyDeviceToHost, stream));
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+        sync_and_collect();
+        out8[0] = decode(red_h[0]); out8[1] = decode(red_h[1]); out8[2] = decode(red_h[2]); out8[3] = red_h[3] ? 1.0 : 0.0;
+        for (int k = 4; k < 8; ++k) out8[k] = 0.0;
+    }
+    void dd_pass(int which, double dt) override {
+        HC(hipSetDevice(cfg.device));
+        if (which == 1) {
+            Ev e1 = begin_phase(PH_PASS1);
+            launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));
+            end_phase(e1);
+        } else {
+            Ev e2 = begin_phase(PH_PASS2);
+            launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));
+            end_phase(e2);
+            std::swap(iA, iB);
+            stepped = true;
+            iteration += 1; last_dt = dt; total_time += dt;
+        }
+    }
+    void dd_download_owned(void* pos, void* vel, void* rho, int64_t* ids, int64_t* n_out) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipStreamSynchronize(stream));
+        std::vector<V4> h0(N), h1(N);
+        std::vector<uint8_t> ty(N);
+        std::vector<long long> idv(N);
+        HC(hipMemcpy(h0.data(), pk0[iA], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        HC(hipMemcpy(h1.data(), pk1[iA], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        HC(hipMemcpy(ty.data(), type[cur], (size_t)N, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(idv.data(), id[cur], (size_t)N * 8, hipMemcpyDeviceToHost));
+        int64_t m = 0;
+        double* P_ = (double*)pos; double* V_ = (double*)vel; double* R_ = (double*)rho;
+        for (int i = 0; i < N; ++i) {
+            if (ty[i] == 0 || (ty[i] & kGhostMask)) continue;
+            P_[m * D] = h0[i].x; P_[m * D + 1] = h0[i].y; if (D == 3) P_[m * D + 2] = h0[i].z;
+            V_[m * D] = h1[i].x; V_[m * D + 1] = h1[i].y; if (D == 3) V_[m * D + 2] = h1[i].z;
+            R_[m] = std::fabs((double)h0[i].w);
+            ids[m] = idv[i];
+            ++m;
+        }
+        *n_out = m;
+    }
+
     void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
         if (n) *n = PH_COUNT;
         for (int i = 0; i < PH_COUNT && i < cap; ++i) {
@@ -577,7 +728,34 @@ int sphmi_destroy(sphmi_handle* h) {
 int sphmi_upload(sphmi_handle* h, const void* position, const void* velocity, const void* acceleration,
                  const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker,
                  const void* ghost_points) {
-    SPHMI_GUARD(h, h->e->upload(position, velocity, acceleration, density, type, id, group_marker, ghost_points));
+    SPHMI_GUARD(h, (h->e->reset_count(), h->e->upload(position, velocity, acceleration, density, type, id, group_marker, ghost_points)));
+}
+
+int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream) { SPHMI_GUARD(h, h->e->dd_set_stream(hip_stream)); }
+int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity, const void* acceleration,
+                    const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker) {
+    SPHMI_GUARD(h, h->e->dd_upload(n, position, velocity, acceleration, density, type, id, group_marker));
+}
+int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
+int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
+int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }
+int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
+int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_gather(idx_dev, n, buf_dev)); }
+int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n) { SPHMI_GUARD(h, h->e->dd_kill(idx_dev, n)); }
+int sphmi_dd_kill_ghosts(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_kill_ghosts()); }
+int sphmi_dd_append(sphmi_handle* h, const void* buf_dev, int64_t n, int flag) { SPHMI_GUARD(h, h->e->dd_append(buf_dev, n, flag)); }
+int sphmi_dd_rebuild(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_rebuild()); }
+int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_pack(set, idx_dev, n, buf_dev)); }
+int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_unpack(set, idx_dev, n, buf_dev)); }
+int sphmi_dd_reductions(sphmi_handle* h, double* out8) { SPHMI_GUARD(h, h->e->dd_reductions(out8)); }
+int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt)); }
+int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id, int64_t* n_out) {
+    SPHMI_GUARD(h, h->e->dd_download_owned(position, velocity, density, id, n_out));
+}
+int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
+    SPHMI_GUARD(h, (out->iteration = h->e->iteration, out->steps_done = 0, out->n_rebuilds = h->e->n_rebuilds,
+                    out->index_counter = h->e->index_counter, out->total_time = h->e->total_time,
+                    out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));
 }
 
 int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time) {

@@ -408,12 +408,16 @@ k_neighbor_force(const ForceParams<T> P) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    const uint8_t ty_a = P.type[ac];
+    // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
+    // state arrives by halo exchange, so nothing is stored or reduced for them
+    const uint8_t ty_raw = P.type[ac];
+    const bool owned = valid && !(ty_raw & 0xC0);
+    const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
     const T ml = fluid_a ? T(1) : T(0);
     if constexpr (PASS == PASS_FORCES_ONLY) {
         V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho;
-        if (valid) P.accbuf[a] = o;
+        if (owned) P.accbuf[a] = o;
     } else if constexpr (PASS == PASS_PREDICTOR) {
         // HalfTimeStep (src/SPHCellList.jl:624-638) + LimitDensityAtBoundary! (SimulationEquations.jl:36-42)
         if constexpr (D == 3) az += P.g * gf; else ay += P.g * gf;
@@ -424,7 +428,7 @@ k_neighbor_force(const ForceParams<T> P) {
         if (!fluid_a && rho_h < P.rho0) rho_h = P.rho0;
         o0.w = rho_h;
         o1.w = s_a;                         // ρⁿ·s travels with the half-step stream
-        if (valid) { P.out0[a] = o0; P.out1[a] = o1; }
+        if (owned) { P.out0[a] = o0; P.out1[a] = o1; }
     } else {
         // LimitDensityAtBoundary!(Density) → DensityEpsi! → FullTimeStep
         // (src/SPHCellList.jl:794-798, 640-652; src/SimulationEquations.jl:28-33)
@@ -444,7 +448,7 @@ k_neighbor_force(const ForceParams<T> P) {
         o0.w = fluid_a ? rho_new : -rho_new;
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;
-        if (valid) {
+        if (owned) {
             P.out0[a] = o0; P.out1[a] = o1; P.accbuf[a] = oa;
             // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
             if (!(rho_new > T(0))) atomicOr(&P.red[3], 1ull);
@@ -456,7 +460,7 @@ k_neighbor_force(const ForceParams<T> P) {
         const T rr = o0.x * o0.x + o0.y * o0.y + o0.z * o0.z;
         T vis = absT(P.h * vr / (rr + P.eta2));
         T a2 = ax * ax + ay * ay + az * az;
-        if (!valid) { disp2 = T(0); vis = T(0); a2 = T(0); }      // tail lanes of the last tile
+        if (!owned) { disp2 = T(0); vis = T(0); a2 = T(0); }      // tail lanes of the last tile
         disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
         if (lane == 0) {
             atomic_max_bits(&P.red[0], disp2);

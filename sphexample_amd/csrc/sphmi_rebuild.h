@@ -34,17 +34,22 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // bbox[0..2] = min cell, bbox[3..5] = max cell (ExtractCells!, :118-123, reduced)
+// Type byte: low bits = ParticleType (1/2/3), 0 = dead (left the rank at a domain-decomposition rebuild),
+// 0x80 / 0x40 = ghost copy of a particle owned by the left / right neighbour rank.
+constexpr uint8_t kGhostLeft = 0x80, kGhostRight = 0x40, kGhostMask = 0xC0, kTypeMask = 0x3F;
+
 template <class T, int D>
-__global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type* pk0, int N, T inv_cutoff,
-                                                   int* bbox) {
+__global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
+                                                   T inv_cutoff, int* bbox) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int ic = i < N ? i : N - 1;
     auto p = pk0[ic];
+    const bool live = i < N && type[ic] != 0;
     int c[3] = {map_floor<T>(p.x, inv_cutoff), map_floor<T>(p.y, inv_cutoff),
                 D == 3 ? map_floor<T>(p.z, inv_cutoff) : 0};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        int mn = wave_min_i(c[d]), mx = wave_max_i(c[d]);
+        int mn = wave_min_i(live ? c[d] : INT32_MAX), mx = wave_max_i(live ? c[d] : INT32_MIN);
         if ((threadIdx.x & 63) == 0) {
             // almost every wave is inside the box already: test before paying for the atomic
             if (mn < __hip_atomic_load(&bbox[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bbox[d], mn);
@@ -60,8 +65,8 @@ struct GridDesc {
 };
 
 template <class T, int D>
-__global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type* pk0, int N, T inv_cutoff,
-                                                    GridDesc g, int* count, int* key, int* slot) {
+__global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
+                                                    T inv_cutoff, GridDesc g, int* count, int* key, int* slot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     auto p = pk0[i];
@@ -69,6 +74,7 @@ __global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type
     int cy = map_floor<T>(p.y, inv_cutoff) - g.gmin[1] + 1;
     int cz = D == 3 ? map_floor<T>(p.z, inv_cutoff) - g.gmin[2] + 1 : 0;
     int k = cx + g.np[0] * (cy + g.np[1] * cz);
+    if (type[i] == 0) k = g.ncell;          // dead particles sort behind every cell ("graveyard" key)
     key[i] = k;
     slot[i] = atomicAdd(&count[k], 1);
 }
@@ -387,6 +393,85 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
         me.w = me.w > T(0) ? newrho : -newrho;
         M.pk0[i] = me;
     }
+}
+
+// ---- domain decomposition (one process per GPU, x-slabs; sphexample_amd/distributed.py) -----------
+// global cell x-index of every particle, current order
+template <class T>
+__global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* pk0, int N, T inv_cutoff, int* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = map_floor<T>(pk0[i].x, inv_cutoff);
+}
+
+// Migration record buffer for n particles: [n×V4 pk0][n×V4 pk1][n×V4 acc][n×i64 id][n×u64 group][n×u8 type]
+template <class T> struct DdRecord {
+    using V4 = typename Vec4<T>::type;
+    static __host__ __device__ size_t bytes(size_t n) { return n * (3 * sizeof(V4) + 16) + ((n + 7) & ~size_t(7)); }
+    static __host__ __device__ V4* pk0(void* b, size_t) { return (V4*)b; }
+    static __host__ __device__ V4* pk1(void* b, size_t n) { return (V4*)b + n; }
+    static __host__ __device__ V4* acc(void* b, size_t n) { return (V4*)b + 2 * n; }
+    static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + 3 * n); }
+    static __host__ __device__ unsigned long long* grp(void* b, size_t n) { return (unsigned long long*)id(b, n) + n; }
+    static __host__ __device__ uint8_t* type(void* b, size_t n) { return (uint8_t*)(grp(b, n) + n); }
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) k_dd_gather(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+                                                   const typename Vec4<T>::type* acc, const long long* id,
+                                                   const unsigned long long* grp, const uint8_t* type,
+                                                   const int* idx, int n, void* buf) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    DdRecord<T>::pk0(buf, n)[k] = pk0[i];
+    DdRecord<T>::pk1(buf, n)[k] = pk1[i];
+    DdRecord<T>::acc(buf, n)[k] = acc[i];
+    DdRecord<T>::id(buf, n)[k] = id[i];
+    DdRecord<T>::grp(buf, n)[k] = grp[i];
+    DdRecord<T>::type(buf, n)[k] = type[i] & kTypeMask;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) k_dd_append(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+                                                   typename Vec4<T>::type* acc, long long* id, unsigned long long* grp,
+                                                   uint8_t* type, int at, int n, void* buf, uint8_t flag) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    pk0[at + k] = DdRecord<T>::pk0(buf, n)[k];
+    pk1[at + k] = DdRecord<T>::pk1(buf, n)[k];
+    acc[at + k] = DdRecord<T>::acc(buf, n)[k];
+    id[at + k] = DdRecord<T>::id(buf, n)[k];
+    grp[at + k] = DdRecord<T>::grp(buf, n)[k];
+    type[at + k] = DdRecord<T>::type(buf, n)[k] | flag;
+}
+
+__global__ void __launch_bounds__(256) k_dd_kill(uint8_t* type, const int* idx, int n) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) type[idx[k]] = 0;
+}
+__global__ void __launch_bounds__(256) k_dd_kill_ghosts(uint8_t* type, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && (type[i] & kGhostMask)) type[i] = 0;
+}
+
+// per-step halo: packets of the listed particles → contiguous [n×V4 pk0][n×V4 pk1] and back
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_pack(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+                                                   const int* idx, int n, typename Vec4<T>::type* buf) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    buf[k] = pk0[i];
+    buf[n + k] = pk1[i];
+}
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_unpack(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+                                                     const int* idx, int n, const typename Vec4<T>::type* buf) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int i = idx[k];
+    pk0[i] = buf[k];
+    pk1[i] = buf[n + k];
 }
 
 }  // namespace sphmi

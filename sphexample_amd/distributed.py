@@ -1,0 +1,393 @@
+"""Domain decomposition of the SPH hot path over the GPUs of one node.
+
+The reference has no multi-process path at all; this module is new work for the MI355X
+engine.  One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI), 1-D slabs along
+x cut on cell-column boundaries so that every rank starts with the same number of particles.
+
+Why this shape
+--------------
+Interactions reach at most H and the cell size equals H, so a ONE-cell-column halo per side is enough
+as long as owner and ghost copy use the same (stale) cell assignment — which they do, because particles
+only change cells at a cell-list rebuild and the rebuild is a collective decision (the Δx criterion of
+``src/SPHCellList.jl:744,758`` is evaluated on the global maxima).  A slab has at most two neighbours, each
+on its own xGMI link, so the halo is two point-to-point messages per pass (no ring, no all-to-all); the
+only collective in the step is one MAX-allreduce of four scalars that makes dt and the rebuild decision
+bit-identical on all ranks.
+
+Per step (mirrors ``Engine::step_once`` in csrc/sphmi_engine.hip):
+    reductions → allreduce(MAX) → Δx, dt → [rebuild: migrate, re-ghost, sort] →
+    halo(state A) → predictor pass → halo(half-step state H) → corrector pass
+Ghost copies are ordinary entries of the rank's sorted particle array (type bits 0x80 / 0x40); the
+kernels use them as neighbours and never write or reduce them.
+
+Rebuild (collective): kill ghosts → send the particles whose cell column left the slab to the adjacent
+rank → sort → send copies of the slab's first / last column as the neighbours' ghosts → sort again →
+rebuild the halo index lists.  Both sorts are stable, so the k-th boundary particle of the sender is the
+k-th ghost slot of the receiver and the per-step halo needs no indices on the wire.
+
+Known limits: static cuts (no re-balancing while the fluid moves), migration to adjacent ranks
+only, no mDBC, per-step control on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from ._abi import SphmiConfig, SphmiProgress, make_config
+
+GHOST_LEFT, GHOST_RIGHT, GHOST_MASK = 0x80, 0x40, 0xC0
+
+
+def cell_x_of(x: np.ndarray, H_inv: float) -> np.ndarray:
+    """map_floor of src/SPHCellList.jl:56-61 on the x coordinate (round half away from zero)."""
+    return (np.sign(x) * np.trunc(np.abs(x) * H_inv + 0.5)).astype(np.int64)
+
+
+@dataclass
+class SlabPlan:
+    """Static x-slab cuts: rank r owns the cell columns cx_lo[r] … cx_hi[r] (inclusive)."""
+    cx_lo: List[int]
+    cx_hi: List[int]
+
+    @property
+    def world(self) -> int:
+        return len(self.cx_lo)
+
+    @staticmethod
+    def from_columns(cx: np.ndarray, world: int) -> "SlabPlan":
+        """Equal-particle-count cuts on column boundaries (a uniform spatial cut would put the whole
+        initial water column on a quarter of the ranks)."""
+        lo, hi = int(cx.min()), int(cx.max())
+        hist = np.bincount(cx - lo, minlength=hi - lo + 1)
+        cum = np.cumsum(hist)
+        total = int(cum[-1])
+        cuts = [lo]
+        for r in range(1, world):
+            # first column whose cumulative count reaches r/world of the particles
+            c = lo + int(np.searchsorted(cum, total * r / world, side="left")) + 1
+            c = max(c, cuts[-1] + 2)            # every slab at least two columns wide
+            cuts.append(c)
+        cuts.append(hi + 1)
+        for r in range(world):
+            if cuts[r + 1] - cuts[r] < 2:
+                raise ValueError(f"slab {r} would be narrower than two cell columns: too many ranks for this domain")
+        INF = 1 << 30
+        cx_lo = [(-INF if r == 0 else cuts[r]) for r in range(world)]
+        cx_hi = [(INF if r == world - 1 else cuts[r + 1] - 1) for r in range(world)]
+        return SlabPlan(cx_lo, cx_hi)
+
+    def owner_of(self, cx: np.ndarray) -> np.ndarray:
+        bounds = np.array([self.cx_lo[r] for r in range(1, self.world)], dtype=np.int64)
+        return np.searchsorted(bounds, cx, side="right")
+
+
+def step_control(red: np.ndarray, delta_x: float, cfg: SphmiConfig) -> Tuple[float, float, bool]:
+    """Δx accumulation, Δt and the rebuild decision from the GLOBAL reductions
+    (src/SPHCellList.jl:706-724,744,758; src/TimeStepping.jl:30-43) — same arithmetic as step_once."""
+    maxdisp = float(np.sqrt(red[0]))
+    visc = float(red[1])
+    amax = float(np.sqrt(red[2]))
+    delta_x = delta_x + 4.0 * maxdisp
+    with np.errstate(divide="ignore"):
+        dt1 = float(np.sqrt(np.float64(cfg.h) / np.float64(amax))) if amax > 0 else float("inf")
+    dt2 = cfg.h / (cfg.c0 + visc)
+    dt = cfg.CFL * min(dt1, dt2)
+    return delta_x, dt, delta_x >= cfg.h
+
+
+class _Comm:
+    """Point-to-point exchange with the two slab neighbours + the per-step MAX-allreduce.
+    Device tensors go straight to RCCL; with the gloo backend (tests) they are staged through the host."""
+
+    def __init__(self, rank: int, world: int, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.device = rank, world, device
+        self.on_device = dist.get_backend() == "nccl"
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+
+    def allreduce_max(self, values: np.ndarray) -> np.ndarray:
+        t = self.torch.as_tensor(values, dtype=self.torch.float64)
+        if self.on_device:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    def exchange(self, send_left, send_right, recv_left_bytes: int, recv_right_bytes: int):
+        """send_*: uint8 device tensors (or None); returns the two received uint8 device tensors."""
+        torch, dist = self.torch, self.dist
+        stage = (lambda t: t) if self.on_device else (lambda t: t.cpu())
+        dev = self.device if self.on_device else "cpu"
+        ops, recv = [], {}
+        for peer, send, nrecv, key in ((self.left, send_left, recv_left_bytes, "L"),
+                                       (self.right, send_right, recv_right_bytes, "R")):
+            if peer is None:
+                continue
+            if nrecv > 0:
+                recv[key] = torch.empty(nrecv, dtype=torch.uint8, device=dev)
+                ops.append(dist.P2POp(dist.irecv, recv[key], peer))
+            if send is not None and send.numel() > 0:
+                ops.append(dist.P2POp(dist.isend, stage(send).contiguous(), peer))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        out = []
+        for key in ("L", "R"):
+            t = recv.get(key)
+            out.append(None if t is None else t.to(self.device))
+        return out[0], out[1]
+
+    def exchange_counts(self, n_left: int, n_right: int) -> Tuple[int, int]:
+        torch = self.torch
+        dev = self.device if self.on_device else "cpu"
+        mk = lambda v: torch.tensor([v], dtype=torch.int64, device=dev).view(torch.uint8)  # noqa: E731
+        rl, rr = self.exchange(mk(n_left).to(self.device) if self.left is not None else None,
+                               mk(n_right).to(self.device) if self.right is not None else None, 8, 8)
+        g = lambda t: 0 if t is None else int(t.cpu().view(torch.int64)[0])  # noqa: E731
+        return g(rl), g(rr)
+
+
+class DistributedEngine:
+    """Same ``advance`` / ``force_kernel_stats`` surface as ``engine.Engine``, on a slab of the domain."""
+
+    def __init__(self, particles, setup, rank: int, world: int, local_device: int = 0,
+                 device_float_bytes: int = 4, capacity_factor: float = 1.6):
+        import torch
+        from .engine import Engine, load_library
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", local_device)
+        torch.cuda.set_device(self.device)
+        H_inv = setup.SimKernel.H_inv
+        # initial ownership from the positions as the device will see them
+        xdev = particles.Position[:, 0].astype(np.float32 if device_float_bytes == 4 else np.float64)
+        cx = cell_x_of(xdev.astype(np.float64), H_inv)
+        self.plan = SlabPlan.from_columns(cx, world)
+        mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
+        self.n_total = len(particles)
+        n_own = len(mine)
+        halo_guess = max(1024, int(0.25 * n_own))
+        cap = int(capacity_factor * (self.n_total / world)) + halo_guess
+        cap = max(cap, int(1.2 * n_own) + halo_guess)
+        cfg = make_config(cap, setup.SimConstants, setup.SimKernel, setup.SimMetaData, setup.SimViscosity,
+                          setup.SimDensityDiffusion, device_float_bytes=device_float_bytes, host_float_bytes=8,
+                          device=local_device)
+        self.cfg = cfg
+        self.eng = Engine(cfg)
+        self.lib = load_library()
+        self.h = self.eng._h
+        self._declare()
+        self._call("dd_set_stream", C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        keep = [f(particles.Position[mine]), f(particles.Velocity[mine]), f(particles.Acceleration[mine]),
+                f(particles.Density[mine]), np.ascontiguousarray(particles.Type[mine], dtype=np.uint8),
+                np.ascontiguousarray(particles.ID[mine], dtype=np.int64),
+                np.ascontiguousarray(particles.GroupMarker[mine], dtype=np.uint64)]
+        self._call("dd_upload", C.c_int64(n_own), *[a.ctypes.data_as(C.c_void_p) for a in keep])
+        self.comm = _Comm(rank, world, self.device)
+        self.D = cfg.dims
+        self.vbytes = 4 * cfg.device_float_bytes            # one V4 packet
+        self.delta_x = 0.0
+        self.total_time, self.iteration, self.last_dt = 0.0, 0, 0.0
+        self.n_rebuilds = 0
+        self._halo = None
+
+    # -- ctypes plumbing -----------------------------------------------------------------------------
+    def _declare(self):
+        L = self.lib
+        vp, i64, i32p = C.c_void_p, C.c_int64, C.c_void_p
+        L.sphmi_dd_set_stream.argtypes = [vp, vp]
+        L.sphmi_dd_upload.argtypes = [vp, i64] + [vp] * 7
+        L.sphmi_dd_count.argtypes = [vp, C.POINTER(i64)]
+        L.sphmi_dd_cell_x.argtypes = [vp, vp]
+        L.sphmi_dd_types.argtypes = [vp, vp]
+        L.sphmi_dd_record_bytes.argtypes = [vp, i64, C.POINTER(i64)]
+        L.sphmi_dd_gather.argtypes = [vp, i32p, i64, vp]
+        L.sphmi_dd_kill.argtypes = [vp, i32p, i64]
+        L.sphmi_dd_kill_ghosts.argtypes = [vp]
+        L.sphmi_dd_append.argtypes = [vp, vp, i64, C.c_int]
+        L.sphmi_dd_rebuild.argtypes = [vp]
+        L.sphmi_dd_halo_pack.argtypes = [vp, C.c_int, i32p, i64, vp]
+        L.sphmi_dd_halo_unpack.argtypes = [vp, C.c_int, i32p, i64, vp]
+        L.sphmi_dd_reductions.argtypes = [vp, vp]
+        L.sphmi_dd_pass.argtypes = [vp, C.c_int, C.c_double]
+        L.sphmi_dd_download_owned.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i64)]
+        L.sphmi_dd_progress.argtypes = [vp, C.POINTER(SphmiProgress)]
+
+    def _call(self, name, *args):
+        self.eng._check(getattr(self.lib, "sphmi_" + name)(self.h, *args))
+
+    def _count(self) -> int:
+        n = C.c_int64()
+        self._call("dd_count", C.byref(n))
+        return n.value
+
+    def _cell_x(self) -> np.ndarray:
+        out = np.empty(self._count(), dtype=np.int32)
+        self._call("dd_cell_x", out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def _types(self) -> np.ndarray:
+        out = np.empty(self._count(), dtype=np.uint8)
+        self._call("dd_types", out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def _idx_dev(self, idx: np.ndarray):
+        return self.torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+
+    def _gather(self, idx: np.ndarray):
+        """Full records of the listed particles → uint8 device tensor (None when empty)."""
+        n = len(idx)
+        if n == 0:
+            return None
+        nb = C.c_int64()
+        self._call("dd_record_bytes", C.c_int64(n), C.byref(nb))
+        buf = self.torch.empty(nb.value, dtype=self.torch.uint8, device=self.device)
+        di = self._idx_dev(idx)
+        self._call("dd_gather", C.c_void_p(di.data_ptr()), C.c_int64(n), C.c_void_p(buf.data_ptr()))
+        self.torch.cuda.current_stream(self.device).synchronize()      # di / buf outlive the kernel
+        return buf
+
+    def _record_bytes(self, n: int) -> int:
+        nb = C.c_int64()
+        self._call("dd_record_bytes", C.c_int64(n), C.byref(nb))
+        return nb.value
+
+    # -- collective rebuild ------------------------------------------------------------------------
+    def _rebuild(self):
+        torch = self.torch
+        lo, hi = self.plan.cx_lo[self.rank], self.plan.cx_hi[self.rank]
+        # 1. ghosts die, leavers migrate to the adjacent rank
+        cx = self._cell_x()
+        ty = self._types()
+        owned = (ty & GHOST_MASK) == 0
+        go_l = np.nonzero(owned & (cx < lo))[0]
+        go_r = np.nonzero(owned & (cx > hi))[0]
+        if len(go_l) and (cx[go_l] < self.plan.cx_lo[self.rank - 1]).any() or \
+           len(go_r) and (cx[go_r] > self.plan.cx_hi[self.rank + 1]).any():
+            raise RuntimeError("domain decomposition: a particle skipped a whole slab between two rebuilds")
+        self._call("dd_kill_ghosts")
+        sl, sr = self._gather(go_l), self._gather(go_r)
+        nl, nr = self.comm.exchange_counts(len(go_l), len(go_r))
+        rl, rr = self.comm.exchange(sl, sr, self._record_bytes(nl) if nl else 0, self._record_bytes(nr) if nr else 0)
+        leavers = np.concatenate([go_l, go_r])
+        if len(leavers):
+            di = self._idx_dev(leavers)
+            self._call("dd_kill", C.c_void_p(di.data_ptr()), C.c_int64(len(leavers)))
+        for buf, n in ((rl, nl), (rr, nr)):
+            if n:
+                self._call("dd_append", C.c_void_p(buf.data_ptr()), C.c_int64(n), C.c_int(0))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._call("dd_rebuild")
+        # 2. the first / last column of the slab become the neighbours' ghost layer
+        cx = self._cell_x()
+        b_l = np.nonzero(cx == lo)[0] if self.comm.left is not None else np.empty(0, np.int64)
+        b_r = np.nonzero(cx == hi)[0] if self.comm.right is not None else np.empty(0, np.int64)
+        sl, sr = self._gather(b_l), self._gather(b_r)
+        nl, nr = self.comm.exchange_counts(len(b_l), len(b_r))
+        rl, rr = self.comm.exchange(sl, sr, self._record_bytes(nl) if nl else 0, self._record_bytes(nr) if nr else 0)
+        if nl:
+            self._call("dd_append", C.c_void_p(rl.data_ptr()), C.c_int64(nl), C.c_int(GHOST_LEFT))
+        if nr:
+            self._call("dd_append", C.c_void_p(rr.data_ptr()), C.c_int64(nr), C.c_int(GHOST_RIGHT))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._call("dd_rebuild")
+        # 3. halo index lists in the final order (stable sorts ⇒ k-th sender entry ↔ k-th ghost slot)
+        cx = self._cell_x()
+        ty = self._types()
+        owned = (ty & GHOST_MASK) == 0
+        send_l = np.nonzero(owned & (cx == lo))[0] if self.comm.left is not None else np.empty(0, np.int64)
+        send_r = np.nonzero(owned & (cx == hi))[0] if self.comm.right is not None else np.empty(0, np.int64)
+        slot_l = np.nonzero((ty & GHOST_LEFT) != 0)[0]
+        slot_r = np.nonzero((ty & GHOST_RIGHT) != 0)[0]
+        assert len(send_l) == len(b_l) and len(send_r) == len(b_r), "boundary columns changed between the two sorts"
+        assert len(slot_l) == nl and len(slot_r) == nr
+        vb = 2 * self.vbytes
+        mk = lambda n: torch.empty(max(n, 1) * vb, dtype=torch.uint8, device=self.device)  # noqa: E731
+        self._halo = dict(send_l=self._idx_dev(send_l), send_r=self._idx_dev(send_r),
+                          slot_l=self._idx_dev(slot_l), slot_r=self._idx_dev(slot_r),
+                          n_send_l=len(send_l), n_send_r=len(send_r), n_slot_l=nl, n_slot_r=nr,
+                          buf_l=mk(len(send_l)), buf_r=mk(len(send_r)))
+        self.n_rebuilds += 1
+
+    def _halo_exchange(self, which: int):
+        """Refresh the ghost copies of state set `which` (0 = A, 1 = H) from their owners."""
+        hl, p = self._halo, C.c_void_p
+        vb = 2 * self.vbytes
+        if hl["n_send_l"]:
+            self._call("dd_halo_pack", C.c_int(which), p(hl["send_l"].data_ptr()), C.c_int64(hl["n_send_l"]), p(hl["buf_l"].data_ptr()))
+        if hl["n_send_r"]:
+            self._call("dd_halo_pack", C.c_int(which), p(hl["send_r"].data_ptr()), C.c_int64(hl["n_send_r"]), p(hl["buf_r"].data_ptr()))
+        rl, rr = self.comm.exchange(hl["buf_l"][:hl["n_send_l"] * vb] if hl["n_send_l"] else None,
+                                    hl["buf_r"][:hl["n_send_r"] * vb] if hl["n_send_r"] else None,
+                                    hl["n_slot_l"] * vb, hl["n_slot_r"] * vb)
+        if hl["n_slot_l"]:
+            self._call("dd_halo_unpack", C.c_int(which), p(hl["slot_l"].data_ptr()), C.c_int64(hl["n_slot_l"]), p(rl.data_ptr()))
+        if hl["n_slot_r"]:
+            self._call("dd_halo_unpack", C.c_int(which), p(hl["slot_r"].data_ptr()), C.c_int64(hl["n_slot_r"]), p(rr.data_ptr()))
+        self._keep = (rl, rr)        # keep the receive buffers alive until the next exchange
+
+    # -- the SimulationLoop of src/SPHCellList.jl:727-805, distributed --------------------------------
+    def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
+        cfg = self.cfg
+        self.delta_x = 1.0 + cfg.h                                   # :739
+        steps = 0
+        red = np.zeros(8)
+        while self.total_time <= t_target and (max_steps < 0 or steps < max_steps):
+            self._call("dd_reductions", red.ctypes.data_as(C.c_void_p))
+            g = self.comm.allreduce_max(red[:4])
+            if g[3] > 0:
+                raise RuntimeError("non-positive density produced on some rank")
+            self.delta_x, dt, rebuild = step_control(g, self.delta_x, cfg)
+            if not (dt > 0.0) or np.isnan(dt):
+                raise RuntimeError(f"non-positive or NaN dt {dt} at iteration {self.iteration}")
+            if rebuild:
+                self._rebuild()
+                self.delta_x = 0.0
+            self._halo_exchange(0)
+            self._call("dd_pass", C.c_int(1), C.c_double(dt))
+            self._halo_exchange(1)
+            self._call("dd_pass", C.c_int(2), C.c_double(dt))
+            self.iteration += 1
+            self.last_dt = dt
+            self.total_time += dt
+            steps += 1
+        self.torch.cuda.current_stream(self.device).synchronize()
+        prog = SphmiProgress()
+        self._call("dd_progress", C.byref(prog))
+        prog.iteration, prog.steps_done, prog.n_rebuilds = self.iteration, steps, self.n_rebuilds
+        prog.total_time, prog.last_dt, prog.delta_x = self.total_time, self.last_dt, self.delta_x
+        return prog
+
+    def force_kernel_stats(self, reset: bool = False):
+        return self.eng.force_kernel_stats(reset)
+
+    def download_owned(self) -> dict:
+        n = self._count()
+        pos = np.empty((n, self.D)); vel = np.empty((n, self.D)); rho = np.empty(n); ids = np.empty(n, dtype=np.int64)
+        m = C.c_int64()
+        self._call("dd_download_owned", pos.ctypes.data_as(C.c_void_p), vel.ctypes.data_as(C.c_void_p),
+                   rho.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.byref(m))
+        k = m.value
+        return {"Position": pos[:k], "Velocity": vel[:k], "Density": rho[:k], "ID": ids[:k]}
+
+    def gather_all(self) -> Optional[dict]:
+        """Owned particles of every rank, concatenated on rank 0 (tests / output)."""
+        import torch.distributed as dist
+        parts: List[Optional[dict]] = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(self.download_owned(), parts, dst=0)
+        if self.rank != 0:
+            return None
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
+def make_distributed_engine(dp: float, setup, rank: int, world: int, local_device: int):
+    """bench.py hook: every rank generates the (deterministic) lattice and keeps its slab."""
+    from .cases import dam_break_3d
+    particles = dam_break_3d(dp)
+    return DistributedEngine(particles, setup, rank, world, local_device), len(particles)
