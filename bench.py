@@ -38,6 +38,18 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 FLOP_PER_UPDATE_3D = 4.5e4       # SURVEY.md §8d estimate (2 passes × (≈1120 × 8 + ≈174 × 78))
 
 
+def measured_traffic(n_local):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_v3_hbm_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+    plus WRITE_SIZE), scaled from the profiled particle count.  None when the record is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+        return rec["bytes_per_particle_per_launch_corrected"] * n_local
+    except Exception:
+        return None
+
+
 def cpu_baseline(dp=0.0085, steps=24):
     """Bounded CPU sample: same case at dp = 0.0085 (the reference example's own resolution,
     ≈159 k particles), `steps` steps after a 2-step warm-up, all host cores."""
@@ -64,6 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dp", type=float, default=None, help="override lattice spacing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="use the slab driver even for one rank (measures its host overhead)")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +95,7 @@ def main():
     dp = args.dp or dp1 / (world ** (1.0 / 3.0))
     setup = setup_dam_break_3d(dp)
 
-    if world == 1:
+    if world == 1 and not args.force_distributed:
         from sphexample_amd.engine import make_engine
         particles = dam_break_3d(dp)
         n_total = len(particles)
@@ -91,7 +105,9 @@ def main():
     else:
         import torch.distributed as dist
         from sphexample_amd.distributed import make_distributed_engine
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         eng, n_total = make_distributed_engine(dp, setup, rank, world, local_rank)
         barrier = dist.barrier
 
@@ -126,7 +142,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"x-slab domain decomposition x{world}, 1-cell halo",
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
+                         "traffic_source": "profiles/r01_v3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "valu": {"achieved_tflops": FLOP_PER_UPDATE_3D / 2.0 * n_local / (kern_ms * 1e-3) / 1e12
@@ -135,7 +152,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_distributed:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

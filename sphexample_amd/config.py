@@ -10,10 +10,10 @@ Everything here is plain host data: these objects only carry parameters to the C
 * viscosity / density-diffusion tag types — /root/reference/src/SPHViscosityModels.jl:16-39,
   /root/reference/src/SPHDensityDiffusionModels.jl:30,54,98,148
 
-Julia's unicode field names are accepted as keyword aliases where Python's identifier rules allow
-them (``ρ₀``→``rho0``, ``α``→``alpha``, ``c₀``→``c0``, ``γ``→``gamma``, ``δᵩ``→``delta_phi``,
-``ν₀``→``nu0``, ``m₀``→``m0``); ``γ⁻¹``/``Cb⁻¹``/``h⁻¹``/``H⁻¹``/``H²``/``η²`` are spelled
-``gamma_inv``/``Cb_inv``/``h_inv``/``H_inv``/``H2``/``eta2``.
+Julia's unicode field names are accepted as keyword aliases (``ρ₀``→``rho0``, ``α``→``alpha``,
+``c₀``→``c0``, ``γ``→``gamma``, ``δᵩ``→``delta_phi``, ``ν₀``→``nu0``, ``m₀``→``m0``); the ones Python's
+identifier grammar rejects (subscript digits) go through ``**{"c₀": 33.14}``.
+``γ⁻¹``/``Cb⁻¹``/``h⁻¹``/``H⁻¹``/``H²``/``η²`` are spelled ``gamma_inv``/``Cb_inv``/``h_inv``/``H_inv``/``H2``/``eta2``.
 """
 from __future__ import annotations
 

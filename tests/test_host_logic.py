@@ -1,0 +1,97 @@
+"""Host-side mirror of the reference API: configuration defaults, CSV loading, case generator and the
+RunSimulation bookkeeping (driven here by the CPU oracle as the backend — test infrastructure only)."""
+import math
+
+import numpy as np
+import pytest
+
+from sphexample_amd import (ArtificialViscosity, Laminar, LinearDensityDiffusion, SimulationConstants,
+                            SimulationMetaData, SPHKernelInstance, WendlandC2, next_output_time)
+from sphexample_amd._abi import make_config
+from sphexample_amd.cases import dam_break_3d, dam_break_3d_count, setup_dam_break_2d
+from sphexample_amd.simulation import RunSimulation
+
+
+def test_simulation_constants_defaults():
+    """src/SimulationConstantsConfiguration.jl:36-52 defaults and dependent defaults."""
+    c = SimulationConstants()
+    assert (c.rho0, c.dx, c.alpha, c.g, c.gamma, c.delta_phi, c.CFL, c.nu0) == (1000, 0.02, 0.01, 9.81, 7, 0.1, 0.2, 1e-6)
+    assert c.m0 == pytest.approx(0.4) and c.c0 == pytest.approx(88.58893836140041, rel=1e-15)
+    assert c.Cb == pytest.approx(1121142.8571428573, rel=1e-15)
+    # Julia's field names are accepted through ** (Python identifiers cannot hold the subscripts)
+    c3 = SimulationConstants(**{"dx": 0.0085, "c₀": 33.14, "α": 0.1, "m₀": 1000 * 0.0085 ** 3, "CFL": 0.2})   # Dambreak3d.jl:9-15
+    assert c3.c0 == 33.14 and c3.alpha == 0.1 and c3.m0 == pytest.approx(1000 * 0.0085 ** 3)
+    with pytest.raises(AssertionError):
+        SimulationConstants(dx=-1.0)
+
+
+def test_kernel_instance():
+    """src/SPHKernels.jl:42-72, αD :22-23."""
+    k = SPHKernelInstance(2, WendlandC2(), dx=0.02)
+    assert (k.h, k.H) == (0.04, 0.08) and k.alphaD == pytest.approx(348.15143801352104, rel=1e-15)
+    assert k.eta2 == pytest.approx(1.6e-07)
+    k3 = SPHKernelInstance(3, WendlandC2(), h=math.sqrt(3 * 0.0085 ** 2))
+    assert k3.alphaD == pytest.approx(21 / (16 * math.pi * k3.h ** 3))
+    with pytest.raises(ValueError):
+        SPHKernelInstance(2, WendlandC2(), dx=0.02, h=0.04)
+
+
+def test_next_output_time():
+    """src/SPHCellList.jl:687-698."""
+    m = SimulationMetaData(Dimensions=2, OutputTimes=0.01, SimulationTime=1.0)
+    m.OutputIterationCounter = 3
+    assert next_output_time(m) == pytest.approx(0.03)
+    m2 = SimulationMetaData(Dimensions=2, OutputTimes=[0.1, 0.25, 0.4], SimulationTime=1.0)
+    m2.OutputIterationCounter = 2
+    assert next_output_time(m2) == 0.25
+    m2.OutputIterationCounter = 3
+    assert next_output_time(m2) == 1.0
+
+
+def test_unsupported_model_raises(dam_break_2d):
+    p, s = dam_break_2d
+    with pytest.raises(NotImplementedError):
+        make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, Laminar(), s.SimDensityDiffusion)
+
+
+def test_csv_loader_matches_reference_rules(dam_break_2d, still_wedge):
+    p, _ = dam_break_2d
+    assert len(p) == 6881 and (p.Type == 2).sum() == 2465 and (p.Type == 1).sum() == 4416
+    assert (np.diff(p.ID) > 0).all() and p.ID[0] == 1                     # sorted by ID = Idp + 1
+    assert p.Position.shape == (6881, 2) and p.Position[:, 1].max() > 0.5   # 2-D takes (Points:0, Points:2)
+    assert set(np.unique(p.GravityFactor)) == {-1.0, 0.0} and ((p.MotionLimiter == 1) == (p.Type == 1)).all()
+    q, _ = still_wedge
+    assert len(q) == 3027 and (q.GhostPoints[:580] != 0).any(1).all() and (q.GhostPoints[580:] == 0).all()
+
+
+def test_generator_reproduces_shipped_layout(dam_break_3d_shipped):
+    p, _ = dam_break_3d_shipped
+    q = dam_break_3d(0.02)
+    nb = 7846
+    assert len(q) == len(p) == 17446 == dam_break_3d_count(0.02)
+    np.testing.assert_allclose(q.Position[nb:], p.Position[nb:], atol=1e-12)      # fluid: same order
+    np.testing.assert_array_equal(q.ID, p.ID)
+    np.testing.assert_allclose(q.Density, p.Density, atol=6e-3)                    # CSV holds 6 digits
+    key = lambda a: set(map(tuple, np.round(a / 0.01).astype(int)))                # noqa: E731
+    assert key(q.Position[:nb]) == key(p.Position[:nb])                            # boundary: same sites
+    assert dam_break_3d_count(0.00425) == 1057738 and dam_break_3d_count(0.002125) == 7700240
+
+
+def test_run_simulation_bookkeeping(dam_break_2d):
+    """Output cadence of src/SPHCellList.jl:849,881-909 with the oracle standing in for the engine."""
+    from oracle.oracle import Oracle
+    p, s = dam_break_2d
+    meta = SimulationMetaData(Dimensions=2, SimulationName="t", SimulationTime=3.0e-4, OutputTimes=1.0e-4)
+    seen = []
+    steps = RunSimulation(SimGeometry=None, SimMetaData=meta, SimConstants=s.SimConstants, SimKernel=s.SimKernel,
+                          SimLogger=None, SimParticles=p.copy(), SimViscosity=ArtificialViscosity(),
+                          SimDensityDiffusion=LinearDensityDiffusion(),
+                          on_output=lambda m, q: seen.append((m.OutputIterationCounter, m.TotalTime, m.Iteration)),
+                          backend_factory=Oracle)
+    # outputs at counter 1 (initial) and after each SimulationLoop call; stops once TotalTime > SimulationTime
+    # dt ≈ 9.08e-5: interval 1 takes two steps (t = 1.82e-4 > 1e-4), intervals 2 and 3 one step each
+    assert [c for c, _, _ in seen] == [1, 2, 3, 4]
+    assert seen[1][1] > 1.0e-4 and seen[2][1] > 2.0e-4 and seen[3][1] > 3.0e-4
+    assert [i for _, _, i in seen] == [0, 2, 3, 4]
+    assert meta.TotalTime > meta.SimulationTime and len(steps) == 3 and all(dt > 0 for dt in steps)
+    assert meta.Iteration == 4
