@@ -50,23 +50,33 @@ def measured_traffic(n_local):
         return None
 
 
-def cpu_baseline(dp=0.0085, steps=24):
+def cpu_baseline(dp=0.0085, steps=160):
     """Bounded CPU sample: same case at dp = 0.0085 (the reference example's own resolution,
-    ≈159 k particles), `steps` steps after a 2-step warm-up, all host cores."""
+    ≈159 k particles), `steps` steps after a warm-up.  The restatement keeps the reference's nthreads full-length
+    accumulator copies (src/PreProcess.jl:204-205), so more threads is not always faster: the thread count is
+    picked by a 2-step probe over {cores, cores/2, cores/4, 16, 8}."""
     from oracle.oracle import Oracle, make_oracle
     from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
-    cores = os.cpu_count() or 1
-    threads = min(cores, Oracle.max_threads())
+    cores = min(os.cpu_count() or 1, Oracle.max_threads())
     p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
-    o = make_oracle(p, s, threads=threads)
-    o.advance(1e9, max_steps=2)
+    o = make_oracle(p, s, threads=cores)
+    o.advance(1e9, max_steps=1)                       # first step holds the one-off sort
+    best, best_t = cores, float("inf")
+    for t in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), min(16, cores), min(8, cores)}, reverse=True):
+        o.set_threads(t)
+        t0 = time.perf_counter()
+        o.advance(1e9, max_steps=2)
+        el = time.perf_counter() - t0
+        if el < best_t:
+            best, best_t = t, el
+    o.set_threads(best)
     t0 = time.perf_counter()
     pr = o.advance(1e9, max_steps=steps)
     dt = time.perf_counter() - t0
-    return {"value": len(p) * pr.steps_done / dt, "unit": "particle-updates/s", "cores": threads,
+    return {"value": len(p) * pr.steps_done / dt, "unit": "particle-updates/s", "cores": best,
             "kind": "port",
             "sample": f"3-D dam break dp={dp} (N={len(p)}), {pr.steps_done} steps, fp64 OpenMP restatement "
-                      f"of the reference algorithm (oracle/sph_oracle.c), {dt:.1f} s"}
+                      f"of the reference algorithm (oracle/sph_oracle.c) on {best} of {cores} host threads, {dt:.1f} s"}
 
 
 def main():
