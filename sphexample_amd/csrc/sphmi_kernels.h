@@ -39,11 +39,17 @@ constexpr int kWave = 64;
 #ifndef SPHMI_ABL_NO_CONSUME
 #define SPHMI_ABL_NO_CONSUME 0
 #endif
+#ifndef SPHMI_SEQ_BLOCKS
+#define SPHMI_SEQ_BLOCKS 1
+#endif
+#ifndef SPHMI_ABL_GATHER
+#define SPHMI_ABL_GATHER 0
+#endif
 #ifndef SPHMI_ABL_NO_P2
 #define SPHMI_ABL_NO_P2 0
 #endif
 #ifndef SPHMI_RING_ROWS
-#define SPHMI_RING_ROWS 4
+#define SPHMI_RING_ROWS 2
 #endif
 #ifndef SPHMI_CHUNKS
 #define SPHMI_CHUNKS 4
@@ -304,8 +310,14 @@ k_neighbor_force(const ForceParams<T> P) {
 #if SPHMI_ABL_NO_P2
                 ax += T(j);
 #else
+#if SPHMI_ABL_GATHER == 1
+                const V4 n0 = P.src0[j]; const V4 n1 = q1;
+#elif SPHMI_ABL_GATHER == 2
+                const V4 n0 = q0; const V4 n1 = q1;
+#else
                 const V4 n0 = P.src0[j];
                 const V4 n1 = P.src1[j];
+#endif
                 pair(j, n0, n1, (unsigned)(j - clo) < cwid);
 #endif
             }
@@ -351,6 +363,9 @@ k_neighbor_force(const ForceParams<T> P) {
 #pragma unroll
                     for (int r = 15; r >= 0; --r)
                         W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
+#if SPHMI_SEQ_BLOCKS
+                    __builtin_amdgcn_sched_barrier(0);      // one 32×32 block in flight: 16 accumulator registers
+#endif
                 }
             }
             swap_halves(W[0], W[1]);
