@@ -234,3 +234,47 @@ def test_full_size_properties():
     np.testing.assert_array_equal(a["Density"], b["Density"])
     np.testing.assert_array_equal(a["Position"], b["Position"])
     assert pr.last_dt == pytest.approx(0.2 * np.sqrt(3) * dp / 33.14, rel=0.2)
+
+
+@pytest.mark.parametrize("dims,n,seed", [(2, 500, 1), (2, 3000, 2), (3, 2000, 3), (3, 9000, 4)])
+def test_random_clouds_forces_and_steps(dims, n, seed):
+    """Non-lattice input: random positions / velocities / densities / particle types (incl. Moving, whose
+    GravityFactor is +1 — src/PreProcess.jl:82-84), negative coordinates (cells on both sides of 0: the
+    round-half-away rule of map_floor), ragged cell populations."""
+    from sphexample_amd import SimulationConstants, SimulationMetaData, SPHKernelInstance, WendlandC2, ArtificialViscosity, LinearDensityDiffusion
+    from sphexample_amd.cases import CaseSetup
+    rng = np.random.default_rng(seed)
+    dx = 0.02
+    box = (n ** (1.0 / dims)) * dx * 0.9
+    pos = rng.uniform(-box / 2, box / 2, size=(n, dims))
+    typ = rng.choice([1, 1, 1, 2, 3], size=n).astype(np.uint8)
+    p = particles_from_arrays(dims, pos, 1000.0 + rng.uniform(-5, 15, n), typ, np.ones(n), np.arange(1, n + 1))
+    p.Velocity[:] = rng.uniform(-1, 1, size=(n, dims))
+    sc = SimulationConstants(dx=dx, m0=1000 * dx ** dims, c0=40.0, alpha=0.05)
+    ker = SPHKernelInstance(dims, WendlandC2(), dx=dx)
+    s = CaseSetup("cloud", sc, ker, SimulationMetaData(Dimensions=dims), ArtificialViscosity(), LinearDensityDiffusion())
+    eng, orc = engines(p, s, 8)
+    d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+    np.testing.assert_array_equal(eng.download(("ID",))["ID"], orc.download(("ID",))["ID"])
+    np.testing.assert_allclose(d1, d2, rtol=0, atol=1e-10 * np.abs(d2).max())
+    np.testing.assert_allclose(a1, a2, rtol=0, atol=1e-10 * np.abs(a2).max())
+    # a few steps of the (violent) cloud: same dt sequence and rebuild cadence, states to rounding
+    eng, orc = engines(p, s, 8)
+    pe, po = eng.advance(1e9, max_steps=6), orc.advance(1e9, max_steps=6)
+    assert pe.n_rebuilds == po.n_rebuilds and pe.total_time == pytest.approx(po.total_time, rel=1e-9)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-8
+    assert np.abs(e["Position"] - o["Position"]).max() < 1e-9 * box
+    eng32, _ = engines(p, s, 4)
+    d3, a3 = eng32.forces_once()
+    i3, i2 = np.argsort(eng32.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    d2b, a2b = make_ref_forces(p, s)
+    assert relmax(d3[i3], d2b) < 5e-4 and relmax(a3[i3], a2b) < 5e-4
+
+
+def make_ref_forces(p, s):
+    from oracle.oracle import make_oracle
+    o = make_oracle(p, s)
+    d, a = o.forces_once()
+    i = np.argsort(o.download(("ID",))["ID"])
+    return d[i], a[i]
