@@ -37,6 +37,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
            # the SLP vectoriser packs the distance tests into v_pk_*_f32 + v_mov shuffles (slower here)
            "-fno-slp-vectorize",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results straight into VGPRs: no v_accvgpr_read per element
            *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:

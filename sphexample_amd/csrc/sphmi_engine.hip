@@ -207,7 +207,7 @@ struct Engine final : EngineBase {
     }
 
     template <int PASS> void launch_force(const ForceParams<T>& P) {
-        dim3 g(P.nblocks), b(kWave);
+        dim3 g((P.nblocks + kTilesPerWG - 1) / kTilesPerWG), b(kWave * kTilesPerWG);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS>), g, b, 0, stream, P);
         else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS>), g, b, 0, stream, P);
         HC(hipGetLastError());

@@ -51,6 +51,9 @@ constexpr int kWave = 64;
 #ifndef SPHMI_RING_ROWS
 #define SPHMI_RING_ROWS 2
 #endif
+#ifndef SPHMI_WG_WAVES
+#define SPHMI_WG_WAVES 1        // tiles (waves) per workgroup: adjacent tiles co-resident on one CU share L1 lines
+#endif
 #ifndef SPHMI_CHUNKS
 #define SPHMI_CHUNKS 4
 #endif
@@ -103,6 +106,28 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// min without the canonicalising v_max the compiler puts in front of fmin (inputs are never signalling NaNs)
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float m; asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b)); return m;
+}
+__device__ __forceinline__ double min_raw(double a, double b) { return a < b ? a : b; }
+
+// 16-/32-byte packet gathers through buffer loads: 32-bit offsets, one address instruction per gather
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gather_packet(__amdgpu_buffer_rsrc_t r, int j, float) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, j << 4, 0, 0);
+    float4 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+    return f;
+}
+__device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, int j, double) {
+    const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(r, j << 5, 0, 0);
+    const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(r, (j << 5) + 16, 0, 0);
+    double4 f;
+    f.x = __longlong_as_double(((long long)lo.y << 32) | lo.x); f.y = __longlong_as_double(((long long)lo.w << 32) | lo.z);
+    f.z = __longlong_as_double(((long long)hi.y << 32) | hi.x); f.w = __longlong_as_double(((long long)hi.w << 32) | hi.z);
+    return f;
+}
+
 // EquationOfStateGamma7 — src/SimulationEquations.jl:9-11
 template <class T> __device__ __forceinline__ T eos7(T rho, T rho0, T inv_rho0, T Cbe) {
     T r;
@@ -149,8 +174,17 @@ __device__ __forceinline__ void swap_halves(unsigned& p, unsigned& q) {
     p = r[0]; q = r[1];
 }
 
+constexpr int kTilesPerWG = SPHMI_WG_WAVES;
+
+// LDS hand-off inside ONE wave (ds operations of a wave execute in order; this only pins the compiler)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <class T, int D, int PASS>
-__global__ void __launch_bounds__(kWave)
+__global__ void __launch_bounds__(kWave * kTilesPerWG)
 k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
@@ -158,20 +192,23 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int K = kChunkGroup;                         // 64-candidate chunks per row and pass
     static_assert((RB & (RB - 1)) == 0 && (K & (K - 1)) == 0, "ring geometry: powers of two");
     constexpr int NSLOT = RB * K;
-    __shared__ unsigned long long s_mask[NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
-    __shared__ int s_lo[RB * kWave];                       // [row % RB][lane] the lane's own 3-cell range in that row
-    __shared__ int s_hi[RB * kWave];
-    __shared__ int s_gb[RB];                               // [row % RB] candidate index of bit 0 of chunk 0
+    __shared__ unsigned long long s_mask_all[kTilesPerWG * NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
+    __shared__ int s_base_all[kTilesPerWG * NSLOT];        // [row % RB][chunk] candidate index of bit 0 of that mask
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    unsigned long long* const s_mask = s_mask_all + wv * NSLOT * kWave;
+    int* const s_base = s_base_all + wv * NSLOT;
     // XCD-aware tile order.  The dispatcher places block b on XCD b % 8; every XCD gets one contiguous
     // run of tiles so that neighbouring tiles (which share their source rows) share one L2.  Measured on
     // the 1 M-particle dam break: contiguous 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
     int b = blockIdx.x;
     {
-        const int nb = P.nblocks, per = nb >> 3;
+        const int nb = gridDim.x, per = nb >> 3;
         if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
     }
+    b = b * kTilesPerWG + wv;
+    if (b >= P.nblocks) return;                            // no workgroup-level barrier anywhere below
     const int t0 = b * kWave;
     const int a = t0 + lane;
     const bool valid = a < P.N;
@@ -220,7 +257,7 @@ k_neighbor_force(const ForceParams<T> P) {
     T drho = 0, ax = 0, ay = 0, az = 0;
 
     // ---- pair physics for one accepted neighbour j ------------------------------------------
-    auto pair = [&](const int j, const V4& n0, const V4& n1, const bool in_range) {
+    auto pair = [&](const int j, const V4& n0, const V4& n1) {
         const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
         const T r2 = dx * dx + dy * dy + dz * dz;
         T rho_b, rhon_b, P_b, s_b;
@@ -231,14 +268,11 @@ k_neighbor_force(const ForceParams<T> P) {
             rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
         }
         // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280).
-        // The phase-1 mask is slightly generous and tile-wide: the exact r² ≤ H² test (:275) and the
-        // "candidate lies in MY three cells of this row" test of the reference's stale cell list are here.
+        // The phase-1 mask is slightly generous; the r² ≤ H² cut of :275 needs no branch here: beyond H the
+        // clamp makes (q−2)³ = 0 and every pair term below carries the factor `fac`.
         const T r = fast_sqrt(r2);
-        T qq = r * P.h_inv;
-        qq = qq > T(2) ? T(2) : qq;
-        const T tq = qq - T(2);
-        T fac = P.Cgw * (tq * tq * tq);
-        fac = (r2 <= P.H2 && in_range) ? fac : T(0);
+        const T tq = min_raw(r * P.h_inv, T(2)) - T(2);
+        const T fac = P.Cgw * (tq * tq * tq);
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
         const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
@@ -262,7 +296,7 @@ k_neighbor_force(const ForceParams<T> P) {
         T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
         if (P.visc) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
-            const T vneg = vdx < T(0) ? vdx : T(0);
+            const T vneg = min_raw(vdx, T(0));
             coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
         }
         coef *= fac;
@@ -273,37 +307,34 @@ k_neighbor_force(const ForceParams<T> P) {
     // The masks of the last RB cell rows live in an LDS ring.  Lanes consume at their own pace: a lane
     // with few neighbours in the old rows runs ahead into the newer ones instead of idling, and a ring
     // row is only recycled once EVERY lane is through with it.
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     int cs = 0;                      // next slot (absolute: row * K + chunk) this lane will fetch
-    int cbase = 0, clo = 0;          // candidate index of bit 0 of the current mask; own range start
-    unsigned cwid = 0;               // own range width in the current row
+    int cbase = 0;                   // candidate index of bit 0 of the current mask
     unsigned long long cm = 0;       // unconsumed bits of the current mask
-    auto consume = [&](const int upto, const int produced) {
+    // consume(): run until every lane has FETCHED all slots < upto (a fetched mask lives in registers, so the
+    // ring position is free); `drain` also waits for the fetched bits themselves (last call of a pass).
+    auto consume = [&](const int upto, const int produced, const bool drain) {
 #if SPHMI_ABL_NO_CONSUME
-        ax += T(s_mask[lane] & 1) + T(s_lo[lane] + s_hi[lane] + s_gb[0]);
+        ax += T(s_mask[lane] & 1) + T(s_base[0]);
         return;
 #endif
-        __syncthreads();
-        // a lane still owes old work if it has not fetched all slots < upto, or is inside one of them
+        wave_sync();
         auto any_owes = [&]() -> bool {
-            const bool owes = (cs < upto) | ((cm != 0) & (cs <= upto));
+            bool owes = cs < upto;
+            if (drain) owes |= (cm != 0);
             return __builtin_amdgcn_ballot_w64(owes) != 0;
-        };
-        auto refill = [&]() {
-            const bool need = (cm == 0) & (cs < produced);
-            const int rr = (cs >> kLogChunks) & (RB - 1);
-            const unsigned long long nm = s_mask[(cs & (NSLOT - 1)) * kWave + lane];
-            const int nlo = s_lo[rr * kWave + lane];
-            const int nhi = s_hi[rr * kWave + lane];
-            const int ngb = s_gb[rr] + ((cs & (K - 1)) << 6);
-            cm = need ? nm : cm;
-            cbase = need ? ngb : cbase;
-            clo = need ? nlo : clo;
-            cwid = need ? (unsigned)(nhi - nlo) : cwid;
-            cs += need ? 1 : 0;
         };
         bool go = any_owes();
         while (go) {
-            refill();
+            // branch-free refill: every lane reads its next slot, lanes with an empty mask take it
+            const bool need = (cm == 0) & (cs < produced);
+            const int si = cs & (NSLOT - 1);
+            const unsigned long long nm = s_mask[si * kWave + lane];
+            const int nb = s_base[si];
+            cm = need ? nm : cm;
+            cbase = need ? nb : cbase;
+            cs += need ? 1 : 0;
             if (cm != 0) {
                 const int j = cbase + __builtin_ctzll(cm);
                 cm &= cm - 1;
@@ -311,19 +342,19 @@ k_neighbor_force(const ForceParams<T> P) {
                 ax += T(j);
 #else
 #if SPHMI_ABL_GATHER == 1
-                const V4 n0 = P.src0[j]; const V4 n1 = q1;
+                const V4 n0 = gather_packet(rs0, j, T()); const V4 n1 = q1;
 #elif SPHMI_ABL_GATHER == 2
                 const V4 n0 = q0; const V4 n1 = q1;
 #else
-                const V4 n0 = P.src0[j];
-                const V4 n1 = P.src1[j];
+                const V4 n0 = gather_packet(rs0, j, T());
+                const V4 n1 = gather_packet(rs1, j, T());
 #endif
-                pair(j, n0, n1, (unsigned)(j - clo) < cwid);
+                pair(j, n0, n1);
 #endif
             }
             go = any_owes();
         }
-        __syncthreads();
+        wave_sync();
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -396,7 +427,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #pragma unroll 1
         for (int seg = 0; seg < NSEG; ++seg) {
             // recycle ring position seg % RB: every lane must be through row seg − RB
-            if (seg >= RB) consume((seg - RB + 1) * K, seg * K);
+            if (seg >= RB) consume((seg - RB + 1) * K, seg * K, false);
             const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
                                      : (seg - 1) * P.nxp;
             // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
@@ -411,14 +442,21 @@ k_neighbor_force(const ForceParams<T> P) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 unsigned long long m = 0;
-                if (k * kWave < rem) m = scan_chunk(gb + k * kWave, HI, rr * K + k);
+                if (k * kWave < rem) {
+                    const int cb = gb + k * kWave;
+                    m = scan_chunk(cb, HI, rr * K + k);
+                    // keep only the candidates of MY three cells of this row (the reference's stale cell
+                    // list, quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
+                    const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
+                    const int w = b1 - b0;
+                    const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
+                    m = (w > 0) ? (m & rm) : 0ull;
+                }
                 s_mask[(rr * K + k) * kWave + lane] = m;
+                if (lane == 0) s_base[rr * K + k] = gb + k * kWave;
             }
-            s_lo[rr * kWave + lane] = lo_l;
-            s_hi[rr * kWave + lane] = hi_l;
-            if (lane == 0) s_gb[rr] = gb;
         }
-        consume(NSEG * K, NSEG * K);
+        consume(NSEG * K, NSEG * K, true);
         if (!more) break;
     }
 
