@@ -131,7 +131,7 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&key[k], n * 4));
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
-        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 4 * 8));
+        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
     ~Engine() override {
@@ -146,6 +146,14 @@ struct Engine final : EngineBase {
         }
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
+#ifdef SPHMI_STATS
+        {   // experiment build: loop statistics of the neighbour kernel, summed over every launch
+            unsigned long long st[16];
+            if (hipMemcpy(st, red_d, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[sphmi stats] wave-iterations %llu  lane-iterations %llu  refills %llu  empty refills %llu  chunks %llu  waves %llu\n",
+                        st[8], st[9], st[10], st[11], st[12], st[13]);
+        }
+#endif
         (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
         (void)hipFree(cellx_d);

@@ -48,19 +48,15 @@ constexpr int kWave = 64;
 #ifndef SPHMI_ABL_NO_P2
 #define SPHMI_ABL_NO_P2 0
 #endif
-#ifndef SPHMI_RING_ROWS
-#define SPHMI_RING_ROWS 2
-#endif
 #ifndef SPHMI_WG_WAVES
-#define SPHMI_WG_WAVES 1        // tiles (waves) per workgroup: adjacent tiles co-resident on one CU share L1 lines
+#define SPHMI_WG_WAVES 1        // tiles (waves) per workgroup (measured: 1 is best; 2-8 within 4 %, 16 slower)
 #endif
-#ifndef SPHMI_CHUNKS
-#define SPHMI_CHUNKS 4
+#ifndef SPHMI_QUEUE
+#define SPHMI_QUEUE 8           // per-lane queue of non-empty 32-candidate accept masks (entries; power of two)
 #endif
-constexpr int kChunkGroup = SPHMI_CHUNKS;   // candidate chunks (64 each) per cell row held in registers / LDS slots
-
-static_assert(kChunkGroup == 1 || kChunkGroup == 2 || kChunkGroup == 4, "SPHMI_CHUNKS must be 1, 2 or 4");
-constexpr int kLogChunks = kChunkGroup == 4 ? 2 : (kChunkGroup == 2 ? 1 : 0);
+#ifndef SPHMI_QUEUE_SLACK
+#define SPHMI_QUEUE_SLACK 4     // a full queue is consumed down to QUEUE − 1 − SLACK entries before scanning goes on
+#endif
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 
@@ -188,17 +184,16 @@ __global__ void __launch_bounds__(kWave * kTilesPerWG)
 k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    constexpr int RB = SPHMI_RING_ROWS;                    // cell rows buffered in the LDS ring
-    constexpr int K = kChunkGroup;                         // 64-candidate chunks per row and pass
-    static_assert((RB & (RB - 1)) == 0 && (K & (K - 1)) == 0, "ring geometry: powers of two");
-    constexpr int NSLOT = RB * K;
-    __shared__ unsigned long long s_mask_all[kTilesPerWG * NSLOT * kWave];   // [row % RB][chunk][lane] accept masks
-    __shared__ int s_base_all[kTilesPerWG * NSLOT];        // [row % RB][chunk] candidate index of bit 0 of that mask
+    constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
+    static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
+    // entry = { 32-bit accept mask, candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
+    __shared__ uint2 s_q_all[kTilesPerWG * QCAP * kWave];  // [entry][lane]
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
-    unsigned long long* const s_mask = s_mask_all + wv * NSLOT * kWave;
-    int* const s_base = s_base_all + wv * NSLOT;
+    // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
+    // program order is all the synchronisation the queue needs
+    uint2* const s_q = s_q_all + wv * QCAP * kWave + lane;
     // XCD-aware tile order.  The dispatcher places block b on XCD b % 8; every XCD gets one contiguous
     // run of tiles so that neighbouring tiles (which share their source rows) share one L2.  Measured on
     // the 1 M-particle dam break: contiguous 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
@@ -309,34 +304,38 @@ k_neighbor_force(const ForceParams<T> P) {
     // row is only recycled once EVERY lane is through with it.
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
-    int cs = 0;                      // next slot (absolute: row * K + chunk) this lane will fetch
+#ifdef SPHMI_STATS
+    unsigned long long st_it = 0, st_lane = 0, st_ref = 0, st_emp = 0, st_chunks = 0;
+#endif
+    int wpos = 0, rpos = 0;          // this lane's queue: entries written / fetched so far
     int cbase = 0;                   // candidate index of bit 0 of the current mask
-    unsigned long long cm = 0;       // unconsumed bits of the current mask
-    // consume(): run until every lane has FETCHED all slots < upto (a fetched mask lives in registers, so the
-    // ring position is free); `drain` also waits for the fetched bits themselves (last call of a pass).
-    auto consume = [&](const int upto, const int produced, const bool drain) {
+    unsigned cm = 0;                 // unconsumed bits of the current mask
+    // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
+    // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
+    // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
+    auto run_pairs = [&](const int keep, const bool drain) {
 #if SPHMI_ABL_NO_CONSUME
-        ax += T(s_mask[lane] & 1) + T(s_base[0]);
+        ax += T(s_q[0].x & 1); rpos = wpos;
         return;
 #endif
-        wave_sync();
         auto any_owes = [&]() -> bool {
-            bool owes = cs < upto;
+            bool owes = (wpos - rpos) > keep;
             if (drain) owes |= (cm != 0);
             return __builtin_amdgcn_ballot_w64(owes) != 0;
         };
         bool go = any_owes();
         while (go) {
-            // branch-free refill: every lane reads its next slot, lanes with an empty mask take it
-            const bool need = (cm == 0) & (cs < produced);
-            const int si = cs & (NSLOT - 1);
-            const unsigned long long nm = s_mask[si * kWave + lane];
-            const int nb = s_base[si];
-            cm = need ? nm : cm;
-            cbase = need ? nb : cbase;
-            cs += need ? 1 : 0;
+            const bool need = (cm == 0) & (rpos != wpos);
+            const uint2 ne = s_q[(rpos & (QCAP - 1)) * kWave];
+            cm = need ? ne.x : cm;
+            cbase = need ? (int)ne.y : cbase;
+            rpos += need ? 1 : 0;
+#ifdef SPHMI_STATS
+            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cm != 0));
+            st_ref += __builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
+#endif
             if (cm != 0) {
-                const int j = cbase + __builtin_ctzll(cm);
+                const int j = cbase + __builtin_ctz(cm);
                 cm &= cm - 1;
 #if SPHMI_ABL_NO_P2
                 ax += T(j);
@@ -354,7 +353,6 @@ k_neighbor_force(const ForceParams<T> P) {
             }
             go = any_owes();
         }
-        wave_sync();
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -372,7 +370,7 @@ k_neighbor_force(const ForceParams<T> P) {
         B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
         A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
     }
-    auto scan_chunk = [&](const int cb, const int HI, const int slot) -> unsigned long long {
+    auto scan_chunk = [&](const int cb, const int HI) -> unsigned long long {
         if constexpr (sizeof(T) == 4) {
             const int c = cb + bperm;
             const bool cv = c < HI;
@@ -421,45 +419,42 @@ k_neighbor_force(const ForceParams<T> P) {
     };
 
 #pragma unroll 1
-    for (int g = 0;; ++g) {          // chunk-group passes: g > 0 only when a row holds more than K·64 candidates
-        bool more = false;
-        cs = 0; cm = 0;
+    for (int seg = 0; seg < NSEG; ++seg) {
+        const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
+                                 : (seg - 1) * P.nxp;
+        // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
+        const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
+        const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
+        // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
+        const int LO = rl_i(lo_l, 0);
+        const int HI = rl_i(hi_l, last_lane);
 #pragma unroll 1
-        for (int seg = 0; seg < NSEG; ++seg) {
-            // recycle ring position seg % RB: every lane must be through row seg − RB
-            if (seg >= RB) consume((seg - RB + 1) * K, seg * K, false);
-            const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
-                                     : (seg - 1) * P.nxp;
-            // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
-            const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
-            const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
-            // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
-            const int gb = rl_i(lo_l, 0) + g * K * kWave;
-            const int HI = rl_i(hi_l, last_lane);
-            const int rem = HI - gb;
-            if (rem > K * kWave) more = true;
-            const int rr = seg & (RB - 1);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                unsigned long long m = 0;
-                if (k * kWave < rem) {
-                    const int cb = gb + k * kWave;
-                    m = scan_chunk(cb, HI, rr * K + k);
-                    // keep only the candidates of MY three cells of this row (the reference's stale cell
-                    // list, quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
-                    const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
-                    const int w = b1 - b0;
-                    const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
-                    m = (w > 0) ? (m & rm) : 0ull;
-                }
-                s_mask[(rr * K + k) * kWave + lane] = m;
-                if (lane == 0) s_base[rr * K + k] = gb + k * kWave;
-            }
+        for (int cb = LO; cb < HI; cb += kWave) {
+            // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
+            if (__builtin_amdgcn_ballot_w64((wpos - rpos) > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
+            unsigned long long m = scan_chunk(cb, HI);
+#ifdef SPHMI_STATS
+            st_chunks += 1;
+#endif
+            // keep only the candidates of MY three cells of this row (the reference's stale cell list,
+            // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
+            const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
+            const int w = b1 - b0;
+            const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
+            m = (w > 0) ? (m & rm) : 0ull;
+            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+            if (mlo != 0) { s_q[(wpos & (QCAP - 1)) * kWave] = make_uint2(mlo, (unsigned)cb); wpos += 1; }
+            if (mhi != 0) { s_q[(wpos & (QCAP - 1)) * kWave] = make_uint2(mhi, (unsigned)(cb + 32)); wpos += 1; }
         }
-        consume(NSEG * K, NSEG * K, true);
-        if (!more) break;
     }
+    run_pairs(0, true);
 
+#ifdef SPHMI_STATS
+    if (lane == 0) {
+        atomicAdd(&P.red[8], st_it); atomicAdd(&P.red[9], st_lane); atomicAdd(&P.red[10], st_ref);
+        atomicAdd(&P.red[11], st_emp); atomicAdd(&P.red[12], st_chunks); atomicAdd(&P.red[13], 1ull);
+    }
+#endif
     // ---- epilogue ---------------------------------------------------------------------------
     // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
     // state arrives by halo exchange, so nothing is stored or reduced for them

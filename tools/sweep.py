@@ -32,6 +32,9 @@ for spec in args:
     if not line:
         print(f"{name}: FAILED\n{r.stdout[-500:]}\n{r.stderr[-1500:]}")
         continue
+    for l in r.stderr.splitlines():
+        if l.startswith("[sphmi"):
+            print(f"{name}: {l}")
     j = json.loads(line[-1])
     print(f"{name:28s} flags[{flags}]  {j['value']:.4g} upd/s  step {j['ms_per_step']:.3f} ms  "
           f"force-kernel {j['roofline']['avg_launch_ms']:.3f} ms", flush=True)
