@@ -95,6 +95,8 @@ struct Engine final : EngineBase {
     int cur = 0;                       // which of the [2] copies is live
     int *slot = nullptr, *tmp_idx = nullptr, *perm = nullptr;
     int *count = nullptr, *cstart = nullptr, *tsum = nullptr;
+    int *tile_cost = nullptr, *tile_scan = nullptr, *tile_order = nullptr, *tile_tsum = nullptr, *part_d = nullptr, *part_h = nullptr;
+    int part_max = 0;                  // tiles in the longest XCD run (grid = 8 × part_max blocks)
     int64_t cell_cap = 0;
     int *bbox_d = nullptr, *misc_d = nullptr;              // misc: [0] nonempty, [1] scan total
     unsigned long long* red_d = nullptr;
@@ -131,6 +133,9 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&key[k], n * 4));
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
+        const size_t nt = n / kWave + 2;
+        HC(hipMalloc(&tile_cost, nt * 4)); HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_order, nt * 4));
+        HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 16 * 4)); HC(hipHostMalloc(&part_h, 16 * 4));
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
@@ -145,6 +150,7 @@ struct Engine final : EngineBase {
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
         }
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
+        (void)hipFree(tile_cost); (void)hipFree(tile_scan); (void)hipFree(tile_order); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #ifdef SPHMI_STATS
         {   // experiment build: loop statistics of the neighbour kernel, summed over every launch
@@ -198,6 +204,7 @@ struct Engine final : EngineBase {
         P.red = red_d;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
         P.nblocks = (N + kWave - 1) / kWave;
+        P.order = tile_order; P.part = part_d;
         P.visc = cfg.viscosity == SPHMI_VISC_ARTIFICIAL;
         P.ddt = cfg.density_diffusion == SPHMI_DDT_LINEAR;
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
@@ -215,7 +222,7 @@ struct Engine final : EngineBase {
     }
 
     template <int PASS> void launch_force(const ForceParams<T>& P) {
-        dim3 g((P.nblocks + kTilesPerWG - 1) / kTilesPerWG), b(kWave * kTilesPerWG);
+        dim3 g(8 * part_max), b(kWave);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS>), g, b, 0, stream, P);
         else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS>), g, b, 0, stream, P);
         HC(hipGetLastError());
@@ -285,6 +292,21 @@ struct Engine final : EngineBase {
         cur = nxt;
         HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
         nonempty_pending = true;
+        {   // tile schedule of the neighbour kernel (sphmi_rebuild.h, "Tile schedule")
+            const int ntile = (N + kWave - 1) / kWave;
+            const int sb = (ntile + kScanTile - 1) / kScanTile;
+            hipLaunchKernelGGL(k_tile_cost, dim3((ntile + 255) / 256), dim3(256), 0, stream, key[cur], cstart, N, ntile,
+                               grid.np[0], grid.np[0] * grid.np[1], D, tile_cost);
+            hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_cost, tile_scan, ntile, tile_tsum, misc_d + 2);
+            hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
+            hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost, tile_scan, ntile, tile_order, part_d);
+            HC(hipGetLastError());
+            HC(hipMemcpyAsync(part_h, part_d, 9 * 4, hipMemcpyDeviceToHost, stream));
+            HC(hipStreamSynchronize(stream));
+            part_max = 0;
+            for (int x = 0; x < 8; ++x) part_max = std::max(part_max, part_h[x + 1] - part_h[x]);
+        }
         have_grid = true;
         n_rebuilds += 1;
         end_phase(ev);

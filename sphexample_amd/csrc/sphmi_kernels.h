@@ -48,9 +48,6 @@ constexpr int kWave = 64;
 #ifndef SPHMI_ABL_NO_P2
 #define SPHMI_ABL_NO_P2 0
 #endif
-#ifndef SPHMI_WG_WAVES
-#define SPHMI_WG_WAVES 1        // tiles (waves) per workgroup (measured: 1 is best; 2-8 within 4 %, 16 slower)
-#endif
 #ifndef SPHMI_QUEUE
 #define SPHMI_QUEUE 8           // per-lane queue of non-empty 32-candidate accept masks (entries; power of two)
 #endif
@@ -74,6 +71,8 @@ struct ForceParams {
     const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
     const uint8_t* type;
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
+    const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
+    const int* part;     // 9 run boundaries
     int N, nxp, nxyp, nblocks;
     int visc, ddt;
     T dt, dt2;
@@ -170,7 +169,6 @@ __device__ __forceinline__ void swap_halves(unsigned& p, unsigned& q) {
     p = r[0]; q = r[1];
 }
 
-constexpr int kTilesPerWG = SPHMI_WG_WAVES;
 
 // LDS hand-off inside ONE wave (ds operations of a wave execute in order; this only pins the compiler)
 __device__ __forceinline__ void wave_sync() {
@@ -180,30 +178,29 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 template <class T, int D, int PASS>
-__global__ void __launch_bounds__(kWave * kTilesPerWG)
+__global__ void __launch_bounds__(kWave)
 k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
     static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
-    __shared__ uint2 s_q_all[kTilesPerWG * QCAP * kWave];  // [entry][lane]
+    __shared__ uint2 s_q_all[QCAP * kWave];                // [entry][lane]
 
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
     // program order is all the synchronisation the queue needs
-    uint2* const s_q = s_q_all + wv * QCAP * kWave + lane;
-    // XCD-aware tile order.  The dispatcher places block b on XCD b % 8; every XCD gets one contiguous
-    // run of tiles so that neighbouring tiles (which share their source rows) share one L2.  Measured on
-    // the 1 M-particle dam break: contiguous 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
-    int b = blockIdx.x;
+    uint2* const s_q = s_q_all + lane;
+    // Tile schedule (sphmi_rebuild.h): the dispatcher places block b on XCD b % 8; every XCD works through
+    // one contiguous, cost-balanced run of tiles, expensive tiles first.  Measured on the 1 M-particle dam
+    // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
+    int b;
     {
-        const int nb = gridDim.x, per = nb >> 3;
-        if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
+        const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+        const int pb = P.part[x], pe = P.part[x + 1];
+        if (r >= pe - pb) return;
+        b = P.order[pb + r];
     }
-    b = b * kTilesPerWG + wv;
-    if (b >= P.nblocks) return;                            // no workgroup-level barrier anywhere below
     const int t0 = b * kWave;
     const int a = t0 + lane;
     const bool valid = a < P.N;

@@ -160,6 +160,65 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(int* out, int n, cons
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
+// ------------------------------------------------------------------------------------------
+// Tile schedule of the neighbour kernel.  The dispatcher hands block b to XCD b % 8 and workgroups start
+// in block order, so the engine decides (at every rebuild) WHICH tile each block processes:
+//   * every XCD gets one contiguous run of tiles (neighbouring tiles share source rows → one L2), with
+//     the run boundaries placed so that the eight runs carry equal estimated cost (the water is not
+//     spread evenly over the sorted order: equal-count runs were 8 % out of balance on the dam break);
+//   * inside a run the expensive tiles start first and the cheap wall tiles fill the tail.
+// cost(tile) = candidates its phase 1 scans = Σ over cell rows of the union range length.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cstart, int N, int ntile, int nxp,
+                                                   int nxyp, int D, int* cost) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntile) return;
+    const int kf = key[t * 64], kl = key[min(t * 64 + 63, N - 1)];
+    const int nseg = D == 3 ? 9 : 3;
+    int c = 64;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
+        c += cstart[kl + off + 2] - cstart[kf + off - 1];
+    }
+    cost[t] = c;
+}
+
+constexpr int kTileBuckets = 64;
+// one workgroup per XCD run: find the run, then bucket-sort its tiles by descending cost
+__global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
+                                                     int* part) {
+    __shared__ int s_min, s_max, s_hist[kTileBuckets], s_cur[kTileBuckets];
+    const int x = blockIdx.x;
+    const long long total = cscan[ntile];
+    auto lower_bound = [&](long long v) {
+        int lo = 0, hi = ntile;                       // first t with cscan[t] >= v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cscan[mid] < v) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const int beg = x == 0 ? 0 : lower_bound(total * x / 8);
+    const int end = x == 7 ? ntile : lower_bound(total * (x + 1) / 8);
+    if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; }
+    if (threadIdx.x < kTileBuckets) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    int mn = INT32_MAX, mx = INT32_MIN;
+    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; mn = min(mn, c); mx = max(mx, c); }
+    if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    const int cmin = s_min;
+    const float scale = s_max > cmin ? (float)(kTileBuckets - 1) / (float)(s_max - cmin) : 0.f;
+    // bucket 0 = most expensive
+    auto bucket = [&](int c) { return kTileBuckets - 1 - (int)((float)(c - cmin) * scale); };
+    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) atomicAdd(&s_hist[bucket(cost[t])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < kTileBuckets; ++b) { s_cur[b] = run; run += s_hist[b]; }
+    }
+    __syncthreads();
+    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) order[beg + atomicAdd(&s_cur[bucket(cost[t])], 1)] = t;
+    if (threadIdx.x == 0) { part[x] = beg; if (x == 7) part[8] = ntile; }
+}
+
 __global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const int* slot, const int* cstart,
                                                  int* tmp_idx) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
