@@ -203,10 +203,7 @@ struct Engine final : EngineBase {
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_d;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
-        P.nblocks = (N + kWave - 1) / kWave;
         P.order = tile_order; P.part = part_d;
-        P.visc = cfg.viscosity == SPHMI_VISC_ARTIFICIAL;
-        P.ddt = cfg.density_diffusion == SPHMI_DDT_LINEAR;
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
         P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
@@ -221,11 +218,20 @@ struct Engine final : EngineBase {
         return P;
     }
 
-    template <int PASS> void launch_force(const ForceParams<T>& P) {
+    template <int PASS, int MODEL> void launch_force_model(const ForceParams<T>& P) {
         dim3 g(8 * part_max), b(kWave);
-        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS>), g, b, 0, stream, P);
-        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS>), g, b, 0, stream, P);
+        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL>), g, b, 0, stream, P);
+        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL>), g, b, 0, stream, P);
         HC(hipGetLastError());
+    }
+    template <int PASS> void launch_force(const ForceParams<T>& P) {
+        const int model = (cfg.viscosity == SPHMI_VISC_ARTIFICIAL ? 1 : 0) | (cfg.density_diffusion == SPHMI_DDT_LINEAR ? 2 : 0);
+        switch (model) {
+            case 0: launch_force_model<PASS, 0>(P); break;
+            case 1: launch_force_model<PASS, 1>(P); break;
+            case 2: launch_force_model<PASS, 2>(P); break;
+            default: launch_force_model<PASS, 3>(P); break;
+        }
     }
 
     // ---- UpdateNeighbors! -------------------------------------------------------------------

@@ -73,8 +73,7 @@ struct ForceParams {
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // 9 run boundaries
-    int N, nxp, nxyp, nblocks;
-    int visc, ddt;
+    int N, nxp, nxyp;
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
 };
@@ -177,9 +176,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class T, int D, int PASS>
+// MODEL: bit 0 = ArtificialViscosity, bit 1 = LinearDensityDiffusion (compile-time: no uniform branches per pair)
+template <class T, int D, int PASS, int MODEL>
 __global__ void __launch_bounds__(kWave)
 k_neighbor_force(const ForceParams<T> P) {
+    constexpr bool kVisc = (MODEL & 1) != 0, kDdt = (MODEL & 2) != 0;
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
@@ -271,7 +272,7 @@ k_neighbor_force(const ForceParams<T> P) {
         // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
         drho += rm_a * inv_rho_b * (fac * vdx);
         const T inv_r2e = fast_rcp(r2 + P.eta2);
-        if (P.ddt) {
+        if constexpr (kDdt) {
             // LinearDensityDiffusion, src/SPHDensityDiffusionModels.jl:116-133; orientation rule
             // of SURVEY §8(a)-Q4: target plays "i" iff j sorts before its cell, or after it inside it
             const T dlast = (D == 3) ? dz : dy;
@@ -286,7 +287,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
         T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
-        if (P.visc) {
+        if constexpr (kVisc) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
             const T vneg = min_raw(vdx, T(0));
             coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);

@@ -278,3 +278,24 @@ def make_ref_forces(p, s):
     d, a = o.forces_once()
     i = np.argsort(o.download(("ID",))["ID"])
     return d[i], a[i]
+
+
+@pytest.mark.parametrize("visc,ddt", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("fb,tol", [(8, 1e-10), (4, 5e-4)])
+def test_model_switches(dam_break_2d, visc, ddt, fb, tol):
+    """ZeroViscosity / ArtificialViscosity × no DDT / LinearDensityDiffusion are four compiled variants of the
+    neighbour kernel (src/SPHViscosityModels.jl:43-74, src/SPHDensityDiffusionModels.jl:36-133)."""
+    import dataclasses
+    from sphexample_amd import ZeroViscosity, ArtificialViscosity, ZeroDensityDiffusion, LinearDensityDiffusion
+    p, s = dam_break_2d
+    p = perturbed(p, seed=5)
+    s = dataclasses.replace(s, SimViscosity=ArtificialViscosity() if visc else ZeroViscosity(),
+                            SimDensityDiffusion=LinearDensityDiffusion() if ddt else ZeroDensityDiffusion())
+    eng, orc = engines(p, s, fb)
+    d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+    i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol
+    eng, orc = engines(p, s, fb)
+    eng.advance(1e9, max_steps=10); orc.advance(1e9, max_steps=10)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < (1e-9 if fb == 8 else 1e-5)
