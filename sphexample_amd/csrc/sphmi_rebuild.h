@@ -183,11 +183,17 @@ __global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cs
     cost[t] = c;
 }
 
-constexpr int kTileBuckets = 64;
-// one workgroup per XCD run: find the run, then bucket-sort its tiles by descending cost
+#ifndef SPHMI_TILE_CLASSES
+#define SPHMI_TILE_CLASSES 4
+#endif
+constexpr int kTileClasses = SPHMI_TILE_CLASSES;
+// one workgroup per XCD run: find the run, then a STABLE partition of its tiles into cost classes, most
+// expensive class first.  Inside a class the tiles keep their sorted order, so the ~1000 tiles an XCD has
+// in flight at any time are still neighbours in space and share their source rows in its L2 (a full sort
+// by cost tripled the HBM fetch of the neighbour kernel).
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
                                                      int* part) {
-    __shared__ int s_min, s_max, s_hist[kTileBuckets], s_cur[kTileBuckets];
+    __shared__ int s_min, s_max, s_wsum[16], s_off;
     const int x = blockIdx.x;
     const long long total = cscan[ntile];
     auto lower_bound = [&](long long v) {
@@ -197,25 +203,34 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     };
     const int beg = x == 0 ? 0 : lower_bound(total * x / 8);
     const int end = x == 7 ? ntile : lower_bound(total * (x + 1) / 8);
-    if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; }
-    if (threadIdx.x < kTileBuckets) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; s_off = beg; }
     __syncthreads();
     int mn = INT32_MAX, mx = INT32_MIN;
     for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; mn = min(mn, c); mx = max(mx, c); }
     if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
     const int cmin = s_min;
-    const float scale = s_max > cmin ? (float)(kTileBuckets - 1) / (float)(s_max - cmin) : 0.f;
-    // bucket 0 = most expensive
-    auto bucket = [&](int c) { return kTileBuckets - 1 - (int)((float)(c - cmin) * scale); };
-    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) atomicAdd(&s_hist[bucket(cost[t])], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int b = 0; b < kTileBuckets; ++b) { s_cur[b] = run; run += s_hist[b]; }
+    const float scale = s_max > cmin ? (float)kTileClasses / (float)(s_max - cmin + 1) : 0.f;
+    // class 0 = most expensive
+    auto cls_of = [&](int c) { return kTileClasses - 1 - min(kTileClasses - 1, (int)((float)(c - cmin) * scale)); };
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int cls = 0; cls < kTileClasses; ++cls) {
+        for (int t0 = beg; t0 < end; t0 += 1024) {
+            const int t = t0 + (int)threadIdx.x;
+            const bool in = t < end && cls_of(cost[t]) == cls;
+            const unsigned long long bal = __ballot(in);
+            const int below = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wsum[w] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int k = 0; k < 16; ++k) { const int v = s_wsum[k]; if (k < w) woff += v; tot += v; }
+            const int base = s_off;
+            if (in) order[base + woff + below] = t;
+            __syncthreads();
+            if (threadIdx.x == 0) s_off = base + tot;
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) order[beg + atomicAdd(&s_cur[bucket(cost[t])], 1)] = t;
     if (threadIdx.x == 0) { part[x] = beg; if (x == 7) part[8] = ntile; }
 }
 
