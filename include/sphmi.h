@@ -168,20 +168,26 @@ int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local)
  * launches since the last reset, and the number of launches. */
 int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 
-/* ---- domain decomposition: one process per GPU, x-slabs with a one-cell halo --------------------
+/* ---- domain decomposition: one process per GPU, slabs along one axis with a one-cell halo ---------
  * The reference has no multi-process path; these entry points let a host driver
  * (sphexample_amd/distributed.py: torch.distributed over RCCL) run the SAME kernels on a slab of the
  * domain.  The handle is created with n_particles = the rank's CAPACITY; the live count changes at every
  * cell-list rebuild (migration + ghost layer).  Ghost copies carry type bit 0x80 (owned by the left
  * neighbour) or 0x40 (right neighbour): they act as neighbours only, their state arrives by halo exchange
  * before each neighbour pass.  `*_dev` pointers are DEVICE pointers (e.g. torch tensors' data_ptr()).
- * One step = reductions → (rebuild) → halo(A) → pass 1 → halo(H) → pass 2, all driven by the host. */
+ * One step = reductions → (rebuild) → halo(A) → pass 1 → halo(H) → pass 2, all driven by the host.
+ * With sphmi_dd_set_slab the engine also splits every pass into INTERIOR tiles (no ghost in reach: they may
+ * run while the halo is still in flight) and slab-EDGE tiles (sphmi_dd_pass_part). */
 int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream);   /* run on the caller's HIP stream (torch's) */
 int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity,
                     const void* acceleration, const void* density, const uint8_t* type, const int64_t* id,
                     const uint64_t* group_marker);
 int sphmi_dd_count(sphmi_handle* h, int64_t* n_out);                 /* live particles incl. ghosts      */
-int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out);           /* host: global cell x-index, n ints */
+/* Slab of this rank: cell columns col_lo … col_hi (inclusive) along `axis` (0 = x, 1 = y, 2 = z); has_* say
+ * whether a neighbour rank exists on that side.  Takes effect at the next sphmi_dd_rebuild. */
+int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi, int has_lower_neighbour,
+                      int has_upper_neighbour);
+int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out);   /* host: global cell index along the slab axis, n ints */
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out);              /* host: type bytes incl. ghost bits */
 int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out);   /* migration buffer size    */
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev);
@@ -193,6 +199,8 @@ int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t
 int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev);
 int sphmi_dd_reductions(sphmi_handle* h, double* out8);  /* [0] max|x⁺−x|², [1] visc, [2] max|a|², [3] bad ρ */
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt);            /* 1: predictor pass, 2: corrector   */
+/* part 0 = whole pass (same as sphmi_dd_pass), 1 = interior tiles, 2 = slab-edge tiles (completes the pass) */
+int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part);
 int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id,
                             int64_t* n_out);                          /* host fp64 arrays, owned only      */
 int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out);

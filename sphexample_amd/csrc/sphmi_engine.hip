@@ -34,7 +34,7 @@ struct EngineError : std::runtime_error {
 static thread_local std::string g_create_error;
 
 // Phase labels follow the reference's TimerOutputs sections (src/SPHCellList.jl:748-800).
-enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT };
+enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT, PH_PASS1_EDGE, PH_PASS2_EDGE };
 static const char* kPhaseNames[PH_COUNT] = {
     "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
     "05 First NeighborLoop (+06/07 half step)", "08 Second NeighborLoop (+09/10/11 full step)"};
@@ -72,7 +72,8 @@ struct EngineBase {
     virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
     virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) = 0;
     virtual void dd_reductions(double* out8) = 0;
-    virtual void dd_pass(int which, double dt) = 0;
+    virtual void dd_pass(int which, double dt, int part) = 0;
+    virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) = 0;
     virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) = 0;
 };
 
@@ -95,8 +96,13 @@ struct Engine final : EngineBase {
     int cur = 0;                       // which of the [2] copies is live
     int *slot = nullptr, *tmp_idx = nullptr, *perm = nullptr;
     int *count = nullptr, *cstart = nullptr, *tsum = nullptr;
-    int *tile_cost = nullptr, *tile_scan = nullptr, *tile_order = nullptr, *tile_tsum = nullptr, *part_d = nullptr, *part_h = nullptr;
-    int part_max = 0;                  // tiles in the longest XCD run (grid = 8 × part_max blocks)
+    // tile schedules of the neighbour kernel: list 0 = interior (everything without a slab), list 1 = slab-edge tiles
+    int *tile_cost[2] = {nullptr, nullptr}, *tile_order[2] = {nullptr, nullptr}, *tile_scan = nullptr, *tile_tsum = nullptr;
+    int *part_d = nullptr, *part_h = nullptr;       // 2 × 16 ints: run starts and run lengths per XCD
+    uint8_t* tile_cls = nullptr;
+    int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
+    // domain decomposition: slab axis and the rank's cell-column range along it
+    bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
     int *bbox_d = nullptr, *misc_d = nullptr;              // misc: [0] nonempty, [1] scan total
     unsigned long long* red_d = nullptr;
@@ -134,8 +140,9 @@ struct Engine final : EngineBase {
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
         const size_t nt = n / kWave + 2;
-        HC(hipMalloc(&tile_cost, nt * 4)); HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_order, nt * 4));
-        HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 16 * 4)); HC(hipHostMalloc(&part_h, 16 * 4));
+        for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], nt * 4)); }
+        HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt));
+        HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
@@ -150,7 +157,8 @@ struct Engine final : EngineBase {
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
         }
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
-        (void)hipFree(tile_cost); (void)hipFree(tile_scan); (void)hipFree(tile_order); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
+        for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
+        (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #ifdef SPHMI_STATS
         {   // experiment build: loop statistics of the neighbour kernel, summed over every launch
@@ -180,9 +188,12 @@ struct Engine final : EngineBase {
         for (auto& e : ev_pending) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-                ph_secs[e.phase] += ms * 1e-3;
-                ph_calls[e.phase] += 1;
-                if (e.phase == PH_PASS1 || e.phase == PH_PASS2) { force_ms += ms; force_launches += 1; }
+                // the edge-tile launch of a split pass is part of that pass: its time is added, it is not a call
+                const bool edge = e.phase == PH_PASS1_EDGE || e.phase == PH_PASS2_EDGE;
+                const int ph = e.phase == PH_PASS1_EDGE ? PH_PASS1 : (e.phase == PH_PASS2_EDGE ? PH_PASS2 : e.phase);
+                ph_secs[ph] += ms * 1e-3;
+                ph_calls[ph] += edge ? 0 : 1;
+                if (ph == PH_PASS1 || ph == PH_PASS2) { force_ms += ms; force_launches += edge ? 0 : 1; }
             }
             ev_pool.push_back(e);
         }
@@ -203,7 +214,6 @@ struct Engine final : EngineBase {
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_d;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
-        P.order = tile_order; P.part = part_d;
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
         P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
@@ -218,19 +228,22 @@ struct Engine final : EngineBase {
         return P;
     }
 
-    template <int PASS, int MODEL> void launch_force_model(const ForceParams<T>& P) {
-        dim3 g(8 * part_max), b(kWave);
+    template <int PASS, int MODEL> void launch_force_model(ForceParams<T> P, int list) {
+        if (part_max[list] == 0) return;
+        P.order = tile_order[list]; P.part = part_d + 16 * list;
+        dim3 g(8 * part_max[list]), b(kWave);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL>), g, b, 0, stream, P);
         else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL>), g, b, 0, stream, P);
         HC(hipGetLastError());
     }
-    template <int PASS> void launch_force(const ForceParams<T>& P) {
+    // list: 0 = interior tiles (all tiles when the handle has no slab), 1 = slab-edge tiles
+    template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {
         const int model = (cfg.viscosity == SPHMI_VISC_ARTIFICIAL ? 1 : 0) | (cfg.density_diffusion == SPHMI_DDT_LINEAR ? 2 : 0);
         switch (model) {
-            case 0: launch_force_model<PASS, 0>(P); break;
-            case 1: launch_force_model<PASS, 1>(P); break;
-            case 2: launch_force_model<PASS, 2>(P); break;
-            default: launch_force_model<PASS, 3>(P); break;
+            case 0: launch_force_model<PASS, 0>(P, list); break;
+            case 1: launch_force_model<PASS, 1>(P, list); break;
+            case 2: launch_force_model<PASS, 2>(P, list); break;
+            default: launch_force_model<PASS, 3>(P, list); break;
         }
     }
 
@@ -298,20 +311,32 @@ struct Engine final : EngineBase {
         cur = nxt;
         HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
         nonempty_pending = true;
-        {   // tile schedule of the neighbour kernel (sphmi_rebuild.h, "Tile schedule")
+        {   // tile schedules of the neighbour kernel (sphmi_rebuild.h, "Tile schedule")
             const int ntile = (N + kWave - 1) / kWave;
             const int sb = (ntile + kScanTile - 1) / kScanTile;
-            hipLaunchKernelGGL(k_tile_cost, dim3((ntile + 255) / 256), dim3(256), 0, stream, key[cur], cstart, N, ntile,
-                               grid.np[0], grid.np[0] * grid.np[1], D, tile_cost);
-            hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_cost, tile_scan, ntile, tile_tsum, misc_d + 2);
-            hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
-            hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
-            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost, tile_scan, ntile, tile_order, part_d);
+            const int nlist = dd_slab ? 2 : 1;
+            if (dd_slab) {
+                const int lo_pad = dd_has_lo ? (int)(dd_col_lo - grid.gmin[dd_axis] + 1) : -1;
+                const int hi_pad = dd_has_hi ? (int)(dd_col_hi - grid.gmin[dd_axis] + 1) : -1;
+                hipLaunchKernelGGL(k_tile_class, dim3((ntile * 64 + 255) / 256), dim3(256), 0, stream, key[cur], type[cur], N, ntile,
+                                   grid.np[0], grid.np[1], dd_axis, lo_pad, hi_pad, tile_cls);
+            }
+            hipLaunchKernelGGL(k_tile_cost, dim3((ntile + 255) / 256), dim3(256), 0, stream, key[cur], cstart,
+                               dd_slab ? tile_cls : (const uint8_t*)nullptr, N, ntile, grid.np[0], grid.np[0] * grid.np[1], D,
+                               tile_cost[0], tile_cost[1]);
+            for (int l = 0; l < nlist; ++l) {
+                hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_cost[l], tile_scan, ntile, tile_tsum, misc_d + 2);
+                hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
+                hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l);
+            }
             HC(hipGetLastError());
-            HC(hipMemcpyAsync(part_h, part_d, 9 * 4, hipMemcpyDeviceToHost, stream));
+            HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
             HC(hipStreamSynchronize(stream));
-            part_max = 0;
-            for (int x = 0; x < 8; ++x) part_max = std::max(part_max, part_h[x + 1] - part_h[x]);
+            for (int l = 0; l < 2; ++l) {
+                part_max[l] = 0;
+                if (l < nlist) for (int x = 0; x < 8; ++x) part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]);
+            }
         }
         have_grid = true;
         n_rebuilds += 1;
@@ -572,7 +597,7 @@ struct Engine final : EngineBase {
     void dd_cell_x(int32_t* out_host) override {
         HC(hipSetDevice(cfg.device));
         if (!cellx_d) HC(hipMalloc(&cellx_d, (size_t)cap * 4));
-        hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, cellx_d);
+        hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, dd_axis, cellx_d);
         HC(hipGetLastError());
         HC(hipMemcpyAsync(out_host, cellx_d, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
@@ -640,16 +665,26 @@ struct Engine final : EngineBase {
         out8[0] = decode(red_h[0]); out8[1] = decode(red_h[1]); out8[2] = decode(red_h[2]); out8[3] = red_h[3] ? 1.0 : 0.0;
         for (int k = 4; k < 8; ++k) out8[k] = 0.0;
     }
-    void dd_pass(int which, double dt) override {
+    void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) override {
+        if (axis < 0 || axis >= D) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_set_slab: axis out of range");
+        dd_slab = true; dd_axis = axis; dd_col_lo = lo; dd_col_hi = hi; dd_has_lo = has_lo != 0; dd_has_hi = has_hi != 0;
+    }
+    // part: 0 = the whole pass, 1 = interior tiles only, 2 = slab-edge tiles only (after the halo has landed)
+    void dd_pass(int which, double dt, int part) override {
         HC(hipSetDevice(cfg.device));
-        if (which == 1) {
-            Ev e1 = begin_phase(PH_PASS1);
-            launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));
-            end_phase(e1);
-        } else {
-            Ev e2 = begin_phase(PH_PASS2);
-            launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));
-            end_phase(e2);
+        if (which != 1 && which != 2) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_pass: which must be 1 or 2");
+        const ForceParams<T> P = which == 1 ? force_params(iA, iA, iH, dt) : force_params(iH, iA, iB, dt);
+        if (part == 0 || part == 1) {
+            Ev e = begin_phase(which == 1 ? PH_PASS1 : PH_PASS2);
+            if (which == 1) launch_force<PASS_PREDICTOR>(P, 0); else launch_force<PASS_CORRECTOR>(P, 0);
+            end_phase(e);
+        }
+        if ((part == 0 || part == 2) && part_max[1] > 0) {
+            Ev e = begin_phase(which == 1 ? PH_PASS1_EDGE : PH_PASS2_EDGE);
+            if (which == 1) launch_force<PASS_PREDICTOR>(P, 1); else launch_force<PASS_CORRECTOR>(P, 1);
+            end_phase(e);
+        }
+        if (which == 2 && part != 1) {
             std::swap(iA, iB);
             stepped = true;
             iteration += 1; last_dt = dt; total_time += dt;
@@ -784,7 +819,11 @@ int sphmi_dd_rebuild(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_rebuild()); }
 int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_pack(set, idx_dev, n, buf_dev)); }
 int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_unpack(set, idx_dev, n, buf_dev)); }
 int sphmi_dd_reductions(sphmi_handle* h, double* out8) { SPHMI_GUARD(h, h->e->dd_reductions(out8)); }
-int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt)); }
+int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, 0)); }
+int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, part)); }
+int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi, int has_lower_neighbour, int has_upper_neighbour) {
+    SPHMI_GUARD(h, h->e->dd_set_slab(axis, col_lo, col_hi, has_lower_neighbour, has_upper_neighbour));
+}
 int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id, int64_t* n_out) {
     SPHMI_GUARD(h, h->e->dd_download_owned(position, velocity, density, id, n_out));
 }

@@ -72,7 +72,7 @@ struct ForceParams {
     const uint8_t* type;
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
-    const int* part;     // 9 run boundaries
+    const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     int N, nxp, nxyp;
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
@@ -198,14 +198,18 @@ k_neighbor_force(const ForceParams<T> P) {
     int b;
     {
         const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
-        const int pb = P.part[x], pe = P.part[x + 1];
-        if (r >= pe - pb) return;
-        b = P.order[pb + r];
+        if (r >= P.part[8 + x]) return;
+        b = P.order[P.part[x] + r];
     }
     const int t0 = b * kWave;
     const int a = t0 + lane;
     const bool valid = a < P.N;
     const int ac = valid ? a : P.N - 1;
+    // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
+    // state arrives by halo exchange, so they get no accept masks, and nothing is stored or reduced for them
+    const uint8_t ty_raw = P.type[ac];
+    const bool owned = valid && !(ty_raw & 0xC0);
+    if (__builtin_amdgcn_ballot_w64(owned) == 0) return;          // a tile of ghosts only
 
     // target data
     const V4 q0 = P.src0[ac];
@@ -243,7 +247,7 @@ k_neighbor_force(const ForceParams<T> P) {
     {
         const T Rm = fast_sqrt(wave_max(valid ? tt : T(0))) + T(3) * P.h * T(2);
         const T eps = T(1e-5) + T(1e-6) * (Rm * Rm) / P.H2;
-        thr = valid ? P.H2 * (T(1) + eps) - tt : T(-1e30);
+        thr = owned ? P.H2 * (T(1) + eps) - tt : T(-1e30);
     }
     const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
 
@@ -454,10 +458,6 @@ k_neighbor_force(const ForceParams<T> P) {
     }
 #endif
     // ---- epilogue ---------------------------------------------------------------------------
-    // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
-    // state arrives by halo exchange, so nothing is stored or reduced for them
-    const uint8_t ty_raw = P.type[ac];
-    const bool owned = valid && !(ty_raw & 0xC0);
     const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
     const T ml = fluid_a ? T(1) : T(0);

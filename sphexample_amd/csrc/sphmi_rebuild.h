@@ -169,8 +169,29 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(int* out, int n, cons
 //   * inside a run the expensive tiles start first and the cheap wall tiles fill the tail.
 // cost(tile) = candidates its phase 1 scans = Σ over cell rows of the union range length.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cstart, int N, int ntile, int nxp,
-                                                   int nxyp, int D, int* cost) {
+// Tile list a tile belongs to (domain decomposition; without a slab every tile is list 0):
+//   0 interior — needs owned data only, can run while the halo is still in flight
+//   1 edge     — holds an owned particle of a slab-edge cell column (its neighbourhood reaches the ghost layer)
+//   2 none     — ghost copies only: nothing to compute
+__global__ void __launch_bounds__(256) k_tile_class(const int* key, const uint8_t* type, int N, int ntile, int nxp,
+                                                    int nyp, int axis, int col_lo_pad, int col_hi_pad, uint8_t* cls) {
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (t >= ntile) return;
+    const int i = t * 64 + lane;
+    bool owned = false, edge = false;
+    if (i < N) {
+        const int k = key[i];
+        owned = (type[i] & kGhostMask) == 0;
+        const int col = axis == 0 ? k % nxp : (axis == 1 ? (k / nxp) % nyp : k / (nxp * nyp));
+        edge = owned && (col == col_lo_pad || col == col_hi_pad);
+    }
+    const unsigned long long bo = __ballot(owned), be = __ballot(edge);
+    if (lane == 0) cls[t] = bo == 0 ? 2 : (be != 0 ? 1 : 0);
+}
+
+// cost of a tile in its own list, 0 in the other
+__global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cstart, const uint8_t* cls, int N, int ntile,
+                                                   int nxp, int nxyp, int D, int* cost0, int* cost1) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntile) return;
     const int kf = key[t * 64], kl = key[min(t * 64 + 63, N - 1)];
@@ -180,7 +201,9 @@ __global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cs
         const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
         c += cstart[kl + off + 2] - cstart[kf + off - 1];
     }
-    cost[t] = c;
+    const int k = cls ? cls[t] : 0;
+    cost0[t] = k == 0 ? c : 0;
+    cost1[t] = k == 1 ? c : 0;
 }
 
 #ifndef SPHMI_TILE_CLASSES
@@ -191,6 +214,7 @@ constexpr int kTileClasses = SPHMI_TILE_CLASSES;
 // expensive class first.  Inside a class the tiles keep their sorted order, so the ~1000 tiles an XCD has
 // in flight at any time are still neighbours in space and share their source rows in its L2 (a full sort
 // by cost tripled the HBM fetch of the neighbour kernel).
+// cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
                                                      int* part) {
     __shared__ int s_min, s_max, s_wsum[16], s_off;
@@ -206,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; s_off = beg; }
     __syncthreads();
     int mn = INT32_MAX, mx = INT32_MIN;
-    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; mn = min(mn, c); mx = max(mx, c); }
+    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; if (c > 0) { mn = min(mn, c); mx = max(mx, c); } }
     if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
     const int cmin = s_min;
@@ -217,7 +241,8 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     for (int cls = 0; cls < kTileClasses; ++cls) {
         for (int t0 = beg; t0 < end; t0 += 1024) {
             const int t = t0 + (int)threadIdx.x;
-            const bool in = t < end && cls_of(cost[t]) == cls;
+            const int c = t < end ? cost[t] : 0;
+            const bool in = c > 0 && cls_of(c) == cls;                     // cost 0: the tile is not in this list
             const unsigned long long bal = __ballot(in);
             const int below = __popcll(bal & ((1ull << lane) - 1ull));
             if (lane == 0) s_wsum[w] = __popcll(bal);
@@ -231,7 +256,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
             __syncthreads();
         }
     }
-    if (threadIdx.x == 0) { part[x] = beg; if (x == 7) part[8] = ntile; }
+    if (threadIdx.x == 0) { part[x] = beg; part[8 + x] = s_off - beg; }      // run start in order[], tiles in the run
 }
 
 __global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const int* slot, const int* cstart,
@@ -470,11 +495,14 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
 }
 
 // ---- domain decomposition (one process per GPU, x-slabs; sphexample_amd/distributed.py) -----------
-// global cell x-index of every particle, current order
+// global cell index along the slab axis of every particle, current order
 template <class T>
-__global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* pk0, int N, T inv_cutoff, int* out) {
+__global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* pk0, int N, T inv_cutoff, int axis, int* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) out[i] = map_floor<T>(pk0[i].x, inv_cutoff);
+    if (i < N) {
+        const typename Vec4<T>::type q = pk0[i];
+        out[i] = map_floor<T>(axis == 0 ? q.x : (axis == 1 ? q.y : q.z), inv_cutoff);
+    }
 }
 
 // Migration record buffer for n particles: [n×V4 pk0][n×V4 pk1][n×V4 acc][n×i64 id][n×u64 group][n×u8 type]

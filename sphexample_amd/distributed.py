@@ -1,8 +1,11 @@
 """Domain decomposition of the SPH hot path over the GPUs of one node.
 
 The reference has no multi-process path at all; this module is new work for the MI355X
-engine.  One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI), 1-D slabs along
-x cut on cell-column boundaries so that every rank starts with the same number of particles.
+engine.  One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI), 1-D slabs cut on
+cell-column boundaries so that every rank starts with (nearly) the same number of particles.  The slab
+axis is the one whose columns split most evenly (``choose_axis``): a slab cut is one cell column coarse, so
+the axis with many, evenly filled columns wins (y for the 3-D dam break: the water column occupies a short
+stretch of x but the full width in y).
 
 Why this shape
 --------------
@@ -16,17 +19,20 @@ bit-identical on all ranks.
 
 Per step (mirrors ``Engine::step_once`` in csrc/sphmi_engine.hip):
     reductions → allreduce(MAX) → Δx, dt → [rebuild: migrate, re-ghost, sort] →
-    halo(state A) → predictor pass → halo(half-step state H) → corrector pass
+    halo(state A) ‖ predictor on interior tiles → predictor on slab-edge tiles →
+    halo(half-step state H) ‖ corrector on interior tiles → corrector on slab-edge tiles
 Ghost copies are ordinary entries of the rank's sorted particle array (type bits 0x80 / 0x40); the
-kernels use them as neighbours and never write or reduce them.
+kernels use them as neighbours and never compute, write or reduce them.  A tile (64 consecutive sorted
+particles) is "slab-edge" when it holds an owned particle of the first / last cell column of the slab —
+only those can see a ghost — so everything else runs while the two point-to-point messages are in flight.
 
 Rebuild (collective): kill ghosts → send the particles whose cell column left the slab to the adjacent
 rank → sort → send copies of the slab's first / last column as the neighbours' ghosts → sort again →
 rebuild the halo index lists.  Both sorts are stable, so the k-th boundary particle of the sender is the
 k-th ghost slot of the receiver and the per-step halo needs no indices on the wire.
 
-Known limits: static cuts (no re-balancing while the fluid moves), migration to adjacent ranks
-only, no mDBC, per-step control on the host.
+Known limits: static cuts and axis (no re-balancing while the fluid moves), migration to
+adjacent ranks only, no mDBC, per-step control on the host.
 """
 from __future__ import annotations
 
@@ -42,13 +48,30 @@ GHOST_LEFT, GHOST_RIGHT, GHOST_MASK = 0x80, 0x40, 0xC0
 
 
 def cell_x_of(x: np.ndarray, H_inv: float) -> np.ndarray:
-    """map_floor of src/SPHCellList.jl:56-61 on the x coordinate (round half away from zero)."""
+    """map_floor of src/SPHCellList.jl:56-61 on one coordinate (round half away from zero)."""
     return (np.sign(x) * np.trunc(np.abs(x) * H_inv + 0.5)).astype(np.int64)
+
+
+def choose_axis(cols: List[np.ndarray], world: int) -> int:
+    """Slab axis: the one whose equal-count column cuts leave the lightest heaviest rank.  Ties go to the
+    slowest sort axis (its ghost layers are contiguous runs of the cell-sorted arrays)."""
+    best, best_load = 0, None
+    for ax, cx in enumerate(cols):
+        try:
+            plan = SlabPlan.from_columns(cx, world)
+        except ValueError:
+            continue
+        load = np.bincount(plan.owner_of(cx), minlength=world).max()
+        if best_load is None or load <= best_load:
+            best, best_load = ax, load
+    if best_load is None:
+        raise ValueError("no axis has two cell columns per rank: too many ranks for this domain")
+    return best
 
 
 @dataclass
 class SlabPlan:
-    """Static x-slab cuts: rank r owns the cell columns cx_lo[r] … cx_hi[r] (inclusive)."""
+    """Static slab cuts along one axis: rank r owns the cell columns cx_lo[r] … cx_hi[r] (inclusive)."""
     cx_lo: List[int]
     cx_hi: List[int]
 
@@ -118,12 +141,14 @@ class _Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
-    def exchange(self, send_left, send_right, recv_left_bytes: int, recv_right_bytes: int):
-        """send_*: uint8 device tensors (or None); returns the two received uint8 device tensors."""
+    def start_exchange(self, send_left, send_right, recv_left_bytes: int, recv_right_bytes: int):
+        """Post the two point-to-point exchanges; returns a token for ``finish_exchange``.  With RCCL the
+        transfers run on the communicator's stream (ordered after the work already queued on the current
+        stream), so kernels launched between start and finish overlap with them."""
         torch, dist = self.torch, self.dist
         stage = (lambda t: t) if self.on_device else (lambda t: t.cpu())
         dev = self.device if self.on_device else "cpu"
-        ops, recv = [], {}
+        ops, recv, keep = [], {}, []
         for peer, send, nrecv, key in ((self.left, send_left, recv_left_bytes, "L"),
                                        (self.right, send_right, recv_right_bytes, "R")):
             if peer is None:
@@ -132,15 +157,24 @@ class _Comm:
                 recv[key] = torch.empty(nrecv, dtype=torch.uint8, device=dev)
                 ops.append(dist.P2POp(dist.irecv, recv[key], peer))
             if send is not None and send.numel() > 0:
-                ops.append(dist.P2POp(dist.isend, stage(send).contiguous(), peer))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+                keep.append(stage(send).contiguous())
+                ops.append(dist.P2POp(dist.isend, keep[-1], peer))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, recv, keep
+
+    def finish_exchange(self, token):
+        works, recv, _keep = token
+        for w in works:
+            w.wait()            # RCCL: the current stream waits for the transfer; gloo: the host does
         out = []
         for key in ("L", "R"):
             t = recv.get(key)
             out.append(None if t is None else t.to(self.device))
         return out[0], out[1]
+
+    def exchange(self, send_left, send_right, recv_left_bytes: int, recv_right_bytes: int):
+        """send_*: uint8 device tensors (or None); returns the two received uint8 device tensors."""
+        return self.finish_exchange(self.start_exchange(send_left, send_right, recv_left_bytes, recv_right_bytes))
 
     def exchange_counts(self, n_left: int, n_right: int) -> Tuple[int, int]:
         torch = self.torch
@@ -156,7 +190,8 @@ class DistributedEngine:
     """Same ``advance`` / ``force_kernel_stats`` surface as ``engine.Engine``, on a slab of the domain."""
 
     def __init__(self, particles, setup, rank: int, world: int, local_device: int = 0,
-                 device_float_bytes: int = 4, capacity_factor: float = 1.6):
+                 device_float_bytes: int = 4, capacity_factor: float = 1.6, axis: Optional[int] = None,
+                 overlap: bool = True):
         import torch
         from .engine import Engine, load_library
         self.torch = torch
@@ -165,8 +200,11 @@ class DistributedEngine:
         torch.cuda.set_device(self.device)
         H_inv = setup.SimKernel.H_inv
         # initial ownership from the positions as the device will see them
-        xdev = particles.Position[:, 0].astype(np.float32 if device_float_bytes == 4 else np.float64)
-        cx = cell_x_of(xdev.astype(np.float64), H_inv)
+        ft = np.float32 if device_float_bytes == 4 else np.float64
+        D = particles.Position.shape[1]
+        cols = [cell_x_of(particles.Position[:, a].astype(ft).astype(np.float64), H_inv) for a in range(D)]
+        self.axis = choose_axis(cols, world) if axis is None else int(axis)
+        cx = cols[self.axis]
         self.plan = SlabPlan.from_columns(cx, world)
         mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
         self.n_total = len(particles)
@@ -183,6 +221,11 @@ class DistributedEngine:
         self.h = self.eng._h
         self._declare()
         self._call("dd_set_stream", C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        INF = 1 << 30
+        lo, hi = self.plan.cx_lo[rank], self.plan.cx_hi[rank]
+        self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(lo, -INF)), C.c_int64(min(hi, INF)),
+                   C.c_int(rank > 0), C.c_int(rank < world - 1))
+        self.overlap = overlap
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
         keep = [f(particles.Position[mine]), f(particles.Velocity[mine]), f(particles.Acceleration[mine]),
                 f(particles.Density[mine]), np.ascontiguousarray(particles.Type[mine], dtype=np.uint8),
@@ -196,6 +239,7 @@ class DistributedEngine:
         self.total_time, self.iteration, self.last_dt = 0.0, 0, 0.0
         self.n_rebuilds = 0
         self._halo = None
+        self._keep = [None, None]
 
     # -- ctypes plumbing -----------------------------------------------------------------------------
     def _declare(self):
@@ -216,6 +260,8 @@ class DistributedEngine:
         L.sphmi_dd_halo_unpack.argtypes = [vp, C.c_int, i32p, i64, vp]
         L.sphmi_dd_reductions.argtypes = [vp, vp]
         L.sphmi_dd_pass.argtypes = [vp, C.c_int, C.c_double]
+        L.sphmi_dd_pass_part.argtypes = [vp, C.c_int, C.c_double, C.c_int]
+        L.sphmi_dd_set_slab.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.c_int]
         L.sphmi_dd_download_owned.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.sphmi_dd_progress.argtypes = [vp, C.POINTER(SphmiProgress)]
 
@@ -315,22 +361,38 @@ class DistributedEngine:
                           buf_l=mk(len(send_l)), buf_r=mk(len(send_r)))
         self.n_rebuilds += 1
 
-    def _halo_exchange(self, which: int):
-        """Refresh the ghost copies of state set `which` (0 = A, 1 = H) from their owners."""
+    def _halo_start(self, which: int):
+        """Pack the slab-edge columns of state set `which` (0 = A, 1 = H) and post the exchange."""
         hl, p = self._halo, C.c_void_p
         vb = 2 * self.vbytes
         if hl["n_send_l"]:
             self._call("dd_halo_pack", C.c_int(which), p(hl["send_l"].data_ptr()), C.c_int64(hl["n_send_l"]), p(hl["buf_l"].data_ptr()))
         if hl["n_send_r"]:
             self._call("dd_halo_pack", C.c_int(which), p(hl["send_r"].data_ptr()), C.c_int64(hl["n_send_r"]), p(hl["buf_r"].data_ptr()))
-        rl, rr = self.comm.exchange(hl["buf_l"][:hl["n_send_l"] * vb] if hl["n_send_l"] else None,
-                                    hl["buf_r"][:hl["n_send_r"] * vb] if hl["n_send_r"] else None,
-                                    hl["n_slot_l"] * vb, hl["n_slot_r"] * vb)
+        return self.comm.start_exchange(hl["buf_l"][:hl["n_send_l"] * vb] if hl["n_send_l"] else None,
+                                        hl["buf_r"][:hl["n_send_r"] * vb] if hl["n_send_r"] else None,
+                                        hl["n_slot_l"] * vb, hl["n_slot_r"] * vb)
+
+    def _halo_finish(self, which: int, token):
+        """Wait for the exchange and refresh the ghost copies of state set `which`."""
+        hl, p = self._halo, C.c_void_p
+        rl, rr = self.comm.finish_exchange(token)
         if hl["n_slot_l"]:
             self._call("dd_halo_unpack", C.c_int(which), p(hl["slot_l"].data_ptr()), C.c_int64(hl["n_slot_l"]), p(rl.data_ptr()))
         if hl["n_slot_r"]:
             self._call("dd_halo_unpack", C.c_int(which), p(hl["slot_r"].data_ptr()), C.c_int64(hl["n_slot_r"]), p(rr.data_ptr()))
-        self._keep = (rl, rr)        # keep the receive buffers alive until the next exchange
+        self._keep[which] = (rl, rr, token)   # receive / send buffers stay alive until this set is exchanged again
+
+    def _pass(self, which: int, dt: float):
+        """One neighbour pass with its halo: interior tiles run while the messages are in flight."""
+        token = self._halo_start(which - 1)
+        if self.overlap:
+            self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(1))
+            self._halo_finish(which - 1, token)
+            self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(2))
+        else:
+            self._halo_finish(which - 1, token)
+            self._call("dd_pass", C.c_int(which), C.c_double(dt))
 
     # -- the SimulationLoop of src/SPHCellList.jl:727-805, distributed --------------------------------
     def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
@@ -349,10 +411,8 @@ class DistributedEngine:
             if rebuild:
                 self._rebuild()
                 self.delta_x = 0.0
-            self._halo_exchange(0)
-            self._call("dd_pass", C.c_int(1), C.c_double(dt))
-            self._halo_exchange(1)
-            self._call("dd_pass", C.c_int(2), C.c_double(dt))
+            self._pass(1, dt)
+            self._pass(2, dt)
             self.iteration += 1
             self.last_dt = dt
             self.total_time += dt

@@ -45,17 +45,17 @@ def comm_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def engine_worker(rank, world, port, out_dir, case, steps, fb):
+def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overlap=True):
     """2 ranks sharing GPU 0 (gloo staging): slab engines vs nothing — rank 0 stores the gathered result."""
     dist = _init(rank, world, port)
     import conftest
     from sphexample_amd.distributed import DistributedEngine
     p, s = getattr(conftest, "load_" + case)()
-    eng = DistributedEngine(p, s, rank, world, local_device=0, device_float_bytes=fb)
+    eng = DistributedEngine(p, s, rank, world, local_device=0, device_float_bytes=fb, axis=axis, overlap=overlap)
     pr = eng.advance(1e9, max_steps=steps)
     res = eng.gather_all()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dd.npz"), iteration=pr.iteration, total_time=pr.total_time,
-                 n_rebuilds=pr.n_rebuilds, **res)
+                 n_rebuilds=pr.n_rebuilds, axis=eng.axis, **res)
     dist.barrier()
     dist.destroy_process_group()

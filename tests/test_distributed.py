@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from sphexample_amd._abi import make_config
-from sphexample_amd.distributed import SlabPlan, cell_x_of, step_control
+from sphexample_amd.distributed import SlabPlan, cell_x_of, choose_axis, step_control
 
 
 def _free_port():
@@ -38,6 +38,21 @@ def test_slab_plan_balances_particles(dam_break_3d_shipped):
             sel = owner == r
             assert cx[sel].min() >= plan.cx_lo[r] and cx[sel].max() <= plan.cx_hi[r]
         assert all(plan.cx_hi[r] + 1 == plan.cx_lo[r + 1] for r in range(world - 1))
+
+
+def test_choose_axis_prefers_the_evenly_filled_direction(dam_break_3d_shipped):
+    """The 3-D dam break fills the whole width (y) of the tank but a short stretch of its length (x): slabs along
+    y balance better than slabs along x; z (few layers) cannot host 8 ranks at this resolution."""
+    p, s = dam_break_3d_shipped
+    cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(3)]
+    loads = {}
+    for ax in range(3):
+        plan = SlabPlan.from_columns(cols[ax], 2)
+        loads[ax] = np.bincount(plan.owner_of(cols[ax]), minlength=2).max()
+    ax = choose_axis(cols, 2)
+    assert loads[ax] == min(loads.values())
+    with pytest.raises(ValueError):
+        choose_axis([np.zeros(10, dtype=np.int64)], 2)          # one column cannot be split
 
 
 def test_step_control_matches_oracle_dt(dam_break_2d):
@@ -72,9 +87,12 @@ def test_comm_over_gloo_world3():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,steps,fb,tol", [("dam_break_3d_shipped", 30, 8, 1e-9), ("dam_break_3d_shipped", 30, 4, 1e-5),
-                                               ("dam_break_2d", 60, 8, 1e-9)])
-def test_two_slabs_match_single_gpu(case, steps, fb, tol, request):
+@pytest.mark.parametrize("case,steps,fb,tol,axis,overlap", [
+    ("dam_break_3d_shipped", 30, 8, 1e-9, None, True), ("dam_break_3d_shipped", 30, 4, 1e-5, None, True),
+    ("dam_break_3d_shipped", 30, 8, 1e-9, 0, True), ("dam_break_3d_shipped", 30, 8, 1e-9, 1, False),
+    ("dam_break_3d_shipped", 30, 8, 1e-9, 2, True),
+    ("dam_break_2d", 60, 8, 1e-9, None, True), ("dam_break_2d", 60, 8, 1e-9, 0, False), ("dam_break_2d", 60, 8, 1e-9, 1, True)])
+def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
     import torch.multiprocessing as mp
@@ -85,8 +103,9 @@ def test_two_slabs_match_single_gpu(case, steps, fb, tol, request):
     pr = ref.advance(1e9, max_steps=steps)
     r = ref.download(("Position", "Density", "ID", "Velocity"))
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(engine_worker, args=(2, _free_port(), d, case, steps, fb), nprocs=2, join=True)
+        mp.spawn(engine_worker, args=(2, _free_port(), d, case, steps, fb, axis, overlap), nprocs=2, join=True)
         dd = dict(np.load(os.path.join(d, "dd.npz")))
+    assert axis is None or int(dd["axis"]) == axis
     assert int(dd["iteration"]) == pr.iteration == steps
     assert int(dd["n_rebuilds"]) == pr.n_rebuilds
     assert float(dd["total_time"]) == pytest.approx(pr.total_time, rel=1e-12 if fb == 8 else 1e-6)
