@@ -198,6 +198,10 @@ int sphmi_dd_rebuild(sphmi_handle* h);                               /* UpdateNe
 int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev);
 int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev);
 int sphmi_dd_reductions(sphmi_handle* h, double* out8);  /* [0] max|x⁺−x|², [1] visc, [2] max|a|², [3] bad ρ */
+/* Same four slots as raw bit patterns (float32 bits in the low word for 4-byte handles, float64 bits otherwise)
+ * into a DEVICE buffer of 4 × int64: non-negative values order like integers, so an integer MAX-allreduce of
+ * this buffer is the global maximum (NaN sorts on top).  Resets the slots. */
+int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev);
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt);            /* 1: predictor pass, 2: corrector   */
 /* part 0 = whole pass (same as sphmi_dd_pass), 1 = interior tiles, 2 = slab-edge tiles (completes the pass) */
 int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part);

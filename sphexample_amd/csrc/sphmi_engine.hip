@@ -72,6 +72,7 @@ struct EngineBase {
     virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
     virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) = 0;
     virtual void dd_reductions(double* out8) = 0;
+    virtual void dd_reductions_dev(void* out4_dev) = 0;
     virtual void dd_pass(int which, double dt, int part) = 0;
     virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) = 0;
     virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) = 0;
@@ -665,6 +666,13 @@ struct Engine final : EngineBase {
         out8[0] = decode(red_h[0]); out8[1] = decode(red_h[1]); out8[2] = decode(red_h[2]); out8[3] = red_h[3] ? 1.0 : 0.0;
         for (int k = 4; k < 8; ++k) out8[k] = 0.0;
     }
+    // the four reduction slots as raw bit patterns (non-negative floats: integer MAX = float MAX, NaN on top)
+    // into a caller-owned device buffer of 4 × int64, then reset — no host round trip before the allreduce
+    void dd_reductions_dev(void* out4_dev) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipMemcpyAsync(out4_dev, red_d, 4 * 8, hipMemcpyDeviceToDevice, stream));
+        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+    }
     void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) override {
         if (axis < 0 || axis >= D) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_set_slab: axis out of range");
         dd_slab = true; dd_axis = axis; dd_col_lo = lo; dd_col_hi = hi; dd_has_lo = has_lo != 0; dd_has_hi = has_hi != 0;
@@ -818,6 +826,7 @@ int sphmi_dd_append(sphmi_handle* h, const void* buf_dev, int64_t n, int flag) {
 int sphmi_dd_rebuild(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_rebuild()); }
 int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_pack(set, idx_dev, n, buf_dev)); }
 int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_unpack(set, idx_dev, n, buf_dev)); }
+int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev) { SPHMI_GUARD(h, h->e->dd_reductions_dev(out4_dev)); }
 int sphmi_dd_reductions(sphmi_handle* h, double* out8) { SPHMI_GUARD(h, h->e->dd_reductions(out8)); }
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, 0)); }
 int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, part)); }

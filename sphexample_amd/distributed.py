@@ -141,6 +141,17 @@ class _Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
+    def allreduce_max_bits(self, t):
+        """In-place integer MAX over the ranks of a device int64 tensor (the engine's reduction bit patterns)."""
+        if self.world > 1:
+            if self.on_device:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            else:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
+                t.copy_(h)
+        return t
+
     def start_exchange(self, send_left, send_right, recv_left_bytes: int, recv_right_bytes: int):
         """Post the two point-to-point exchanges; returns a token for ``finish_exchange``.  With RCCL the
         transfers run on the communicator's stream (ordered after the work already queued on the current
@@ -259,6 +270,7 @@ class DistributedEngine:
         L.sphmi_dd_halo_pack.argtypes = [vp, C.c_int, i32p, i64, vp]
         L.sphmi_dd_halo_unpack.argtypes = [vp, C.c_int, i32p, i64, vp]
         L.sphmi_dd_reductions.argtypes = [vp, vp]
+        L.sphmi_dd_reductions_dev.argtypes = [vp, vp]
         L.sphmi_dd_pass.argtypes = [vp, C.c_int, C.c_double]
         L.sphmi_dd_pass_part.argtypes = [vp, C.c_int, C.c_double, C.c_int]
         L.sphmi_dd_set_slab.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.c_int]
@@ -399,10 +411,13 @@ class DistributedEngine:
         cfg = self.cfg
         self.delta_x = 1.0 + cfg.h                                   # :739
         steps = 0
-        red = np.zeros(8)
+        red_t = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
         while self.total_time <= t_target and (max_steps < 0 or steps < max_steps):
-            self._call("dd_reductions", red.ctypes.data_as(C.c_void_p))
-            g = self.comm.allreduce_max(red[:4])
+            # local maxima → global maxima without leaving the device; ONE host sync per step (the .cpu())
+            self._call("dd_reductions_dev", C.c_void_p(red_t.data_ptr()))
+            bits = self.comm.allreduce_max_bits(red_t).cpu().numpy()
+            g = (bits.astype(np.uint32).view(np.float32) if cfg.device_float_bytes == 4 else bits.view(np.float64)).astype(np.float64)
+            g[3] = float(bits[3] != 0)
             if g[3] > 0:
                 raise RuntimeError("non-positive density produced on some rank")
             self.delta_x, dt, rebuild = step_control(g, self.delta_x, cfg)
