@@ -101,6 +101,7 @@ struct Engine final : EngineBase {
     int *tile_cost[2] = {nullptr, nullptr}, *tile_order[2] = {nullptr, nullptr}, *tile_scan = nullptr, *tile_tsum = nullptr;
     int *part_d = nullptr, *part_h = nullptr;       // 2 × 16 ints: run starts and run lengths per XCD
     uint8_t* tile_cls = nullptr;
+    unsigned long long* trace_d = nullptr;
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
@@ -143,6 +144,9 @@ struct Engine final : EngineBase {
         const size_t nt = n / kWave + 2;
         for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], nt * 4)); }
         HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt));
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+        HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
+#endif
         HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
@@ -161,6 +165,17 @@ struct Engine final : EngineBase {
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+        if (trace_d) {   // experiment build: start / end clock of every tile of the LAST launch → $SPHMI_TRACE_FILE
+            const char* fn = getenv("SPHMI_TRACE_FILE");
+            std::vector<unsigned long long> tr((size_t)(cap / kWave + 2) * 2);
+            if (fn && hipMemcpy(tr.data(), trace_d, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                FILE* f = fopen(fn, "wb");
+                if (f) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
+            }
+            (void)hipFree(trace_d);
+        }
+#endif
 #ifdef SPHMI_STATS
         {   // experiment build: loop statistics of the neighbour kernel, summed over every launch
             unsigned long long st[16];
@@ -231,7 +246,7 @@ struct Engine final : EngineBase {
 
     template <int PASS, int MODEL> void launch_force_model(ForceParams<T> P, int list) {
         if (part_max[list] == 0) return;
-        P.order = tile_order[list]; P.part = part_d + 16 * list;
+        P.order = tile_order[list]; P.part = part_d + 16 * list; P.trace = trace_d;
         dim3 g(8 * part_max[list]), b(kWave);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL>), g, b, 0, stream, P);
         else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL>), g, b, 0, stream, P);

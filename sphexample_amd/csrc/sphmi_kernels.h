@@ -73,6 +73,7 @@ struct ForceParams {
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
+    unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
     int N, nxp, nxyp;
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
@@ -306,6 +307,9 @@ k_neighbor_force(const ForceParams<T> P) {
     // row is only recycled once EVERY lane is through with it.
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef SPHMI_STATS
     unsigned long long st_it = 0, st_lane = 0, st_ref = 0, st_emp = 0, st_chunks = 0;
 #endif
@@ -451,6 +455,12 @@ k_neighbor_force(const ForceParams<T> P) {
     }
     run_pairs(0, true);
 
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+    if (lane == 0 && P.trace) {
+        P.trace[2 * b] = st_t0;
+        P.trace[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #ifdef SPHMI_STATS
     if (lane == 0) {
         atomicAdd(&P.red[8], st_it); atomicAdd(&P.red[9], st_lane); atomicAdd(&P.red[10], st_ref);
