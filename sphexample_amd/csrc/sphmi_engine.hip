@@ -103,6 +103,8 @@ struct Engine final : EngineBase {
     uint8_t* tile_cls = nullptr;
     unsigned long long* trace_d = nullptr;
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
+    int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
+    static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -130,6 +132,7 @@ struct Engine final : EngineBase {
         if (c.device < 0 || c.device >= ndev) throw EngineError(SPHMI_ERR_ARGUMENT, "device ordinal out of range");
         HC(hipSetDevice(c.device));
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) force_wpt = v; }
         const size_t n = (size_t)N;
         for (int k = 0; k < 3; ++k) { HC(hipMalloc(&pk0[k], n * sizeof(V4))); HC(hipMalloc(&pk1[k], n * sizeof(V4))); }
         for (int k = 0; k < 2; ++k) {
@@ -244,13 +247,21 @@ struct Engine final : EngineBase {
         return P;
     }
 
+    template <int PASS, int MODEL, int WPT> void launch_force_wpt(const ForceParams<T>& P, int list) {
+        dim3 g(8 * part_max[list]), b(kWave * WPT);
+        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, WPT>), g, b, 0, stream, P);
+        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL, WPT>), g, b, 0, stream, P);
+        HC(hipGetLastError());
+    }
     template <int PASS, int MODEL> void launch_force_model(ForceParams<T> P, int list) {
         if (part_max[list] == 0) return;
         P.order = tile_order[list]; P.part = part_d + 16 * list; P.trace = trace_d;
-        dim3 g(8 * part_max[list]), b(kWave);
-        if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL>), g, b, 0, stream, P);
-        else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL>), g, b, 0, stream, P);
-        HC(hipGetLastError());
+        // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip
+        const int ntile = (N + kWave - 1) / kWave;
+        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
+        if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
+        else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
+        else launch_force_wpt<PASS, MODEL, 1>(P, list);
     }
     // list: 0 = interior tiles (all tiles when the handle has no slab), 1 = slab-edge tiles
     template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {

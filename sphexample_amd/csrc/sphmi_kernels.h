@@ -178,8 +178,12 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // MODEL: bit 0 = ArtificialViscosity, bit 1 = LinearDensityDiffusion (compile-time: no uniform branches per pair)
-template <class T, int D, int PASS, int MODEL>
-__global__ void __launch_bounds__(kWave)
+// WPT: waves per tile.  The waves of a workgroup share the tile's 64 targets and split its candidate chunks
+// (chunk c of a row goes to wave (c + row) % WPT); wave 0 adds the partial sums in wave order and runs the
+// epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
+// last round of a 1 M-particle launch) shorter-lived waves keep the SIMDs filled.
+template <class T, int D, int PASS, int MODEL, int WPT>
+__global__ void __launch_bounds__(kWave * WPT)
 k_neighbor_force(const ForceParams<T> P) {
     constexpr bool kVisc = (MODEL & 1) != 0, kDdt = (MODEL & 2) != 0;
     using V4 = typename Vec4<T>::type;
@@ -187,12 +191,13 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
     static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
-    __shared__ uint2 s_q_all[QCAP * kWave];                // [entry][lane]
+    __shared__ uint2 s_q_all[WPT * QCAP * kWave];          // [wave][entry][lane]
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
     // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
     // program order is all the synchronisation the queue needs
-    uint2* const s_q = s_q_all + lane;
+    uint2* const s_q = s_q_all + wv * QCAP * kWave + lane;
     // Tile schedule (sphmi_rebuild.h): the dispatcher places block b on XCD b % 8; every XCD works through
     // one contiguous, cost-balanced run of tiles, expensive tiles first.  Measured on the 1 M-particle dam
     // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
@@ -435,7 +440,7 @@ k_neighbor_force(const ForceParams<T> P) {
         const int LO = rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
 #pragma unroll 1
-        for (int cb = LO; cb < HI; cb += kWave) {
+        for (int cb = LO + ((wv + WPT - seg % WPT) % WPT) * kWave; cb < HI; cb += kWave * WPT) {
             // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
             if (__builtin_amdgcn_ballot_w64((wpos - rpos) > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
             unsigned long long m = scan_chunk(cb, HI);
@@ -454,6 +459,18 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     }
     run_pairs(0, true);
+    if constexpr (WPT > 1) {
+        __shared__ V4 s_part[(WPT - 1) * kWave];            // partial sums of waves 1 … WPT−1
+        // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
+        if (wv > 0) { V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_part[(wv - 1) * kWave + lane] = o; }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int k = 0; k < WPT - 1; ++k) {
+            const V4 o = s_part[k * kWave + lane];
+            ax += o.x; ay += o.y; az += o.z; drho += o.w;
+        }
+    }
 
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     if (lane == 0 && P.trace) {
