@@ -149,7 +149,8 @@ def main():
             "config": {"workload": f"3D dam-break dp={dp:.6g}, N={n_total} particles, "
                                    f"example/Dambreak3d.jl parameters, fp32 kernels",
                        "particles": n_total, "particles_per_gpu": n_local,
-                       "parallelism": "single GPU" if world == 1 else f"x-slab domain decomposition x{world}, 1-cell halo",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"{'xyz'[getattr(eng, 'axis', 0)]}-slab domain decomposition x{world}, 1-cell halo, interior tiles overlap the exchange",
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),

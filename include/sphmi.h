@@ -155,7 +155,9 @@ int sphmi_unique_cells(sphmi_handle* h, int64_t* cells_out, int64_t capacity, in
 
 /*
  * Per-phase device seconds accumulated since create, under the reference's TimerOutputs labels
- * (src/SPHCellList.jl:748-800).  names_out receives pointers to static strings.
+ * (src/SPHCellList.jl:748-800).  names_out receives pointers to static strings.  The step phases are timed with
+ * HIP events on every 8th step and scaled by 8 (an event pair per phase and step costs more than a small pass);
+ * rebuilds are always timed.
  */
 int sphmi_timers(sphmi_handle* h, int32_t capacity, const char** names_out, double* seconds_out,
                  int64_t* calls_out, int32_t* n_out);
@@ -165,7 +167,7 @@ int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local)
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------- */
 /* Average duration in ms (HIP events on the engine's stream) of the neighbour+force kernel over the
- * launches since the last reset, and the number of launches. */
+ * launches since the last reset (sampled: the launches of every 8th step), and the number of launches. */
 int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 
 /* ---- domain decomposition: one process per GPU, slabs along one axis with a one-cell halo ---------

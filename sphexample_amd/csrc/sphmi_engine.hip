@@ -115,11 +115,12 @@ struct Engine final : EngineBase {
     GridDesc grid{};
     bool have_grid = false, stepped = false, nonempty_pending = false;
     // timing
-    struct Ev { hipEvent_t a, b; int phase; };
+    struct Ev { hipEvent_t a, b; int phase; int weight; };   // weight 0: not sampled (no events recorded)
     std::vector<Ev> ev_pool, ev_pending;
     double ph_secs[PH_COUNT] = {};
     int64_t ph_calls[PH_COUNT] = {};
     double force_ms = 0; int64_t force_launches = 0;
+    int64_t ev_always_until = 2;       // every step is timed while iteration < this (start-up, and after a stats reset)
 
     explicit Engine(const sphmi_config& c) {
         cfg = c;
@@ -194,15 +195,21 @@ struct Engine final : EngineBase {
     }
 
     // ---- timing helpers ---------------------------------------------------------------------
+    // An event pair costs several µs of stream bubbles (27 µs per step on the 7 k-particle 2-D case whose
+    // passes last 20 µs; 28 µs = 2 % per step at 1 M particles), so the phases are timed on one step in
+    // kEvSample and the sample is weighted accordingly; rebuilds are always timed.
+    static constexpr int kEvSample = 8;
     Ev begin_phase(int phase) {
-        Ev e;
-        if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); }
-        else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
+        Ev e{};
         e.phase = phase;
+        e.weight = (phase == PH_REBUILD || iteration < ev_always_until) ? 1 : ((iteration % kEvSample) == 0 ? kEvSample : 0);
+        if (e.weight == 0) return e;
+        if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; }
+        else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
         HC(hipEventRecord(e.a, stream));
         return e;
     }
-    void end_phase(Ev e) { HC(hipEventRecord(e.b, stream)); ev_pending.push_back(e); }
+    void end_phase(Ev e) { if (e.weight == 0) return; HC(hipEventRecord(e.b, stream)); ev_pending.push_back(e); }
     void collect_events() {   // call only after a stream sync
         for (auto& e : ev_pending) {
             float ms = 0;
@@ -210,9 +217,9 @@ struct Engine final : EngineBase {
                 // the edge-tile launch of a split pass is part of that pass: its time is added, it is not a call
                 const bool edge = e.phase == PH_PASS1_EDGE || e.phase == PH_PASS2_EDGE;
                 const int ph = e.phase == PH_PASS1_EDGE ? PH_PASS1 : (e.phase == PH_PASS2_EDGE ? PH_PASS2 : e.phase);
-                ph_secs[ph] += ms * 1e-3;
-                ph_calls[ph] += edge ? 0 : 1;
-                if (ph == PH_PASS1 || ph == PH_PASS2) { force_ms += ms; force_launches += edge ? 0 : 1; }
+                ph_secs[ph] += ms * 1e-3 * e.weight;
+                ph_calls[ph] += edge ? 0 : e.weight;
+                if (ph == PH_PASS1 || ph == PH_PASS2) { force_ms += ms * e.weight; force_launches += edge ? 0 : e.weight; }
             }
             ev_pool.push_back(e);
         }
@@ -758,7 +765,7 @@ struct Engine final : EngineBase {
     void force_stats(int reset, double* avg_ms, int64_t* launches) override {
         if (avg_ms) *avg_ms = force_launches ? force_ms / (double)force_launches : 0.0;
         if (launches) *launches = force_launches;
-        if (reset) { force_ms = 0; force_launches = 0; }
+        if (reset) { force_ms = 0; force_launches = 0; ev_always_until = iteration + 2; }   // short windows still get samples
     }
     void device_ptrs(void** p0, void** p1, int64_t* n) override {
         if (p0) *p0 = pk0[iA];
