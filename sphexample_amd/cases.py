@@ -130,6 +130,33 @@ def setup_dam_break_2d() -> CaseSetup:
     return CaseSetup("dam_break_2d", consts, kern, meta, ArtificialViscosity(), LinearDensityDiffusion())
 
 
+def setup_dam_break_2d_mdbc() -> CaseSetup:
+    """example/Dambreak2dMDBC.jl:7,30-36,74-81 (the script pairs dx = 0.01 with the Dp0.02 layouts; kept as is)."""
+    consts = SimulationConstants(dx=0.01, c0=88.14487860902641, delta_phi=0.1, CFL=0.5, alpha=0.01)
+    kern = SPHKernelInstance(2, WendlandC2(), dx=0.01)
+    meta = SimulationMetaData(Dimensions=2, BMode=SimpleMDBC, SimulationName="DamBreak2D",
+                              SimulationTime=2.0, OutputTimes=[0.01 * k for k in range(1, 201)])
+    return CaseSetup("dam_break_2d_mdbc", consts, kern, meta, ArtificialViscosity(), LinearDensityDiffusion())
+
+
+def setup_still_wedge_middle_square_mdbc() -> CaseSetup:
+    """example/StillWedgeMiddleSquareMDBC.jl:7,30-38,50,59-61."""
+    consts = SimulationConstants(dx=0.02, c0=42.48576250492629, delta_phi=0.1, CFL=0.5)
+    kern = SPHKernelInstance(2, WendlandC2(), dx=0.02)
+    meta = SimulationMetaData(Dimensions=2, BMode=SimpleMDBC, SimulationName="StillWedgeMiddleSquare",
+                              SimulationTime=4.0, OutputTimes=0.01)
+    return CaseSetup("still_wedge_middle_square_mdbc", consts, kern, meta, ArtificialViscosity(), LinearDensityDiffusion())
+
+
+def setup_duckling_mdbc() -> CaseSetup:
+    """example/DucklingMDBC.jl:7,29-42: the reference's only 3-D mDBC case (4×4 moment matrices)."""
+    consts = SimulationConstants(dx=0.01, c0=23.43842998154953, delta_phi=0.1, CFL=0.2, alpha=0.02, m0=0.001)
+    kern = SPHKernelInstance(3, WendlandC2(), dx=0.01, k=1.5)
+    meta = SimulationMetaData(Dimensions=3, BMode=SimpleMDBC, SimulationName="CaseDuckling",
+                              SimulationTime=1.0, OutputTimes=0.02)
+    return CaseSetup("duckling_mdbc", consts, kern, meta, ArtificialViscosity(), LinearDensityDiffusion())
+
+
 def setup_still_wedge_mdbc() -> CaseSetup:
     """example/StillWedgeMDBC.jl:7,30-38,60,69-71."""
     consts = SimulationConstants(dx=0.02, c0=42.48576250492629, delta_phi=0.1, CFL=0.5)

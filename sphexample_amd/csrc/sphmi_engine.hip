@@ -381,8 +381,8 @@ struct Engine final : EngineBase {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
         M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
-        M.H_inv = (T)cfg.H_inv; M.H2 = (T)cfg.H2; M.h_inv = (T)cfg.h_inv; M.h = (T)cfg.h;
-        M.alphaD = (T)cfg.alphaD; M.m0 = (T)cfg.m0; M.rho0 = (T)cfg.rho0;
+        M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
+        M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0;
         dim3 g((N + 63) / 64), b(64);
         if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
         else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);

@@ -348,25 +348,31 @@ template <class T> struct MdbcParams {
     GridDesc g;
     unsigned long long* red;   // red[3]: non-positive density flag
     int N;
-    T H_inv, H2, h_inv, h, alphaD, m0, rho0;
+    T H_inv;               // the cell hash stays in the handle's precision (same cells as the particles)
+    double H2, h_inv, h, alphaD, m0, rho0;
 };
 
 template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22) {
     return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
 }
 
+// All arithmetic of the moment matrix and its solve is fp64 in BOTH builds: the (D+1)×(D+1) systems of thin
+// boundary layers are ill-conditioned, and fp32 accumulation flipped the |det| ≥ 1e-3 branch for a handful
+// of particles of example/Dambreak2dMDBC.jl (density off by 3e-3); the kernel is a negligible part of a step.
 template <class T, int D>
 __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
     constexpr int P = D + 1;
+    using R = double;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.N) return;
     const auto gq = M.ghost[i];
     if (gq.w == T(0)) return;
-    const T g[3] = {gq.x, gq.y, gq.z};
+    const T gT[3] = {gq.x, gq.y, gq.z};
+    const R g[3] = {(R)gq.x, (R)gq.y, (R)gq.z};
     int gc[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) gc[d] = d < D ? map_floor<T>(g[d], M.H_inv) - M.g.gmin[d] + 1 : 0;
-    T b[P], A[P][P];   // A[r][c]
+    for (int d = 0; d < 3; ++d) gc[d] = d < D ? map_floor<T>(gT[d], M.H_inv) - M.g.gmin[d] + 1 : 0;
+    R b[P], A[P][P];   // A[r][c]
 #pragma unroll
     for (int r = 0; r < P; ++r) { b[r] = 0;
 #pragma unroll
@@ -386,23 +392,23 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
             for (int j = s; j < e; ++j) {
                 const auto n0 = M.pk0[j];
                 if (!(n0.w > T(0))) continue;                 // ParticleType[j] == Fluid
-                const T xij[3] = {g[0] - n0.x, g[1] - n0.y, D == 3 ? g[2] - n0.z : T(0)};
-                const T r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
+                const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
+                const R r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
                 if (!(r2 <= M.H2)) continue;
-                T q = fast_sqrt(r2) * M.h_inv;
-                q = q > T(2) ? T(2) : q;
-                const T t1 = T(1) - q / T(2);
-                const T t2 = t1 * t1;
-                const T Wij = M.alphaD * (t2 * t2) * (T(2) * q + T(1));      // src/SPHKernels.jl:75-78
-                const T tq = q - T(2);
-                const T fac = M.alphaD * T(5) * (tq * tq * tq) / (T(8) * M.h * M.h);
-                const T Vj = M.m0 / n0.w;
-                T fc[P];
+                R q = sqrt(r2) * M.h_inv;
+                q = q > R(2) ? R(2) : q;
+                const R t1 = R(1) - q / R(2);
+                const R t2 = t1 * t1;
+                const R Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));      // src/SPHKernels.jl:75-78
+                const R tq = q - R(2);
+                const R fac = M.alphaD * R(5) * (tq * tq * tq) / (R(8) * M.h * M.h);
+                const R Vj = M.m0 / (R)n0.w;
+                R fc[P];
                 fc[0] = Vj * Wij;
                 b[0] += M.m0 * Wij;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    const T gw = fac * xij[d];
+                    const R gw = fac * xij[d];
                     fc[d + 1] = Vj * gw;
                     b[d + 1] += M.m0 * gw;
                 }
@@ -415,14 +421,14 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
             }
         }
     // ApplyMDBCCorrection, src/SPHCellList.jl:598-622
-    T det;
+    R det;
     if constexpr (P == 3) {
-        det = det3<T>(A[0][0], A[0][1], A[0][2], A[1][0], A[1][1], A[1][2], A[2][0], A[2][1], A[2][2]);
+        det = det3<R>(A[0][0], A[0][1], A[0][2], A[1][0], A[1][1], A[1][2], A[2][0], A[2][1], A[2][2]);
     } else {
         det = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            T m[3][3];
+            R m[3][3];
             int cc = 0;
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
@@ -431,16 +437,16 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
                 for (int r = 1; r < 4; ++r) m[r - 1][cc] = A[r][c2];
                 cc++;
             }
-            const T d3 = det3<T>(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
-            det += ((c & 1) ? T(-1) : T(1)) * A[0][c] * d3;
+            const R d3 = det3<R>(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
+            det += ((c & 1) ? R(-1) : R(1)) * A[0][c] * d3;
         }
     }
     auto me = M.pk0[i];
-    T newrho = absT(me.w);
+    R newrho = fabs((R)me.w);
     bool write = false;
-    if (absT(det) >= T(1e-3)) {
+    if (fabs(det) >= R(1e-3)) {
         // Gaussian elimination with partial pivoting on [A | b] (same order as the oracle)
-        T Mx[P][P + 1];
+        R Mx[P][P + 1];
 #pragma unroll
         for (int r = 0; r < P; ++r) {
 #pragma unroll
@@ -450,46 +456,46 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             int p = k;
-            T best = absT(Mx[k][k]);
+            R best = fabs(Mx[k][k]);
 #pragma unroll
-            for (int r = k + 1; r < P; ++r) if (absT(Mx[r][k]) > best) { best = absT(Mx[r][k]); p = r; }
+            for (int r = k + 1; r < P; ++r) if (fabs(Mx[r][k]) > best) { best = fabs(Mx[r][k]); p = r; }
 #pragma unroll
             for (int r = k + 1; r < P; ++r) {
                 if (r == p) {
 #pragma unroll
-                    for (int c = 0; c <= P; ++c) { T t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
+                    for (int c = 0; c <= P; ++c) { R t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
                 }
             }
 #pragma unroll
             for (int r = k + 1; r < P; ++r) {
-                const T f = Mx[r][k] / Mx[k][k];
+                const R f = Mx[r][k] / Mx[k][k];
 #pragma unroll
                 for (int c = k; c <= P; ++c) Mx[r][c] -= f * Mx[k][c];
             }
         }
-        T s[P];
+        R s[P];
 #pragma unroll
         for (int r = P - 1; r >= 0; --r) {
-            T acc = Mx[r][P];
+            R acc = Mx[r][P];
 #pragma unroll
             for (int c = r + 1; c < P; ++c) acc -= Mx[r][c] * s[c];
             s[r] = acc / Mx[r][r];
         }
-        const T xi[3] = {me.x, me.y, me.z};
-        T v1 = s[0];
+        const R xi[3] = {(R)me.x, (R)me.y, (R)me.z};
+        R v1 = s[0];
 #pragma unroll
         for (int d = 0; d < D; ++d) v1 += s[d + 1] * (xi[d] - g[d]);
-        newrho = (v1 != v1) ? M.rho0 : v1;
+        newrho = (v1 != v1) ? (R)M.rho0 : v1;
         write = true;
-    } else if (A[0][0] > T(0)) {
-        const T v = b[0] / A[0][0];
-        newrho = (v != v) ? M.rho0 : v;
+    } else if (A[0][0] > R(0)) {
+        const R v = b[0] / A[0][0];
+        newrho = (v != v) ? (R)M.rho0 : v;
         write = true;
     }
     if (write) {
         // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
-        if (!(newrho > T(0))) atomicOr(&M.red[3], 1ull);
-        me.w = me.w > T(0) ? newrho : -newrho;
+        if (!(newrho > R(0))) atomicOr(&M.red[3], 1ull);
+        me.w = me.w > T(0) ? (T)newrho : (T)(-newrho);
         M.pk0[i] = me;
     }
 }

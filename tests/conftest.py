@@ -36,6 +36,31 @@ def load_still_wedge():
     return p, setup_still_wedge_mdbc()
 
 
+def _load_mdbc(dims, stem_bound, stem_fluid, stem_ghost, setup):
+    from sphexample_amd import AllocateDataStructures, LoadMDBCNormals
+    p = AllocateDataStructures(_geoms(dims, stem_bound, stem_fluid))
+    LoadMDBCNormals(p, os.path.join(INPUT, stem_ghost))
+    return p, setup
+
+
+def load_dam_break_2d_mdbc():
+    from sphexample_amd.cases import setup_dam_break_2d_mdbc
+    return _load_mdbc(2, "DamBreak2d_Dp0.02_MDBC_Bound_ThreeLayers.csv.gz", "DamBreak2d_Dp0.02_MDBC_Fluid_ThreeLayers.csv.gz",
+                      "DamBreak2d_Dp0.02_MDBC_GhostNodes_ThreeLayers.csv.gz", setup_dam_break_2d_mdbc())
+
+
+def load_still_wedge_middle_square():
+    from sphexample_amd.cases import setup_still_wedge_middle_square_mdbc
+    return _load_mdbc(2, "StillWedge_MiddleSquare_Dp0.02_Bound.csv.gz", "StillWedge_MiddleSquare_Dp0.02_Fluid.csv.gz",
+                      "StillWedge_MiddleSquare_Dp0.02_GhostNodes.csv.gz", setup_still_wedge_middle_square_mdbc())
+
+
+def load_duckling():
+    from sphexample_amd.cases import setup_duckling_mdbc
+    return _load_mdbc(3, "CaseDuckling_Dp0.01_Bound_MDBC.csv.gz", "CaseDuckling_Dp0.01_Fluid_MDBC.csv.gz",
+                      "CaseDuckling_Dp0.01_GhostNodes.csv.gz", setup_duckling_mdbc())
+
+
 def load_dam_break_3d_shipped():
     from sphexample_amd import AllocateDataStructures
     from sphexample_amd.cases import setup_dam_break_3d
@@ -50,6 +75,21 @@ def dam_break_2d():
 @pytest.fixture(scope="session")
 def still_wedge():
     return load_still_wedge()
+
+
+@pytest.fixture(scope="session")
+def dam_break_2d_mdbc():
+    return load_dam_break_2d_mdbc()
+
+
+@pytest.fixture(scope="session")
+def still_wedge_middle_square():
+    return load_still_wedge_middle_square()
+
+
+@pytest.fixture(scope="session")
+def duckling():
+    return load_duckling()
 
 
 @pytest.fixture(scope="session")
