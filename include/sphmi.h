@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SPHMI_ABI_VERSION 1
+#define SPHMI_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -48,8 +48,11 @@ enum {
 
 /* model tags; values mirror the reference's dispatch types */
 enum { SPHMI_KERNEL_WENDLAND_C2 = 0 };                      /* src/SPHKernels.jl:13,75-87        */
-enum { SPHMI_VISC_ZERO = 0, SPHMI_VISC_ARTIFICIAL = 1 };    /* src/SPHViscosityModels.jl:51-74   */
-enum { SPHMI_DDT_NONE = 0, SPHMI_DDT_LINEAR = 2 };          /* src/SPHDensityDiffusionModels.jl:100-136 */
+enum { SPHMI_VISC_ZERO = 0, SPHMI_VISC_ARTIFICIAL = 1, SPHMI_VISC_LAMINAR = 2, SPHMI_VISC_LAMINAR_SPS = 3 };
+                                                            /* src/SPHViscosityModels.jl:51-126  */
+enum { SPHMI_DDT_NONE = 0, SPHMI_DDT_ZERO_GRAVITY_LINEAR = 1, SPHMI_DDT_LINEAR = 2, SPHMI_DDT_COMPLEX = 3 };
+                                                            /* src/SPHDensityDiffusionModels.jl:30-188 */
+enum { SPHMI_SHIFT_NONE = 0, SPHMI_SHIFT_PLANAR = 1 };      /* src/SPHCellList.jl:73-88,654-677 */
 enum { SPHMI_MDBC_NONE = 0, SPHMI_MDBC_SIMPLE = 1 };        /* src/SimulationMetaDataConfiguration.jl:20-22 */
 /* ParticleType values, src/SimulationGeometry.jl:10-14 */
 enum { SPHMI_FLUID = 1, SPHMI_FIXED = 2, SPHMI_MOVING = 3 };
@@ -71,7 +74,7 @@ typedef struct sphmi_config {
     int32_t density_diffusion;   /* SPHMI_DDT_*                                                  */
     int32_t mdbc;                /* SPHMI_MDBC_*                                                 */
     int32_t device;              /* HIP device ordinal                                           */
-    int32_t reserved0;
+    int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
     int32_t reserved1;
     int64_t n_particles;         /* length(SimParticles)                                         */
     int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
@@ -79,6 +82,8 @@ typedef struct sphmi_config {
     double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;
     /* SPHKernelInstance */
     double k, h, h_inv, H, H_inv, H2, alphaD, eta2;
+    /* SimulationConstants, continued (LaminarSPS) */
+    double blin_constant, smagorinsky_constant;
 } sphmi_config;
 
 /* What the reference's SimulationLoop leaves in SimMetaData (src/SPHCellList.jl:679-685,:759). */
@@ -121,6 +126,15 @@ int sphmi_upload(sphmi_handle* h,
 
 /* Set / read SimMetaData.Iteration and SimMetaData.TotalTime (they live in the host struct). */
 int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
+
+/*
+ * MotionDetails of the Geometry with this GroupMarker (src/SimulationGeometry.jl:17-22): particles of Type Moving
+ * in that group get Velocity = velocity·direction while start_time <= TotalTime <= start_time + duration (0
+ * otherwise) and are displaced by Velocity·dt/2 before each neighbour pass — ProgressMotion,
+ * src/SPHCellList.jl:575-596, called at :765 and :787.  `direction` holds `dims` doubles.  At most 16 groups.
+ */
+int sphmi_set_motion(sphmi_handle* h, uint64_t group_marker, double velocity, double start_time, double duration,
+                     const double* direction);
 
 /*
  * One SimulationLoop call (src/SPHCellList.jl:727-805): reset Δx = 1 + h, then step

@@ -55,6 +55,11 @@ typedef struct orc_handle {
     void    *scratch;
     /* mdbc */
     double  *bgam, *Agam;
+    /* PlanarShifting accumulators ∇Cᵢ (N*D) and ∇◌rᵢ (N) with their per-thread copies (src/PreProcess.jl:198-215) */
+    double  *gradC, *divr, **gradC_thr, **divr_thr;
+    /* MotionDetails by GroupMarker (src/SimulationGeometry.jl:17-22) */
+    int      n_motion;
+    struct { uint64_t group; double vel, start, dur, dir[MAXD]; } motion[16];
     /* SimMetaData */
     int64_t iteration, n_rebuilds;
     double  total_time, last_dt, delta_x;
@@ -255,14 +260,31 @@ static int64_t cell_slot(const orc_handle *o, const int64_t *cell) {
     return 1;
 }
 
+/* SimulationEquations.jl:49-62 Estimate7thRoot / InverseHydrostaticEquationOfState (Float64 bit trick + two
+ * Newton steps of t³ − x/t⁴ = 0; @fastmath may re-associate: not reproduced) */
+static inline double estimate_7th_root(double x) {
+    union { double d; uint64_t u; } a, t0;
+    a.d = fabs(x);
+    t0.u = 0x36cd000000000000ull + a.u / 7ull;
+    double t = copysign(t0.d, x);
+    for (int k = 0; k < 2; ++k) {
+        double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, xot4 = x / t4;
+        t = t - t * (t3 - xot4) / (4.0 * t3 + 3.0 * xot4);
+    }
+    return t;
+}
+
 /* ---------------------------------------------------------------------------------------------
- * SPHCellList.jl:268-317 ComputeInteractions!  with
- * SPHDensityDiffusionModels.jl:100-136 (Linear) and SPHViscosityModels.jl:56-74 (Artificial).
- * i, j are 0-based.  `rho` is the Density argument of the pair loop; o->rho is SimParticles.Density.
+ * SPHCellList.jl:268-317 ComputeInteractions!  with the density-diffusion models of
+ * SPHDensityDiffusionModels.jl:30-188, the viscosity models of SPHViscosityModels.jl:51-126 and
+ * add_shifting_terms! (SPHCellList.jl:73-88).
+ * i, j are 0-based.  `rho` / `vel` are the Density / Velocity arguments of the pair loop;
+ * o->rho / o->vel are SimParticles.Density / .Velocity (quirk Q2: several model terms read those).
  * ------------------------------------------------------------------------------------------- */
 static inline void compute_interactions(const orc_handle *o, const double *pos, const double *rho,
                                         const double *press, const double *vel,
-                                        int64_t i, int64_t j, double *drho_t, double *acc_t) {
+                                        int64_t i, int64_t j, double *drho_t, double *acc_t,
+                                        double *gradC_t, double *divr_t) {
     const sphmi_config *c = &o->cfg;
     const int D = o->D;
     double xij[MAXD], r2 = 0.0;
@@ -289,16 +311,23 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
 
     /* density diffusion — reads SimParticles.Density (quirk Q2) */
     double Di = 0.0, Dj = 0.0;
-    if (c->density_diffusion == SPHMI_DDT_LINEAR) {
-        double lin = (1.0 / (c->Cb * c->gamma)) * c->rho0;
+    if (c->density_diffusion != SPHMI_DDT_NONE) {
         double rn_i = o->rho[i], rn_j = o->rho[j];
-        double PH = c->rho0 * (-c->g) * -xij[D - 1];
-        double rhoH = PH * lin;
+        double rhoH = 0.0, mlc = 1.0;
+        if (c->density_diffusion == SPHMI_DDT_LINEAR) {                       /* :100-136 */
+            double lin = (1.0 / (c->Cb * c->gamma)) * c->rho0;
+            double PH = c->rho0 * (-c->g) * -xij[D - 1];
+            rhoH = PH * lin;
+            mlc = o->ml[i] * o->ml[j];
+        } else if (c->density_diffusion == SPHMI_DDT_COMPLEX) {               /* :150-188 */
+            double PH = c->rho0 * (-c->g) * -xij[D - 1];
+            rhoH = c->rho0 * (estimate_7th_root(1.0 + PH * (1.0 / c->Cb)) - 1.0);
+            mlc = o->ml[i] * o->ml[j];
+        }                                                                     /* :56-87: no ρᴴ, no MLcond */
         double inv = 1.0 / (r2 + c->eta2);
         double rji = rn_j - rn_i;
         double dot = 0.0;
         for (int d = 0; d < D; ++d) dot += (2.0 * (rji - rhoH) * (-xij[d]) * inv) * gW[d];
-        double mlc = o->ml[i] * o->ml[j];
         Di = c->delta_phi * c->h * c->c0 * (c->m0 / rn_j) * dot * mlc;
         Dj = -Di;
     }
@@ -309,7 +338,7 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
     double um[MAXD];
     for (int d = 0; d < D; ++d) um[d] = -c->m0 * (Pfac + 0.0) * gW[d];
 
-    if (c->viscosity == SPHMI_VISC_ARTIFICIAL) {
+    if (c->viscosity == SPHMI_VISC_ARTIFICIAL) {                              /* :56-74 */
         double rn_i = o->rho[i], rn_j = o->rho[j];
         double vdx = 0.0;
         for (int d = 0; d < D; ++d) vdx += vij[d] * xij[d];
@@ -319,10 +348,57 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
             double k = -c->m0 * (-c->alpha * c->c0 * mu) / rbar;
             for (int d = 0; d < D; ++d) um[d] += k * gW[d];
         }
+    } else if (c->viscosity == SPHMI_VISC_LAMINAR || c->viscosity == SPHMI_VISC_LAMINAR_SPS) {
+        double rn_i = o->rho[i], rn_j = o->rho[j];
+        double xdg = 0.0;
+        for (int d = 0; d < D; ++d) xdg += xij[d] * gW[d];
+        /* :77-87 — the denominator adds (ρᵢ+ρⱼ) and (d²+η²) exactly as the reference does */
+        double term = (4.0 * c->m0 * c->nu0 * xdg) / ((rn_i + rn_j) + (r2 + c->eta2));
+        for (int d = 0; d < D; ++d) um[d] += term * vij[d];
+        if (c->viscosity == SPHMI_VISC_LAMINAR_SPS) {                         /* :90-126 */
+            const double *vi = &o->vel[i * D], *vj = &o->vel[j * D];          /* SimParticles.Velocity */
+            double Si[MAXD][MAXD], Sj[MAXD][MAXD], ti[MAXD][MAXD], tj[MAXD][MAXD];
+            double ssi = 0.0, ssj = 0.0, tri = 0.0, trj = 0.0;
+            for (int r = 0; r < D; ++r)
+                for (int cc = 0; cc < D; ++cc) {
+                    Si[r][cc] = (c->m0 / rn_j) * (vj[r] - vi[r]) * gW[cc];
+                    Sj[r][cc] = (c->m0 / rn_i) * (vi[r] - vj[r]) * -gW[cc];
+                    ssi += Si[r][cc] * Si[r][cc];
+                    ssj += Sj[r][cc] * Sj[r][cc];
+                    if (r == cc) { tri += Si[r][cc]; trj += Sj[r][cc]; }
+                }
+            double ni = sqrt(2.0 * ssi), nj = sqrt(2.0 * ssj);
+            double csdx2 = (c->smagorinsky_constant * c->dx) * (c->smagorinsky_constant * c->dx);
+            double nuti = csdx2 * ni, nutj = csdx2 * nj;
+            for (int r = 0; r < D; ++r)
+                for (int cc = 0; cc < D; ++cc) {
+                    double I = r == cc ? 1.0 : 0.0;
+                    ti[r][cc] = 2.0 * nuti * rn_i * (Si[r][cc] - (1.0 / 3.0) * tri * I)
+                                - (2.0 / 3.0) * rn_i * c->blin_constant * (c->dx * c->dx) * (ni * ni) * I;
+                    tj[r][cc] = 2.0 * nutj * rn_j * (Sj[r][cc] - (1.0 / 3.0) * trj * I)
+                                - (2.0 / 3.0) * rn_j * c->blin_constant * (c->dx * c->dx) * (nj * nj) * I;
+                }
+            for (int r = 0; r < D; ++r) {
+                double sacc = 0.0;
+                for (int cc = 0; cc < D; ++cc) sacc += (ti[r][cc] + tj[r][cc]) * gW[cc];
+                um[r] += (c->m0 / (rn_j * rn_i)) * sacc;
+            }
+        }
     }
     for (int d = 0; d < D; ++d) {
         acc_t[i * D + d] += um[d];
         acc_t[j * D + d] -= um[d];
+    }
+    if (gradC_t) {                                                            /* add_shifting_terms!, :73-88 */
+        double mlc = o->ml[i] * o->ml[j];
+        double xdg = 0.0;
+        for (int d = 0; d < D; ++d) xdg += xij[d] * gW[d];
+        for (int d = 0; d < D; ++d) {
+            gradC_t[i * D + d] += (c->m0 / rho_i) * gW[d];
+            gradC_t[j * D + d] += (c->m0 / rho_j) * -gW[d];
+        }
+        divr_t[i] += (c->m0 / rho_j) * (-xdg) * mlc;
+        divr_t[j] += (c->m0 / rho_i) * (-xdg) * mlc;
     }
 }
 
@@ -353,13 +429,16 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
     if (chunk < 1) chunk = 1;
     int64_t nchunks = (nview + chunk - 1) / chunk;
 
+    const int shift = o->cfg.shifting == SPHMI_SHIFT_PLANAR;
     /* ResetStep! */
     memset(o->drhodt, 0, sizeof(double) * (size_t)N);
     memset(o->acc, 0, sizeof(double) * (size_t)N * D);
+    if (shift) { memset(o->gradC, 0, sizeof(double) * (size_t)N * D); memset(o->divr, 0, sizeof(double) * (size_t)N); }
 #pragma omp parallel for num_threads(T) schedule(static)
     for (int t = 0; t < T; ++t) {
         memset(o->drhodt_thr[t], 0, sizeof(double) * (size_t)N);
         memset(o->acc_thr[t], 0, sizeof(double) * (size_t)N * D);
+        if (shift) { memset(o->gradC_thr[t], 0, sizeof(double) * (size_t)N * D); memset(o->divr_thr[t], 0, sizeof(double) * (size_t)N); }
     }
 
 #pragma omp parallel for num_threads(T) schedule(static, 1)
@@ -368,6 +447,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
         /* chunks ch, ch+T, ... share a copy; with schedule(static,1) they also share a thread */
         double *drho_t = o->drhodt_thr[copy];
         double *acc_t = o->acc_thr[copy];
+        double *gC_t = shift ? o->gradC_thr[copy] : NULL, *dr_t = shift ? o->divr_thr[copy] : NULL;
         int64_t it0 = ch * chunk + 1, it1 = it0 + chunk - 1;  /* 1-based iter as in the reference */
         if (it1 > nview) it1 = nview;
         for (int64_t iter = it0; iter <= it1; ++iter) {
@@ -375,7 +455,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
             int64_t s0 = o->ranges[iter - 1], e0 = o->ranges[iter] - 1;  /* 1-based inclusive */
             for (int64_t i = s0; i <= e0; ++i)
                 for (int64_t j = i + 1; j <= e0; ++j)
-                    compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t);
+                    compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t);
             for (int s = 0; s < ns; ++s) {
                 int64_t sc[MAXD];
                 for (int d = 0; d < D; ++d) sc[d] = cell[d] + stencil[s][d];
@@ -383,7 +463,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
                 int64_t s1 = o->ranges[nb - 1], e1 = o->ranges[nb] - 1;
                 for (int64_t i = s0; i <= e0; ++i)
                     for (int64_t j = s1; j <= e1; ++j)
-                        compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t);
+                        compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t);
             }
         }
     }
@@ -393,6 +473,10 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
         for (int t = 0; t < T; ++t) {
             o->drhodt[i] += o->drhodt_thr[t][i];
             for (int d = 0; d < D; ++d) o->acc[i * D + d] += o->acc_thr[t][i * D + d];
+            if (shift) {
+                o->divr[i] += o->divr_thr[t][i];
+                for (int d = 0; d < D; ++d) o->gradC[i * D + d] += o->gradC_thr[t][i * D + d];
+            }
         }
     }
 }
@@ -531,16 +615,47 @@ static void half_time_step(orc_handle *o, double dt2) {
     }
 }
 
-/* SPHCellList.jl:640-652 FullTimeStep (NoShifting) */
+/* SPHCellList.jl:640-652 FullTimeStep (NoShifting) and :654-677 (PlanarShifting) */
 static void full_time_step(orc_handle *o, double dt) {
     const int D = o->D;
+    const int shift = o->cfg.shifting == SPHMI_SHIFT_PLANAR;
+    const double A = 2.0, A_FST = 0.0, A_FSM = (double)D;
     for (int64_t i = 0; i < o->N; ++i) {
         o->acc[i * D + D - 1] += o->cfg.g * o->gf[i];
+        for (int d = 0; d < D; ++d) o->vel[i * D + d] += o->acc[i * D + d] * dt * o->ml[i];
+        double dxs[MAXD] = {0.0, 0.0, 0.0};
+        if (shift) {
+            double A_FSC = (o->divr[i] - A_FST) / (A_FSM - A_FST);
+            if (!(A_FSC < 0.0)) {
+                double vn = 0.0;
+                for (int d = 0; d < D; ++d) vn += o->vel[i * D + d] * o->vel[i * D + d];
+                vn = sqrt(vn);
+                for (int d = 0; d < D; ++d) dxs[d] = -A_FSC * A * o->cfg.h * vn * dt * o->gradC[i * D + d];
+            }
+        }
         for (int d = 0; d < D; ++d) {
             double a = o->acc[i * D + d];
-            o->vel[i * D + d] += a * dt * o->ml[i];
             double v = o->vel[i * D + d];
-            o->pos[i * D + d] += (((v + (v - a * dt * o->ml[i])) / 2.0) * dt) * o->ml[i];
+            o->pos[i * D + d] += (((v + (v - a * dt * o->ml[i])) / 2.0) * dt + dxs[d]) * o->ml[i];
+        }
+    }
+}
+
+/* SPHCellList.jl:575-596 ProgressMotion */
+static void progress_motion(orc_handle *o, double dt2) {
+    const int D = o->D;
+    if (o->n_motion == 0) return;
+    for (int64_t i = 0; i < o->N; ++i) {
+        if (o->type[i] != SPHMI_MOVING) continue;
+        for (int m = 0; m < o->n_motion; ++m) {
+            if (o->motion[m].group != o->group[i]) continue;
+            double should = (o->motion[m].start <= o->total_time &&
+                             o->total_time <= o->motion[m].start + o->motion[m].dur) ? 1.0 : 0.0;
+            for (int d = 0; d < D; ++d) {
+                o->vel[i * D + d] = o->motion[m].vel * o->motion[m].dir[d] * should;
+                o->pos[i * D + d] += o->vel[i * D + d] * dt2;
+            }
+            break;
         }
     }
 }
@@ -558,12 +673,13 @@ static int one_step(orc_handle *o) {
         update_neighbors(o);
         o->delta_x = 0.0;
     }
-    /* ProgressMotion (:765): no Moving groups in scope */
+    progress_motion(o, dt2);                                    /* :765 */
     pressure(o, o->press, o->rho);                              /* :771 */
     if (o->cfg.mdbc == SPHMI_MDBC_SIMPLE) apply_mdbc_before_half(o);   /* :772 */
     neighbor_loop(o, o->pos, o->rho, o->press, o->vel);         /* :768,:774-775 */
     half_time_step(o, dt2);                                     /* :778 */
     limit_density_at_boundary(o, o->rho_np);                    /* :781 */
+    progress_motion(o, dt2);                                    /* :787 */
     pressure(o, o->press, o->rho_np);                           /* :789 */
     neighbor_loop(o, o->pos_np, o->rho_np, o->press, o->vel_np);/* :784,:790-791 */
     limit_density_at_boundary(o, o->rho);                       /* :794 */
@@ -605,6 +721,7 @@ int orc_create(const sphmi_config *cfg, orc_handle **out) {
     o->ranges = xcalloc(N + 2, 8); o->ucells = xcalloc((N + 1) * D, 8);
     o->perm = xcalloc(N, 8); o->perm_tmp = xcalloc(N, 8); o->scratch = xcalloc(N * D, 8);
     o->bgam = xcalloc(N * 4, 8); o->Agam = xcalloc(N * 16, 8);
+    o->gradC = xcalloc(N * D, 8); o->divr = xcalloc(N, 8);
     o->nthreads = 0;
     orc_set_threads(o, 1);
     *out = o;
@@ -614,23 +731,29 @@ int orc_create(const sphmi_config *cfg, orc_handle **out) {
 int orc_set_threads(orc_handle *o, int n) {
     if (n < 1) n = 1;
     if (o->drhodt_thr) {
-        for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); }
-        free(o->drhodt_thr); free(o->acc_thr);
+        for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); }
+        free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr);
     }
     o->nthreads = n;
     o->drhodt_thr = calloc((size_t)n, sizeof(double *));
     o->acc_thr = calloc((size_t)n, sizeof(double *));
+    o->gradC_thr = calloc((size_t)n, sizeof(double *));
+    o->divr_thr = calloc((size_t)n, sizeof(double *));
+    const int shift = o->cfg.shifting == SPHMI_SHIFT_PLANAR;
     for (int t = 0; t < n; ++t) {
         o->drhodt_thr[t] = xcalloc((size_t)o->N, 8);
         o->acc_thr[t] = xcalloc((size_t)o->N * o->D, 8);
+        o->gradC_thr[t] = xcalloc(shift ? (size_t)o->N * o->D : 1, 8);
+        o->divr_thr[t] = xcalloc(shift ? (size_t)o->N : 1, 8);
     }
     return SPHMI_OK;
 }
 
 int orc_destroy(orc_handle *o) {
     if (!o) return SPHMI_OK;
-    for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); }
-    free(o->drhodt_thr); free(o->acc_thr);
+    for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); }
+    free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr);
+    free(o->gradC); free(o->divr);
     free(o->pos); free(o->vel); free(o->acc); free(o->rho); free(o->press); free(o->gf); free(o->ml);
     free(o->ghost); free(o->type); free(o->id); free(o->group); free(o->cells);
     free(o->drhodt); free(o->vel_np); free(o->pos_np); free(o->rho_np);
@@ -665,6 +788,18 @@ int orc_upload(orc_handle *o, const double *position, const double *velocity, co
     pressure(o, o->press, o->rho);         /* src/SPHCellList.jl:835 */
     o->index_counter = 0;
     o->uploaded = 1;
+    return SPHMI_OK;
+}
+
+int orc_set_motion(orc_handle *o, uint64_t group, double velocity, double start_time, double duration,
+                   const double *direction) {
+    if (!o || !direction) return SPHMI_ERR_ARGUMENT;
+    int m = 0;
+    while (m < o->n_motion && o->motion[m].group != group) ++m;
+    if (m == 16) { snprintf(o->err, sizeof(o->err), "orc_set_motion: more than 16 groups"); return SPHMI_ERR_ARGUMENT; }
+    if (m == o->n_motion) o->n_motion += 1;
+    o->motion[m].group = group; o->motion[m].vel = velocity; o->motion[m].start = start_time; o->motion[m].dur = duration;
+    for (int d = 0; d < MAXD; ++d) o->motion[m].dir[d] = d < o->D ? direction[d] : 0.0;
     return SPHMI_OK;
 }
 

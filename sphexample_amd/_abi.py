@@ -13,7 +13,7 @@ import numpy as np
 from .config import (NoMDBC, SimpleMDBC, SimulationConstants, SimulationMetaData, SPHDensityDiffusion,
                      SPHKernelInstance, SPHViscosity)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NUMERIC, ERR_DOMAIN, ERR_STATE = range(6)
 
@@ -23,13 +23,14 @@ class SphmiConfig(C.Structure):
         ("struct_size", C.c_int32), ("abi_version", C.c_int32), ("dims", C.c_int32),
         ("host_float_bytes", C.c_int32), ("device_float_bytes", C.c_int32), ("kernel", C.c_int32),
         ("viscosity", C.c_int32), ("density_diffusion", C.c_int32), ("mdbc", C.c_int32),
-        ("device", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("device", C.c_int32), ("shifting", C.c_int32), ("reserved1", C.c_int32),
         ("n_particles", C.c_int64), ("max_cells", C.c_int64),
         ("rho0", C.c_double), ("dx", C.c_double), ("m0", C.c_double), ("alpha", C.c_double),
         ("g", C.c_double), ("c0", C.c_double), ("gamma", C.c_double), ("delta_phi", C.c_double),
         ("CFL", C.c_double), ("Cb", C.c_double), ("nu0", C.c_double),
         ("k", C.c_double), ("h", C.c_double), ("h_inv", C.c_double), ("H", C.c_double),
         ("H_inv", C.c_double), ("H2", C.c_double), ("alphaD", C.c_double), ("eta2", C.c_double),
+        ("blin_constant", C.c_double), ("smagorinsky_constant", C.c_double),
     ]
 
 
@@ -58,8 +59,8 @@ def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: 
     for tag, what in ((SimViscosity, "viscosity"), (SimDensityDiffusion, "density diffusion")):
         if getattr(tag, "abi_value", None) is None:
             raise NotImplementedError(f"{type(tag).__name__}: {what} model not implemented by the engine")
-    if SimMetaData.SMode.__name__ != "NoShifting" or SimMetaData.KMode.__name__ != "NoKernelOutput":
-        raise NotImplementedError("PlanarShifting / StoreKernelOutput are not implemented by the engine")
+    if SimMetaData.KMode.__name__ != "NoKernelOutput":
+        raise NotImplementedError("StoreKernelOutput is not implemented by the engine")
     c = SphmiConfig()
     c.struct_size = C.sizeof(SphmiConfig)
     c.abi_version = ABI_VERSION
@@ -70,6 +71,9 @@ def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: 
     c.viscosity = SimViscosity.abi_value
     c.density_diffusion = SimDensityDiffusion.abi_value
     c.mdbc = 1 if SimMetaData.BMode is SimpleMDBC else 0
+    c.shifting = 1 if SimMetaData.SMode.__name__ == "PlanarShifting" else 0
+    c.blin_constant = SimConstants.BlinConstant
+    c.smagorinsky_constant = SimConstants.SmagorinskyConstant
     c.device = device
     c.n_particles = n_particles
     c.max_cells = max_cells
@@ -106,6 +110,7 @@ class Backend:
         f("destroy").argtypes = [C.c_void_p]
         f("upload").argtypes = [C.c_void_p] * 9
         f("set_clock").argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        f("set_motion").argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
         f("advance").argtypes = [C.c_void_p, C.c_double, C.c_int64, C.POINTER(SphmiProgress)]
         f("download").argtypes = [C.c_void_p] * 11
         f("forces_once").argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -150,6 +155,19 @@ class Backend:
     def upload_particles(self, p):
         self.upload(p.Position, p.Velocity, p.Acceleration, p.Density, p.Type, p.ID, p.GroupMarker,
                     p.GhostPoints if self.cfg.mdbc else None)
+
+    def set_motion(self, group_marker: int, motion):
+        """MotionDetails of one Geometry (src/SimulationGeometry.jl:17-22) → ProgressMotion of that group."""
+        d = np.zeros(3)
+        d[:self.D] = np.asarray(motion.Direction, dtype=np.float64)[:self.D]
+        self._check(self._fn("set_motion")(self._h, int(group_marker), float(motion.Velocity), float(motion.StartTime),
+                                            float(motion.Duration), d.ctypes.data_as(C.c_void_p)))
+
+    def set_motions(self, geometries):
+        """Register the Motion of every Geometry that has one (RunSimulation's MotionDefinition dict, :846-850)."""
+        for g in geometries or ():
+            if getattr(g, "Motion", None) is not None:
+                self.set_motion(g.GroupMarker, g.Motion)
 
     def set_clock(self, iteration: int, total_time: float):
         self._check(self._fn("set_clock")(self._h, iteration, total_time))

@@ -20,7 +20,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from .config import (ArtificialViscosity, Fixed, Fluid, LinearDensityDiffusion, NoMDBC, SimpleMDBC,
-                     SimulationConstants, SimulationMetaData, SPHKernelInstance, WendlandC2)
+                     SimulationConstants, SimulationMetaData, SPHKernelInstance, WendlandC2, LaminarSPS, MotionDetails, PlanarShifting)
 from .preprocess import SimParticles, particles_from_arrays
 
 
@@ -155,6 +155,21 @@ def setup_duckling_mdbc() -> CaseSetup:
     meta = SimulationMetaData(Dimensions=3, BMode=SimpleMDBC, SimulationName="CaseDuckling",
                               SimulationTime=1.0, OutputTimes=0.02)
     return CaseSetup("duckling_mdbc", consts, kern, meta, ArtificialViscosity(), LinearDensityDiffusion())
+
+
+def setup_moving_square_2d(dx: float = 0.04) -> CaseSetup:
+    """example/MovingSquare2d.jl:9-25,67,78-79 (PlanarShifting + LaminarSPS + a Moving body); dx = 0.04 is the
+    resolution whose three input files the reference ships."""
+    consts = SimulationConstants(dx=dx, c0=28.0, delta_phi=0.1, g=0.0, Cb=112000.0, alpha=1e-6, CFL=0.2)
+    kern = SPHKernelInstance(2, WendlandC2(), dx=dx, k=math.sqrt(2))
+    meta = SimulationMetaData(Dimensions=2, SMode=PlanarShifting, BMode=NoMDBC, SimulationName="MovingSquare2D",
+                              SimulationTime=2.5, OutputTimes=0.01)
+    return CaseSetup("moving_square_2d", consts, kern, meta, LaminarSPS(), LinearDensityDiffusion())
+
+
+def moving_square_motion() -> MotionDetails:
+    """example/MovingSquare2d.jl:45-50."""
+    return MotionDetails(Velocity=2.8, StartTime=0.0, Duration=3.0, Direction=(1.0, 0.0))
 
 
 def setup_still_wedge_mdbc() -> CaseSetup:

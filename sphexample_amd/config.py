@@ -48,12 +48,12 @@ class ArtificialViscosity(SPHViscosity):
     abi_value = 1
 
 
-class Laminar(SPHViscosity):  # next
-    abi_value = None
+class Laminar(SPHViscosity):  # src/SPHViscosityModels.jl:77-87
+    abi_value = 2
 
 
-class LaminarSPS(SPHViscosity):
-    abi_value = None
+class LaminarSPS(SPHViscosity):  # src/SPHViscosityModels.jl:90-126
+    abi_value = 3
 
 
 class SPHDensityDiffusion:  # src/SPHDensityDiffusionModels.jl:22
@@ -71,17 +71,17 @@ class LinearDensityDiffusion(SPHDensityDiffusion):
     abi_value = 2
 
 
-class ZeroGravityLinearDensityDiffusion(SPHDensityDiffusion):  # next (f1)
-    abi_value = None
+class ZeroGravityLinearDensityDiffusion(SPHDensityDiffusion):  # src/SPHDensityDiffusionModels.jl:56-87
+    abi_value = 1
 
 
-class ComplexDensityDiffusion(SPHDensityDiffusion):  # next (f1)
-    abi_value = None
+class ComplexDensityDiffusion(SPHDensityDiffusion):  # src/SPHDensityDiffusionModels.jl:150-188
+    abi_value = 3
 
 
 class ShiftingMode: ...
 class NoShifting(ShiftingMode): ...
-class PlanarShifting(ShiftingMode): ...          # next (f1)
+class PlanarShifting(ShiftingMode): ...          # src/SPHCellList.jl:73-88,654-677
 class KernelOutputMode: ...
 class NoKernelOutput(KernelOutputMode): ...
 class StoreKernelOutput(KernelOutputMode): ...   # next (f1)

@@ -57,6 +57,7 @@ struct EngineBase {
     virtual void device_ptrs(void** pk0, void** pk1, int64_t* n) = 0;
     virtual void reset_count() = 0;
     // domain decomposition
+    virtual void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) = 0;
     virtual void dd_set_stream(void* s) = 0;
     virtual void dd_upload(int64_t n, const void*, const void*, const void*, const void*, const uint8_t*,
                            const int64_t*, const uint64_t*) = 0;
@@ -102,6 +103,7 @@ struct Engine final : EngineBase {
     int *part_d = nullptr, *part_h = nullptr;       // 2 × 16 ints: run starts and run lengths per XCD
     uint8_t* tile_cls = nullptr;
     unsigned long long* trace_d = nullptr;
+    MotionTable motions{};
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
     static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
@@ -248,6 +250,12 @@ struct Engine final : EngineBase {
         P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
         P.eta2 = (T)cfg.eta2;
         P.Kv2 = (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h);
+        P.visc = cfg.viscosity; P.ddt = cfg.density_diffusion; P.shift = cfg.shifting == SPHMI_SHIFT_PLANAR;
+        P.exact_cut = !(cfg.H >= 2.0 * cfg.h);
+        P.Klam = (T)(4.0 * cfg.m0 * cfg.nu0);
+        P.sps_cs2 = (T)((cfg.smagorinsky_constant * cfg.dx) * (cfg.smagorinsky_constant * cfg.dx));
+        P.sps_blin = (T)((2.0 / 3.0) * cfg.blin_constant * cfg.dx * cfg.dx);
+        P.hyd_a = cfg.rho0 * cfg.g / cfg.Cb; P.hyd_b = cfg.rho0;
         P.rho0 = (T)cfg.rho0; P.inv_rho0 = (T)(1.0 / cfg.rho0);
         P.g = (T)cfg.g;
         P.Cbe = (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0);
@@ -272,13 +280,28 @@ struct Engine final : EngineBase {
     }
     // list: 0 = interior tiles (all tiles when the handle has no slab), 1 = slab-edge tiles
     template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {
-        const int model = (cfg.viscosity == SPHMI_VISC_ARTIFICIAL ? 1 : 0) | (cfg.density_diffusion == SPHMI_DDT_LINEAR ? 2 : 0);
-        switch (model) {
-            case 0: launch_force_model<PASS, 0>(P, list); break;
-            case 1: launch_force_model<PASS, 1>(P, list); break;
-            case 2: launch_force_model<PASS, 2>(P, list); break;
-            default: launch_force_model<PASS, 3>(P, list); break;
-        }
+        // the compiled-in variant: the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
+        const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
+                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h;
+        if (dflt) launch_force_model<PASS, kModelDefault>(P, list);
+        else      launch_force_model<PASS, kModelGeneric>(P, list);
+    }
+
+    void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) override {
+        if (!dir) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_motion: null direction");
+        int m = 0;
+        while (m < motions.n && motions.group[m] != group) ++m;
+        if (m == 16) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_motion: more than 16 moving groups");
+        if (m == motions.n) motions.n += 1;
+        motions.group[m] = group; motions.vel[m] = vel; motions.start[m] = start; motions.dur[m] = dur;
+        for (int d = 0; d < 3; ++d) motions.dir[m][d] = d < D ? dir[d] : 0.0;
+    }
+    // ProgressMotion (src/SPHCellList.jl:765,787) on state set A
+    void progress_motion(double dt2) {
+        if (motions.n == 0) return;
+        hipLaunchKernelGGL(k_progress_motion<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA], type[cur],
+                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2);
+        HC(hipGetLastError());
     }
 
     // ---- UpdateNeighbors! -------------------------------------------------------------------
@@ -417,11 +440,13 @@ struct Engine final : EngineBase {
             throw EngineError(SPHMI_ERR_NUMERIC, buf);
         }
         if (delta_x >= cfg.h) { rebuild(); delta_x = 0.0; }                   // :758-762
+        progress_motion(dt * 0.5);                                            // :765
         HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
         if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();                        // :772 (Pressure! of :771 is in pk1.w)
         Ev e1 = begin_phase(PH_PASS1);
         launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));          // :774-781
         end_phase(e1);
+        progress_motion(dt * 0.5);                                            // :787
         Ev e2 = begin_phase(PH_PASS2);
         launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));          // :789-798
         end_phase(e2);
@@ -623,6 +648,7 @@ struct Engine final : EngineBase {
                    const void* density, const uint8_t* ty, const int64_t* ids, const uint64_t* groups) override {
         if (n < 1 || n > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: particle count exceeds the handle's capacity");
         if (cfg.mdbc != SPHMI_MDBC_NONE) throw EngineError(SPHMI_ERR_ARGUMENT, "mDBC is not supported under domain decomposition yet");
+        if (motions.n) throw EngineError(SPHMI_ERR_ARGUMENT, "moving bodies are not supported under domain decomposition yet");
         N = (int)n;
         upload(position, velocity, acceleration, density, ty, ids, groups, nullptr);
     }
@@ -812,10 +838,12 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
     if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 30))
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^30]");
     if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: only WendlandC2 is implemented");
-    if (cfg->viscosity != SPHMI_VISC_ZERO && cfg->viscosity != SPHMI_VISC_ARTIFICIAL)
+    if (cfg->viscosity < SPHMI_VISC_ZERO || cfg->viscosity > SPHMI_VISC_LAMINAR_SPS)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: viscosity model not implemented");
-    if (cfg->density_diffusion != SPHMI_DDT_NONE && cfg->density_diffusion != SPHMI_DDT_LINEAR)
+    if (cfg->density_diffusion < SPHMI_DDT_NONE || cfg->density_diffusion > SPHMI_DDT_COMPLEX)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: density diffusion model not implemented");
+    if (cfg->shifting != SPHMI_SHIFT_NONE && cfg->shifting != SPHMI_SHIFT_PLANAR)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: shifting mode not implemented");
     if (cfg->mdbc != SPHMI_MDBC_NONE && cfg->mdbc != SPHMI_MDBC_SIMPLE)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: mdbc mode not implemented");
     if (!(cfg->h > 0) || !(cfg->H > 0) || !(cfg->rho0 > 0) || !(cfg->m0 > 0) || !(cfg->c0 > 0) || !(cfg->CFL > 0))
@@ -875,6 +903,10 @@ int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
                     out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));
 }
 
+int sphmi_set_motion(sphmi_handle* h, uint64_t group_marker, double velocity, double start_time, double duration,
+                     const double* direction) {
+    SPHMI_GUARD(h, h->e->set_motion(group_marker, velocity, start_time, duration, direction));
+}
 int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time) {
     SPHMI_GUARD(h, (h->e->iteration = iteration, h->e->total_time = total_time));
 }

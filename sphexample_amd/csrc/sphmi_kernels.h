@@ -56,6 +56,10 @@ constexpr int kWave = 64;
 #endif
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
+// model tags (values of include/sphmi.h)
+enum { kViscZero = 0, kViscArtificial = 1, kViscLaminar = 2, kViscLaminarSPS = 3 };
+enum { kDdtNone = 0, kDdtZeroGravityLinear = 1, kDdtLinear = 2, kDdtComplex = 3 };
+constexpr int kModelDefault = kViscArtificial | (kDdtLinear << 4), kModelGeneric = -1;
 
 template <class T>
 struct ForceParams {
@@ -75,8 +79,13 @@ struct ForceParams {
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
     int N, nxp, nxyp;
+    int visc, ddt, shift;    // model tags for the run-time variant of the kernel
+    int exact_cut;           // H < 2h: apply r² ≤ H² per pair (the compiled-in variant requires H = 2h)
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
+    T Klam;              // 4·m₀·ν₀ (Laminar)
+    T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
+    double hyd_a, hyd_b; // ComplexDensityDiffusion: ρᴴ(z) = ρ₀·(⁷√(1 + hyd_a·z) − 1), hyd_a = ρ₀·g/Cb, hyd_b = ρ₀
 };
 
 // ------------------------------------------------------------------------------------------
@@ -121,6 +130,18 @@ __device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, int j
     f.x = __longlong_as_double(((long long)lo.y << 32) | lo.x); f.y = __longlong_as_double(((long long)lo.w << 32) | lo.z);
     f.z = __longlong_as_double(((long long)hi.y << 32) | hi.x); f.w = __longlong_as_double(((long long)hi.w << 32) | hi.z);
     return f;
+}
+
+// Estimate7thRoot, src/SimulationEquations.jl:49-61: Float64 bit trick + two Newton steps of t³ − x/t⁴ = 0
+__device__ __forceinline__ double root7_estimate(double x) {
+    const unsigned long long u = 0x36cd000000000000ull + (unsigned long long)__double_as_longlong(fabs(x)) / 7ull;
+    double t = copysign(__longlong_as_double((long long)u), x);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, xot4 = x / t4;
+        t = t - t * (t3 - xot4) / (4.0 * t3 + 3.0 * xot4);
+    }
+    return t;
 }
 
 // EquationOfStateGamma7 — src/SimulationEquations.jl:9-11
@@ -177,7 +198,10 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// MODEL: bit 0 = ArtificialViscosity, bit 1 = LinearDensityDiffusion (compile-time: no uniform branches per pair)
+// MODEL >= 0: viscosity tag in bits 0-3, density-diffusion tag in bits 4-7, no shifting — compiled in (no
+// uniform branches per pair; kModelDefault = ArtificialViscosity + LinearDensityDiffusion, what every stock
+// example but one uses).  MODEL < 0: the tags are read from the parameter block at run time (all other
+// combinations: Laminar / LaminarSPS, ZeroGravityLinear / Complex diffusion, PlanarShifting).
 // WPT: waves per tile.  The waves of a workgroup share the tile's 64 targets and split its candidate chunks
 // (chunk c of a row goes to wave (c + row) % WPT); wave 0 adds the partial sums in wave order and runs the
 // epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
@@ -185,7 +209,9 @@ __device__ __forceinline__ void wave_sync() {
 template <class T, int D, int PASS, int MODEL, int WPT>
 __global__ void __launch_bounds__(kWave * WPT)
 k_neighbor_force(const ForceParams<T> P) {
-    constexpr bool kVisc = (MODEL & 1) != 0, kDdt = (MODEL & 2) != 0;
+    const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;
+    const int ddt = MODEL >= 0 ? ((MODEL >> 4) & 15) : P.ddt;
+    const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
@@ -258,7 +284,12 @@ k_neighbor_force(const ForceParams<T> P) {
     const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
 
     T drho = 0, ax = 0, ay = 0, az = 0;
+    T gcx = 0, gcy = 0, gcz = 0, divr = 0;            // PlanarShifting: ∇Cᵢ, ∇◌rᵢ (corrector pass)
+    V4 vn_a = q1;                                       // SimParticles.Velocity of the target (LaminarSPS)
+    if constexpr (PASS == PASS_CORRECTOR) { if (visc == kViscLaminarSPS) vn_a = P.a1[ac]; }
 
+    // SimParticles.Velocity of the neighbours (LaminarSPS in the corrector pass)
+    const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.a1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     // ---- pair physics for one accepted neighbour j ------------------------------------------
     auto pair = [&](const int j, const V4& n0, const V4& n1) {
         const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
@@ -271,39 +302,89 @@ k_neighbor_force(const ForceParams<T> P) {
             rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
         }
         // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280).
-        // The phase-1 mask is slightly generous; the r² ≤ H² cut of :275 needs no branch here: beyond H the
-        // clamp makes (q−2)³ = 0 and every pair term below carries the factor `fac`.
+        // The phase-1 mask is slightly generous; with H = 2h (the default k = 2) the r² ≤ H² cut of :275 needs no
+        // branch: beyond H the clamp makes (q−2)³ = 0 and every pair term below carries the factor `fac`.
         const T r = fast_sqrt(r2);
         const T tq = min_raw(r * P.h_inv, T(2)) - T(2);
-        const T fac = P.Cgw * (tq * tq * tq);
+        T fac = P.Cgw * (tq * tq * tq);
+        // H = k·h with k < 2 (example/DucklingMDBC.jl: 1.5, MovingSquare2d.jl: √2) cuts the kernel off before it
+        // vanishes: there the cut of :275 has to be applied for real (run-time variant of the kernel only)
+        if (MODEL < 0 && P.exact_cut) fac = (r2 <= P.H2) ? fac : T(0);
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
         const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
         // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
         drho += rm_a * inv_rho_b * (fac * vdx);
         const T inv_r2e = fast_rcp(r2 + P.eta2);
-        if constexpr (kDdt) {
-            // LinearDensityDiffusion, src/SPHDensityDiffusionModels.jl:116-133; orientation rule
-            // of SURVEY §8(a)-Q4: target plays "i" iff j sorts before its cell, or after it inside it
+        if (ddt != kDdtNone) {
+            // density diffusion, src/SPHDensityDiffusionModels.jl:56-87 (no hydrostatic part, no MLcond),
+            // :100-136 (linear), :150-188 (inverse hydrostatic EOS); orientation rule of SURVEY §8(a)-Q4:
+            // the target plays "i" iff j sorts before its cell, or after it inside it
             const T dlast = (D == 3) ? dz : dy;
-            const T drn = (rhon_b - rhon_a) - P.linfac * dlast;
-            const T psigw = T(-2) * drn * fac * r2 * inv_r2e;
             const bool a_is_i = (j < cs_a) || (j > a && j < ce_a);
+            T rhoH = T(0);
+            if (ddt == kDdtLinear) rhoH = P.linfac * dlast;
+            else if (ddt == kDdtComplex) {
+                // as "i" the pair sees ρᴴ(xᵢⱼ[end]); as "j" it sees −ρᴴ(−xᵢⱼ[end]) of the mirrored pair
+                const double z = a_is_i ? (double)dlast : -(double)dlast;
+                const double rh = P.hyd_b * (root7_estimate(1.0 + P.hyd_a * z) - 1.0);
+                rhoH = (T)(a_is_i ? rh : -rh);
+            }
+            const T drn = (rhon_b - rhon_a) - rhoH;
+            const T psigw = T(-2) * drn * fac * r2 * inv_r2e;
             T inv_sel;
             if constexpr (PASS == PASS_CORRECTOR) inv_sel = a_is_i ? fast_rcp(rhon_b) : inv_rhon_a;
             else inv_sel = a_is_i ? inv_rho_b : inv_rho_a;
             const T Dv = P.Kddt * inv_sel * psigw;
-            drho += (fluid_a && s_b > T(0)) ? Dv : T(0);
+            const bool on = ddt == kDdtZeroGravityLinear ? true : (fluid_a && s_b > T(0));
+            drho += on ? Dv : T(0);
         }
         // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
         T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
-        if constexpr (kVisc) {
+        if (visc == kViscArtificial) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
             const T vneg = min_raw(vdx, T(0));
             coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
         }
         coef *= fac;
         ax += coef * dx; ay += coef * dy; az += coef * dz;
+        if (visc == kViscLaminar || visc == kViscLaminarSPS) {
+            // Laminar, :77-87: term·vᵢⱼ with term = 4m₀ν₀(xᵢⱼ·∇W)/((ρᵢ+ρⱼ) + (d²+η²)) — the reference ADDS the
+            // two brackets; ρ from SimParticles.Density
+            const T lam = P.Klam * (fac * r2) / ((rhon_a + rhon_b) + (r2 + P.eta2));
+            ax += lam * dvx; ay += lam * dvy; az += lam * dvz;
+            if (visc == kViscLaminarSPS) {
+                // LaminarSPS, :90-126, with SimParticles.Velocity / .Density of BOTH passes.  Both strain
+                // tensors are multiples of O = (vⱼ−vᵢ)⊗∇W:  Sᵢ = (m₀/ρⱼ)O, Sⱼ = (m₀/ρᵢ)O.
+                T wx, wy, wz;                                   // vⁿ_b − vⁿ_a
+                if constexpr (PASS == PASS_CORRECTOR) {
+                    const V4 nv = gather_packet(rsA1, j, T());
+                    wx = nv.x - vn_a.x; wy = nv.y - vn_a.y; wz = nv.z - vn_a.z;
+                } else { wx = -dvx; wy = -dvy; wz = -dvz; }
+                const T gx = fac * dx, gy = fac * dy, gz = fac * dz;
+                const T gg = gx * gx + gy * gy + gz * gz, ww = wx * wx + wy * wy + wz * wz;
+                const T trO = wx * gx + wy * gy + wz * gz;
+                const T normO = fast_sqrt(T(2) * ww * gg);
+                const T ka = P.m0 * fast_rcp(rhon_b), kb = P.m0 * inv_rhon_a;   // Sᵢ = ka·O, Sⱼ = kb·O
+                // τ = 2·νt·ρ·(S − tr(S)/3·I) − (2/3)·ρ·C_B·dx²·‖S‖²·I,  νt = (Cs·dx)²·‖S‖,  ‖S‖ = k·normO
+                const T na = ka * normO, nb = kb * normO;
+                const T ca = T(2) * (P.sps_cs2 * na) * rhon_a, cb = T(2) * (P.sps_cs2 * nb) * rhon_b;
+                // (τᵢ + τⱼ)·∇W = [ca·ka + cb·kb]·(gg·w − trO/3·g) − sps_blin·(ρᵢ·na² + ρⱼ·nb²)·g
+                const T c1 = ca * ka + cb * kb;
+                const T c2 = c1 * (trO * (T(1) / T(3))) + P.sps_blin * (rhon_a * (na * na) + rhon_b * (nb * nb));
+                const T pre = P.m0 * inv_rhon_a * fast_rcp(rhon_b);
+                ax += pre * (c1 * gg * wx - c2 * gx);
+                ay += pre * (c1 * gg * wy - c2 * gy);
+                az += pre * (c1 * gg * wz - c2 * gz);
+            }
+        }
+        if (shift) {
+            // add_shifting_terms!, src/SPHCellList.jl:73-88 (loop densities; both orientations give these)
+            const T k = P.m0 * inv_rho_a * fac;
+            gcx += k * dx; gcy += k * dy; gcz += k * dz;
+            const T dv = P.m0 * inv_rho_b * (-(fac * r2));
+            divr += (fluid_a && s_b > T(0)) ? dv : T(0);
+        }
     };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
@@ -460,30 +541,21 @@ k_neighbor_force(const ForceParams<T> P) {
     }
     run_pairs(0, true);
     if constexpr (WPT > 1) {
-        __shared__ V4 s_part[(WPT - 1) * kWave];            // partial sums of waves 1 … WPT−1
+        __shared__ V4 s_part[2 * (WPT - 1) * kWave];        // partial sums of waves 1 … WPT−1
         // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
-        if (wv > 0) { V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_part[(wv - 1) * kWave + lane] = o; }
+        if (wv > 0) {
+            V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_part[(wv - 1) * kWave + lane] = o;
+            if (shift) { V4 g; g.x = gcx; g.y = gcy; g.z = gcz; g.w = divr; s_part[(WPT - 1 + wv - 1) * kWave + lane] = g; }
+        }
         __syncthreads();
         if (wv > 0) return;
 #pragma unroll
         for (int k = 0; k < WPT - 1; ++k) {
             const V4 o = s_part[k * kWave + lane];
             ax += o.x; ay += o.y; az += o.z; drho += o.w;
+            if (shift) { const V4 g = s_part[(WPT - 1 + k) * kWave + lane]; gcx += g.x; gcy += g.y; gcz += g.z; divr += g.w; }
         }
     }
-
-#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
-    if (lane == 0 && P.trace) {
-        P.trace[2 * b] = st_t0;
-        P.trace[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-#ifdef SPHMI_STATS
-    if (lane == 0) {
-        atomicAdd(&P.red[8], st_it); atomicAdd(&P.red[9], st_lane); atomicAdd(&P.red[10], st_ref);
-        atomicAdd(&P.red[11], st_emp); atomicAdd(&P.red[12], st_chunks); atomicAdd(&P.red[13], 1ull);
-    }
-#endif
     // ---- epilogue ---------------------------------------------------------------------------
     const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
@@ -515,9 +587,18 @@ k_neighbor_force(const ForceParams<T> P) {
         const T adx = ax * P.dt * ml, ady = ay * P.dt * ml, adz = az * P.dt * ml;
         V4 o0, o1, oa;
         o1.x = s1.x + adx; o1.y = s1.y + ady; o1.z = s1.z + adz;
-        o0.x = s0.x + (((o1.x + (o1.x - adx)) / T(2)) * P.dt) * ml;
-        o0.y = s0.y + (((o1.y + (o1.y - ady)) / T(2)) * P.dt) * ml;
-        o0.z = s0.z + (((o1.z + (o1.z - adz)) / T(2)) * P.dt) * ml;
+        T sx = 0, sy = 0, sz = 0;
+        if (shift) {
+            // FullTimeStep with PlanarShifting, src/SPHCellList.jl:654-677 (A = 2, A_FST = 0, A_FSM = D)
+            const T A_FSC = divr / T(D);
+            if (!(A_FSC < T(0))) {
+                const T k = -A_FSC * T(2) * P.h * fast_sqrt(o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * P.dt;
+                sx = k * gcx; sy = k * gcy; sz = k * gcz;
+            }
+        }
+        o0.x = s0.x + (((o1.x + (o1.x - adx)) / T(2)) * P.dt + sx) * ml;
+        o0.y = s0.y + (((o1.y + (o1.y - ady)) / T(2)) * P.dt + sy) * ml;
+        o0.z = s0.z + (((o1.z + (o1.z - adz)) / T(2)) * P.dt + sz) * ml;
         o0.w = fluid_a ? rho_new : -rho_new;
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;

@@ -34,6 +34,7 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
                       host_float_bytes=host_bytes, device=device)
     eng = (backend_factory or Engine)(cfg)
     eng.upload_particles(SimParticles)
+    eng.set_motions(SimGeometry)                      # MotionDefinition, src/SPHCellList.jl:846-850
     eng.set_clock(SimMetaData.Iteration, SimMetaData.TotalTime)
     time_steps: List[float] = []
     SimMetaData.OutputIterationCounter = 1                                       # :849

@@ -347,5 +347,108 @@ def test_mdbc_examples(case, steps, request):
     assert pe.iteration == po.iteration == steps and pe.n_rebuilds == po.n_rebuilds
     assert pe.total_time == pytest.approx(po.total_time, rel=1e-10)
     e, o = by_id(eng.download()), by_id(orc.download())
-    assert relmax(e["Density"], o["Density"]) < 1e-6
-    assert relmax(e["Position"], o["Position"]) < 1e-6
+    assert relmax(e["Density"], o["Density"]) < 1e-9
+    assert relmax(e["Position"], o["Position"]) < 1e-9
+
+
+@pytest.mark.parametrize("visc,ddt", [("Laminar", "LinearDensityDiffusion"), ("LaminarSPS", "LinearDensityDiffusion"),
+                                      ("ArtificialViscosity", "ZeroGravityLinearDensityDiffusion"),
+                                      ("ArtificialViscosity", "ComplexDensityDiffusion"),
+                                      ("LaminarSPS", "ComplexDensityDiffusion"), ("Laminar", "ZeroDensityDiffusion")])
+@pytest.mark.parametrize("case", ["dam_break_2d", "dam_break_3d_shipped"])
+def test_model_variants(case, visc, ddt, request):
+    """the other viscosity / density-diffusion models (src/SPHViscosityModels.jl:77-126,
+    src/SPHDensityDiffusionModels.jl:56-87,150-188) run through the run-time variant of the neighbour kernel."""
+    import dataclasses
+    import sphexample_amd.config as cfgm
+    p, s = request.getfixturevalue(case)
+    p = perturbed(p, seed=21)
+    nu0 = 1e-3 if "Laminar" in visc else s.SimConstants.nu0        # a viscosity large enough to matter in the comparison
+    consts = cfgm.SimulationConstants(**{k: getattr(s.SimConstants, k) for k in
+                                         ("rho0", "dx", "m0", "alpha", "g", "c0", "gamma", "delta_phi", "CFL")}, nu0=nu0)
+    s = dataclasses.replace(s, SimConstants=consts, SimViscosity=getattr(cfgm, visc)(), SimDensityDiffusion=getattr(cfgm, ddt)())
+    for fb, tol in ((8, 1e-10), (4, 5e-4)):
+        eng, orc = engines(p, s, fb)
+        d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+        i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+        assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol
+    eng, orc = engines(p, s, 8)
+    pe, po = eng.advance(1e9, max_steps=12), orc.advance(1e9, max_steps=12)
+    assert pe.total_time == pytest.approx(po.total_time, rel=1e-11)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-9 and relmax(e["Velocity"], o["Velocity"]) < 1e-8
+
+
+def test_model_variants_change_the_answer(dam_break_2d):
+    """Guard against a variant silently falling back to the default model."""
+    import dataclasses
+    import sphexample_amd.config as cfgm
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d
+    p = perturbed(p, seed=21)
+    base = make_engine(p, s, device_float_bytes=8).forces_once()
+    for kw in (dict(SimViscosity=cfgm.Laminar()), dict(SimViscosity=cfgm.LaminarSPS()),
+               dict(SimDensityDiffusion=cfgm.ZeroGravityLinearDensityDiffusion()),
+               dict(SimDensityDiffusion=cfgm.ComplexDensityDiffusion())):
+        d, a = make_engine(p, dataclasses.replace(s, **kw), device_float_bytes=8).forces_once()
+        assert relmax(d, base[0]) > 1e-8 or relmax(a, base[1]) > 1e-8, kw      # Complex ≈ Linear to first order: 4e-7
+
+
+@pytest.mark.parametrize("fb,tol", [(8, 1e-9), (4, 2e-5)])
+def test_planar_shifting(dam_break_2d, fb, tol):
+    """PlanarShifting (src/SPHCellList.jl:73-88 add_shifting_terms!, :654-677 FullTimeStep) against the oracle."""
+    import dataclasses
+    from sphexample_amd.config import PlanarShifting
+    p, s = dam_break_2d
+    p = perturbed(p, seed=2, vel_scale=0.5)
+    s_sh = dataclasses.replace(s, SimMetaData=dataclasses.replace(s.SimMetaData, SMode=PlanarShifting))
+    eng, orc = engines(p, s_sh, fb)
+    eng.advance(1e9, max_steps=30); orc.advance(1e9, max_steps=30)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Position"], o["Position"]) < tol and relmax(e["Density"], o["Density"]) < tol
+    plain, _ = engines(p, s, fb)
+    plain.advance(1e9, max_steps=30)
+    assert relmax(by_id(plain.download())["Position"], o["Position"]) > 1e-6      # shifting did move particles
+
+
+@pytest.mark.parametrize("fb,tol", [(8, 1e-9), (4, 2e-2)])
+def test_moving_square_example(moving_square, fb, tol):
+    """example/MovingSquare2d.jl at the resolution the reference ships completely: a Moving body driven by
+    ProgressMotion (src/SPHCellList.jl:575-596, called at :765 and :787), LaminarSPS, PlanarShifting."""
+    p, s = moving_square
+    geometries = p.geometries
+    if fb == 4:
+        # The lattice spacing is H/2 and k = √2 cuts the kernel where its gradient is far from zero: thousands of
+        # pairs sit EXACTLY on r = H, and fp32 rounding decides them differently (4e-4 in x after 40 steps).
+        # A 1e-3·dx jitter of the fluid removes the ties; and because every pair that crosses r = H while the
+        # body ploughs on switches a finite force on or off (1 % density differences on single particles after
+        # 10 steps), the fp32 run is a kinematics + coarse-agreement check; parity for this case is the fp64 run.
+        p = perturbed(p, seed=1, vel_scale=0.0, rho_scale=0.0, pos_scale=4e-5)
+    steps = 40 if fb == 8 else 10
+    eng, orc = engines(p, s, fb)
+    eng.set_motions(geometries); orc.set_motions(geometries)
+    pe, po = eng.advance(1e9, max_steps=steps), orc.advance(1e9, max_steps=steps)
+    assert pe.n_rebuilds == po.n_rebuilds and pe.total_time == pytest.approx(po.total_time, rel=1e-9 if fb == 8 else 1e-5)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    sq = o["Type"] == 3
+    x0 = p.Position[np.argsort(p.ID)][sq]
+    # fp32 handles accumulate the 80 half-step displacements at x ≈ 1.5 (6e-8 relative each)
+    np.testing.assert_allclose(e["Position"][sq] - x0, [[2.8 * pe.total_time, 0.0]] * sq.sum(), atol=1e-11 if fb == 8 else 1e-5)
+    np.testing.assert_allclose(e["Velocity"][sq], [[2.8, 0.0]] * sq.sum(), rtol=1e-6)
+    assert relmax(e["Position"], o["Position"]) < tol and relmax(e["Density"], o["Density"]) < tol
+
+
+@pytest.mark.parametrize("k", [1.5, 2.0, 2.5])
+@pytest.mark.parametrize("fb,tol", [(8, 1e-10), (4, 5e-4)])
+def test_cutoff_other_than_2h(dam_break_2d, k, fb, tol):
+    """H = k·h (src/SPHKernels.jl:57-60): with k < 2 the r² ≤ H² cut of src/SPHCellList.jl:275 removes pairs
+    whose kernel gradient has not vanished yet (example/DucklingMDBC.jl uses 1.5, MovingSquare2d.jl √2)."""
+    import dataclasses
+    from sphexample_amd import SPHKernelInstance, WendlandC2
+    p, s = dam_break_2d
+    p = perturbed(p, seed=13)
+    s = dataclasses.replace(s, SimKernel=SPHKernelInstance(2, WendlandC2(), dx=0.02, k=k))
+    eng, orc = engines(p, s, fb)
+    d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+    i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol

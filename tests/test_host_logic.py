@@ -50,8 +50,18 @@ def test_next_output_time():
 
 def test_unsupported_model_raises(dam_break_2d):
     p, s = dam_break_2d
+    import dataclasses
+    from sphexample_amd.config import StoreKernelOutput, SPHViscosity
+
+    class UserViscosity(SPHViscosity):       # a user-defined compute_viscosity method has no engine counterpart
+        pass
     with pytest.raises(NotImplementedError):
-        make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, Laminar(), s.SimDensityDiffusion)
+        make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, UserViscosity(), s.SimDensityDiffusion)
+    with pytest.raises(NotImplementedError):
+        make_config(len(p), s.SimConstants, s.SimKernel, dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput),
+                    s.SimViscosity, s.SimDensityDiffusion)
+    c = make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, Laminar(), s.SimDensityDiffusion)
+    assert c.viscosity == 2 and c.shifting == 0 and c.blin_constant == 0.0066 and c.smagorinsky_constant == 0.12
 
 
 def test_csv_loader_matches_reference_rules(dam_break_2d, still_wedge):
