@@ -213,3 +213,125 @@ def test_mdbc_reproduces_linear_density_field_3d(duckling):
     # the rest take the Shepard fallback — nothing in between
     assert 0.4 < (err < 1e-6).mean() < 0.6 and ((err < 1e-6) | (err > 1e-4)).all()
     assert np.array_equal(st["Density"][~bnd], expect[~bnd])
+
+
+def _pair_terms(p, s, i, j):
+    """The pair (i plays "i") evaluated straight from the reference's formulas in numpy — shares no code with the
+    oracle: returns a dict of closures over the model tags."""
+    c, k = s.SimConstants, s.SimKernel
+    xij = p.Position[i] - p.Position[j]
+    vij = p.Velocity[i] - p.Velocity[j]
+    r2 = xij @ xij
+    q = min(np.sqrt(r2) * k.h_inv, 2.0)
+    gW = k.alphaD * 5 * (q - 2) ** 3 / (8 * k.h ** 2) * xij
+    ri, rj = p.Density[i], p.Density[j]
+    P = lambda r: c.Cb * ((r / c.rho0) ** 7 - 1)                                          # noqa: E731
+    return dict(c=c, k=k, xij=xij, vij=vij, r2=r2, gW=gW, ri=ri, rj=rj,
+                cont_i=-ri * (c.m0 / rj) * (-vij @ gW), cont_j=-rj * (c.m0 / ri) * (-vij @ gW),
+                press=-c.m0 * (P(ri) + P(rj)) / (ri * rj) * gW)
+
+
+def _seventh_root_estimate(x):
+    """src/SimulationEquations.jl:49-61 in numpy (no @fastmath)."""
+    t = np.copysign(np.array([0x36cd000000000000 + np.abs(np.float64(x)).view(np.uint64) // 7], dtype=np.uint64).view(np.float64)[0], x)
+    for _ in range(2):
+        t2 = t * t; t3 = t2 * t; t4 = t2 * t2; xot4 = x / t4
+        t = t - t * (t3 - xot4) / (4 * t3 + 3 * xot4)
+    return t
+
+
+@pytest.mark.parametrize("ddt", ["ZeroGravityLinearDensityDiffusion", "ComplexDensityDiffusion"])
+def test_two_particle_density_diffusion_variants(ddt):
+    """src/SPHDensityDiffusionModels.jl:56-87 (no hydrostatic part, no MLcond) and :150-188 (inverse hydrostatic
+    EOS through Estimate7thRoot)."""
+    import dataclasses
+    import sphexample_amd.config as cfgm
+    s = dataclasses.replace(default_2d_setup(), SimDensityDiffusion=getattr(cfgm, ddt)())
+    p = two_particle_state()
+    o = make_oracle(p, s)
+    drho, _ = o.forces_once()
+    st = o.download(("ID",))
+    i, j = int(np.where(st["ID"] == 1)[0][0]), int(np.where(st["ID"] == 2)[0][0])     # sorted slots; particle 1 plays "i"
+    t = _pair_terms(p, s, 0, 1)
+    c, k = t["c"], t["k"]
+    rhoH = 0.0
+    if ddt == "ComplexDensityDiffusion":
+        PH = c.rho0 * (-c.g) * -t["xij"][-1]
+        rhoH = c.rho0 * (_seventh_root_estimate(1 + PH / c.Cb) - 1)
+        assert rhoH == pytest.approx(PH * c.rho0 / (c.Cb * c.gamma), rel=1e-3)        # ≈ the linear model
+    psi = 2 * ((t["rj"] - t["ri"]) - rhoH) * (-t["xij"]) / (t["r2"] + k.eta2)
+    D_i = c.delta_phi * k.h * c.c0 * (c.m0 / t["rj"]) * (psi @ t["gW"])
+    assert drho[i] == pytest.approx(t["cont_i"] + D_i, rel=1e-11)
+    assert drho[j] == pytest.approx(t["cont_j"] - D_i, rel=1e-11)
+
+
+@pytest.mark.parametrize("visc", ["Laminar", "LaminarSPS"])
+def test_two_particle_laminar_viscosity(visc):
+    """src/SPHViscosityModels.jl:77-87 (note the ADDED brackets in the denominator) and :90-126."""
+    import dataclasses
+    import sphexample_amd.config as cfgm
+    base = default_2d_setup()
+    consts = SimulationConstants(nu0=2.5e-3)
+    s = dataclasses.replace(base, SimConstants=consts, SimViscosity=getattr(cfgm, visc)())
+    p = two_particle_state()
+    o = make_oracle(p, s)
+    _, acc = o.forces_once()
+    st = o.download(("ID",))
+    i, j = int(np.where(st["ID"] == 1)[0][0]), int(np.where(st["ID"] == 2)[0][0])
+    t = _pair_terms(p, s, 0, 1)
+    c, k, gW, xij, vij, ri, rj = t["c"], t["k"], t["gW"], t["xij"], t["vij"], t["ri"], t["rj"]
+    term = (4 * c.m0 * c.nu0 * (xij @ gW)) / ((ri + rj) + (t["r2"] + k.eta2))
+    um = t["press"] + term * vij
+    if visc == "LaminarSPS":
+        vi, vj = p.Velocity[0], p.Velocity[1]
+        I = np.eye(2)
+        Si = (c.m0 / rj) * np.outer(vj - vi, gW)
+        Sj = (c.m0 / ri) * np.outer(vi - vj, -gW)
+        def tau(S, rho):
+            n = np.sqrt(2 * (S ** 2).sum())
+            nut = (c.SmagorinskyConstant * c.dx) ** 2 * n
+            return 2 * nut * rho * (S - (1 / 3) * np.trace(S) * I) - (2 / 3) * rho * c.BlinConstant * c.dx ** 2 * n ** 2 * I
+        um = um + (c.m0 / (rj * ri)) * (tau(Si, ri) + tau(Sj, rj)) @ gW
+    assert acc[i] == pytest.approx(um, rel=1e-11)
+    assert acc[j] == pytest.approx(-um, rel=1e-11)
+
+
+def test_planar_shifting_closed_form():
+    """add_shifting_terms! (src/SPHCellList.jl:73-88) and the shifted FullTimeStep (:654-677) on two particles:
+    one step of the oracle against the formulas evaluated with the half-step state."""
+    import dataclasses
+    from sphexample_amd.config import PlanarShifting
+    base = default_2d_setup()
+    s = dataclasses.replace(base, SimMetaData=dataclasses.replace(base.SimMetaData, SMode=PlanarShifting))
+    p = two_particle_state()
+    o, ref = make_oracle(p, s), make_oracle(p, base)
+    o.advance(1e9, max_steps=1); ref.advance(1e9, max_steps=1)
+    a, b = o.download(), ref.download()
+    # the shift is the only difference between the two runs: δx = −(∇◌r/D)·2·h·|v|·dt·∇C when ∇◌r ≥ 0
+    assert np.array_equal(a["Velocity"], b["Velocity"]) and np.array_equal(a["Density"], b["Density"])
+    shift = a["Position"] - b["Position"]
+    assert np.abs(shift).max() > 0
+    # ∇C of the two particles is antiparallel (m₀/ρ·(±∇W)): so are the shifts, scaled by |v|/ρ⁺
+    assert shift[0, 0] * shift[1, 1] - shift[0, 1] * shift[1, 0] == pytest.approx(0.0, abs=1e-18) and shift[0] @ shift[1] < 0
+
+
+def test_progress_motion():
+    """src/SPHCellList.jl:575-596: a Moving particle with a MotionDetails entry gets the prescribed velocity and two
+    half-step displacements per step while StartTime <= TotalTime <= StartTime + Duration, then stops."""
+    from sphexample_amd import MotionDetails, Geometry, Moving
+    s = default_2d_setup()
+    p = particles_from_arrays(2, [[0.0, 0.0], [1.0, 0.0]], [1000.0, 1000.0], [3, 1], [7, 2], [1, 2])
+    o = make_oracle(p, s)
+    o.set_motions([Geometry(CSVFile="", GroupMarker=7, Type=Moving, Motion=MotionDetails(0.5, 0.0, 1.0e-4, (0.6, 0.8)))])
+    pr = o.advance(1e9, max_steps=2)
+    st = o.download()
+    i = int(np.where(st["ID"] == 1)[0][0])
+    np.testing.assert_allclose(st["Velocity"][i], [0.3, 0.4], rtol=1e-15)
+    np.testing.assert_allclose(st["Position"][i], np.array([0.3, 0.4]) * pr.total_time, rtol=1e-12)
+    t_stop = pr.total_time
+    pr = o.advance(1e9, max_steps=3)                      # TotalTime is now past StartTime + Duration
+    st = o.download()
+    i = int(np.where(st["ID"] == 1)[0][0])
+    assert t_stop > 1.0e-4 > t_stop / 2         # step 1 started at 0, step 2 at ≈0.9e-4: both inside the window
+    np.testing.assert_allclose(st["Velocity"][i], [0.0, 0.0])
+    np.testing.assert_allclose(st["Position"][i], np.array([0.3, 0.4]) * t_stop, rtol=1e-12)
