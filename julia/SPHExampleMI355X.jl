@@ -26,11 +26,12 @@ const LIB = get(ENV, "SPHMI_LIB", "libsphmi.so")
 struct SphmiConfig
     struct_size::Int32; abi_version::Int32; dims::Int32; host_float_bytes::Int32; device_float_bytes::Int32
     kernel::Int32; viscosity::Int32; density_diffusion::Int32; mdbc::Int32; device::Int32
-    reserved0::Int32; reserved1::Int32
+    shifting::Int32; reserved1::Int32
     n_particles::Int64; max_cells::Int64
     rho0::Float64; dx::Float64; m0::Float64; alpha::Float64; g::Float64; c0::Float64; gamma::Float64
     delta_phi::Float64; CFL::Float64; Cb::Float64; nu0::Float64
     k::Float64; h::Float64; h_inv::Float64; H::Float64; H_inv::Float64; H2::Float64; alphaD::Float64; eta2::Float64
+    blin_constant::Float64; smagorinsky_constant::Float64
 end
 
 mutable struct SphmiProgress
@@ -42,9 +43,13 @@ end
 # model tags the engine implements; anything else falls back to the stock CPU path
 visc_tag(::ZeroViscosity) = Int32(0)
 visc_tag(::ArtificialViscosity) = Int32(1)
-visc_tag(::SPHViscosity) = nothing
+visc_tag(::Laminar) = Int32(2)
+visc_tag(::LaminarSPS) = Int32(3)
+visc_tag(::SPHViscosity) = nothing                      # user-defined compute_viscosity methods
+ddt_tag(::ZeroGravityLinearDensityDiffusion) = Int32(1)
 ddt_tag(::LinearDensityDiffusion) = Int32(2)
-ddt_tag(::SPHDensityDiffusion) = nothing
+ddt_tag(::ComplexDensityDiffusion) = Int32(3)
+ddt_tag(::SPHDensityDiffusion) = nothing               # ZeroDensityDiffusion cannot run in the reference either
 
 function check(h::Ptr{Cvoid}, rc::Cint)
     rc == 0 && return
@@ -56,7 +61,7 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
                              SimLogger, SimParticles::StructArray, SimViscosity, SimDensityDiffusion,
                              ParticleNormalsPath = nothing, DeviceFloatBytes::Int = 4, Device::Int = 0) where {D,T,S,K,B,L}
     vt, dt_ = visc_tag(SimViscosity), ddt_tag(SimDensityDiffusion)
-    if vt === nothing || dt_ === nothing || !(S <: NoShifting) || !(K <: NoKernelOutput) || !(SimKernel.kernel isa WendlandC2)
+    if vt === nothing || dt_ === nothing || !(K <: NoKernelOutput) || !(SimKernel.kernel isa WendlandC2)
         @warn "model combination not implemented by libsphmi — running the reference CPU path"
         return RunSimulation(; SimGeometry, SimMetaData, SimConstants, SimKernel, SimLogger, SimParticles,
                              SimViscosity, SimDensityDiffusion, ParticleNormalsPath)
@@ -65,11 +70,12 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
     SPHExample.SPHCellList.LoadMDBCNormals!(SimMetaData, SimParticles, ParticleNormalsPath)
 
     N = length(SimParticles)
-    cfg = SphmiConfig(sizeof(SphmiConfig), 1, D, sizeof(T), DeviceFloatBytes, 0, vt, dt_, B <: SimpleMDBC ? 1 : 0,
-                      Device, 0, 0, N, 0,
+    cfg = SphmiConfig(sizeof(SphmiConfig), 2, D, sizeof(T), DeviceFloatBytes, 0, vt, dt_, B <: SimpleMDBC ? 1 : 0,
+                      Device, S <: PlanarShifting ? 1 : 0, 0, N, 0,
                       SimConstants.ρ₀, SimConstants.dx, SimConstants.m₀, SimConstants.α, SimConstants.g, SimConstants.c₀,
                       SimConstants.γ, SimConstants.δᵩ, SimConstants.CFL, SimConstants.Cb, SimConstants.ν₀,
-                      SimKernel.k, SimKernel.h, SimKernel.h⁻¹, SimKernel.H, SimKernel.H⁻¹, SimKernel.H², SimKernel.αD, SimKernel.η²)
+                      SimKernel.k, SimKernel.h, SimKernel.h⁻¹, SimKernel.H, SimKernel.H⁻¹, SimKernel.H², SimKernel.αD, SimKernel.η²,
+                      SimConstants.BlinConstant, SimConstants.SmagorinskyConstant)
     href = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:sphmi_create, LIB), Cint, (Ref{SphmiConfig}, Ref{Ptr{Cvoid}}), cfg, href)
     rc == 0 || error("sphmi_create: " * unsafe_string(ccall((:sphmi_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -85,6 +91,13 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
                            B <: SimpleMDBC ? pointer(P.GhostPoints) : C_NULL))
         end
         check(h, ccall((:sphmi_set_clock, LIB), Cint, (Ptr{Cvoid}, Int64, Float64), h, SimMetaData.Iteration, SimMetaData.TotalTime))
+        for geo in SimGeometry                                                     # MotionDefinition, :846-850
+            geo.Motion === nothing && continue
+            dir = Float64[geo.Motion.Direction...]
+            GC.@preserve dir check(h, ccall((:sphmi_set_motion, LIB), Cint, (Ptr{Cvoid}, UInt64, Float64, Float64, Float64, Ptr{Float64}),
+                                            h, UInt64(geo.GroupMarker), Float64(geo.Motion.Velocity), Float64(geo.Motion.StartTime),
+                                            Float64(geo.Motion.Duration), pointer(dir)))
+        end
 
         output = SetupVTKOutput(SimMetaData, SimParticles, SimKernel, D)          # :846
         SimMetaData.OutputIterationCounter = 1                                     # :849
