@@ -815,9 +815,10 @@ struct sphmi_handle { sphmi::EngineBase* e; };
 
 extern "C" {
 
+static_assert(SPHMI_ABI_VERSION == 2, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
-    return "sphmi abi 1 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
-           "counting-sort cell list, mDBC | no CPU fallback";
+    return "sphmi abi 2 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+           "counting-sort cell list, mDBC, moving bodies, shifting | no CPU fallback";
 }
 
 const char* sphmi_last_error(const sphmi_handle* h) {
