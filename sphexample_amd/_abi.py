@@ -192,7 +192,23 @@ class Backend:
         return {k: v for k, v in out.items() if v is not None}
 
     def download_into(self, p) -> None:
-        """Write the engine state back into a SimParticles (what the reference's in-place loop leaves)."""
+        """Write the engine state back into the arrays of a SimParticles IN PLACE (what the reference's loop leaves in
+        its StructArray).  The same host arrays are used at every output, so the engine page-locks them the second
+        time it sees them and the copies run at PCIe speed."""
+        order = ("Position", "Velocity", "Acceleration", "Density", "Pressure", "ID", "Type", "GroupMarker",
+                 "GhostPoints", "Cells")
+        want = {"Position": self._ft, "Velocity": self._ft, "Acceleration": self._ft, "Density": self._ft,
+                "Pressure": self._ft, "ID": np.int64, "Type": np.uint8, "GroupMarker": np.uint64,
+                "GhostPoints": self._ft, "Cells": np.int64}
+        args = []
+        for k in order:
+            a = getattr(p, k, None)
+            if not (isinstance(a, np.ndarray) and a.dtype == want[k] and a.flags.c_contiguous and len(a) == self.N):
+                a = None                       # field absent or in another layout: fall back to the copying path below
+            args.append(a)
+        if all(a is not None for a in args):
+            self._check(self._fn("download")(self._h, *[_ptr(a) for a in args]))
+            return
         for k, v in self.download().items():
             setattr(p, k, v)
 

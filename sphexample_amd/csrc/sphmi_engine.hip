@@ -167,6 +167,8 @@ struct Engine final : EngineBase {
             (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]);
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
         }
+        for (auto& e : host_pinned) (void)hipHostUnregister(e.first);
+        (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
@@ -537,61 +539,64 @@ struct Engine final : EngineBase {
         }
     }
 
+    // ---- output side: device-packed fields, one copy per field ----------------------------------
+    char* out_arena = nullptr; size_t out_arena_bytes = 0;
+    std::vector<std::pair<void*, size_t>> host_seen, host_pinned;
+    // A host array handed in for the second time is page-locked (the StructArray of the caller lives for the
+    // whole run; temporaries are not worth the registration), so its copies run at PCIe speed.
+    void maybe_pin(void* p, size_t bytes) {
+        for (auto& e : host_pinned) if (e.first == p && e.second >= bytes) return;
+        for (auto& e : host_seen) if (e.first == p && e.second == bytes) {
+            if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) host_pinned.emplace_back(p, bytes);
+            else (void)hipGetLastError();
+            return;
+        }
+        if (host_seen.size() > 64) host_seen.clear();
+        host_seen.emplace_back(p, bytes);
+    }
+    template <class H>
+    void download_as(void* position, void* velocity, void* acceleration, void* density, void* pressure,
+                     int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) {
+        const size_t n = (size_t)N, nd = n * (size_t)D;
+        const size_t need = (4 * nd + 2 * n) * sizeof(H) + nd * 8 + 256 * 8;
+        if (need > out_arena_bytes) {
+            (void)hipFree(out_arena);
+            out_arena = nullptr; out_arena_bytes = 0;
+            HC(hipMalloc(&out_arena, need));
+            out_arena_bytes = need;
+        }
+        char* cursor = out_arena;
+        auto take = [&](bool wanted, size_t bytes) -> char* {
+            if (!wanted) return nullptr;
+            char* r = cursor; cursor += (bytes + 255) & ~size_t(255); return r;
+        };
+        OutFields<H> o{};
+        o.pos = (H*)take(position, nd * sizeof(H)); o.vel = (H*)take(velocity, nd * sizeof(H));
+        o.acc = (H*)take(acceleration, nd * sizeof(H)); o.rho = (H*)take(density, n * sizeof(H));
+        o.press = (H*)take(pressure, n * sizeof(H)); o.ghost = (H*)take(ghost_points, nd * sizeof(H));
+        o.cells = (long long*)take(cells, nd * 8);
+        hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
+                           stepped ? pk0[iH] : (const V4*)nullptr, acc[cur], ghost[cur], key[cur], N, D, grid, have_grid ? 1 : 0,
+                           (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
+        HC(hipGetLastError());
+        auto copy = [&](void* dst, const void* src, size_t bytes) {
+            if (!dst) return;
+            maybe_pin(dst, bytes);
+            HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        };
+        copy(position, o.pos, nd * sizeof(H)); copy(velocity, o.vel, nd * sizeof(H));
+        copy(acceleration, o.acc, nd * sizeof(H)); copy(density, o.rho, n * sizeof(H));
+        copy(pressure, o.press, n * sizeof(H)); copy(ghost_points, o.ghost, nd * sizeof(H));
+        copy(cells, o.cells, nd * 8);
+        copy(ids, id[cur], n * 8); copy(ty, type[cur], n); copy(groups, grp[cur], n * 8);
+        HC(hipStreamSynchronize(stream));
+    }
     void download(void* position, void* velocity, void* acceleration, void* density, void* pressure,
                   int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
         if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
         HC(hipSetDevice(cfg.device));
-        HC(hipStreamSynchronize(stream));
-        const size_t n = (size_t)N;
-        std::vector<V4> h0(N), h1(N), tmp(N);
-        HC(hipMemcpy(h0.data(), pk0[iA], n * sizeof(V4), hipMemcpyDeviceToHost));
-        HC(hipMemcpy(h1.data(), pk1[iA], n * sizeof(V4), hipMemcpyDeviceToHost));
-        const bool h8 = cfg.host_float_bytes == 8;
-        if (position) { if (h8) unpack3(h0, (double*)position, N, D); else unpack3(h0, (float*)position, N, D); }
-        if (velocity) { if (h8) unpack3(h1, (double*)velocity, N, D); else unpack3(h1, (float*)velocity, N, D); }
-        if (density) for (int i = 0; i < N; ++i) { double r = std::fabs((double)h0[i].w); if (h8) ((double*)density)[i] = r; else ((float*)density)[i] = (float)r; }
-        if (pressure) {
-            // SimParticles.Pressure holds Pressure!(ρₙ⁺) of the last step (src/SPHCellList.jl:789); before
-            // any step it is the initial Pressure!(ρ) of :835.
-            if (stepped) {
-                HC(hipMemcpy(tmp.data(), pk0[iH], n * sizeof(V4), hipMemcpyDeviceToHost));
-                const T rho0 = (T)cfg.rho0, inv0 = (T)(1.0 / cfg.rho0), Cbe = (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0);
-                for (int i = 0; i < N; ++i) {
-                    T rr = sizeof(T) == 8 ? tmp[i].w / rho0 : tmp[i].w * inv0;
-                    T r2 = rr * rr, r4 = r2 * r2;
-                    double p = (double)(Cbe * (r4 * r2 * rr - T(1)));
-                    if (h8) ((double*)pressure)[i] = p; else ((float*)pressure)[i] = (float)p;
-                }
-            } else {
-                for (int i = 0; i < N; ++i) { if (h8) ((double*)pressure)[i] = (double)h1[i].w; else ((float*)pressure)[i] = (float)h1[i].w; }
-            }
-        }
-        if (acceleration) {
-            HC(hipMemcpy(tmp.data(), acc[cur], n * sizeof(V4), hipMemcpyDeviceToHost));
-            if (h8) unpack3(tmp, (double*)acceleration, N, D); else unpack3(tmp, (float*)acceleration, N, D);
-        }
-        if (ghost_points) {
-            HC(hipMemcpy(tmp.data(), ghost[cur], n * sizeof(V4), hipMemcpyDeviceToHost));
-            if (h8) unpack3(tmp, (double*)ghost_points, N, D); else unpack3(tmp, (float*)ghost_points, N, D);
-        }
-        if (ids) HC(hipMemcpy(ids, id[cur], n * 8, hipMemcpyDeviceToHost));
-        if (ty) HC(hipMemcpy(ty, type[cur], n, hipMemcpyDeviceToHost));
-        if (groups) HC(hipMemcpy(groups, grp[cur], n * 8, hipMemcpyDeviceToHost));
-        if (cells) {
-            if (!have_grid) { memset(cells, 0, n * D * 8); }
-            else {
-                std::vector<int> k(N);
-                HC(hipMemcpy(k.data(), key[cur], n * 4, hipMemcpyDeviceToHost));
-                for (int i = 0; i < N; ++i) {
-                    int kk = k[i];
-                    int cx = kk % grid.np[0]; kk /= grid.np[0];
-                    int cy = kk % grid.np[1]; int cz = kk / grid.np[1];
-                    cells[(size_t)i * D] = (int64_t)cx - 1 + grid.gmin[0];
-                    cells[(size_t)i * D + 1] = (int64_t)cy - 1 + grid.gmin[1];
-                    if (D == 3) cells[(size_t)i * D + 2] = (int64_t)cz - 1 + grid.gmin[2];
-                }
-            }
-        }
+        if (cfg.host_float_bytes == 8) download_as<double>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+        else download_as<float>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
     }
 
     void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {

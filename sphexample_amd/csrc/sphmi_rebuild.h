@@ -500,6 +500,53 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
     }
 }
 
+// Output side: the SimParticles fields in the HOST's layout and float type, packed on the device
+// so that sphmi_download is one kernel + one copy per field (the host loops of the first version cost more than
+// the 25 steps between two outputs of the 1 M-particle case).
+template <class H> struct OutFields {
+    H *pos, *vel, *acc, *rho, *press, *ghost;      // N×D, N×D, N×D, N, N, N×D  (null = not requested)
+    long long* cells;                              // N×D
+};
+template <class T, class H>
+__global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+                                                     const typename Vec4<T>::type* half0, const typename Vec4<T>::type* accv,
+                                                     const typename Vec4<T>::type* ghostv, const int* key, int N, int D,
+                                                     GridDesc g, int have_grid, T rho0, T inv_rho0, T Cbe, OutFields<H> o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t b = (size_t)i * D;
+    if (o.pos || o.rho) {
+        const auto q = pk0[i];
+        if (o.pos) { o.pos[b] = (H)q.x; o.pos[b + 1] = (H)q.y; if (D == 3) o.pos[b + 2] = (H)q.z; }
+        if (o.rho) o.rho[i] = (H)(q.w < T(0) ? -q.w : q.w);
+    }
+    if (o.vel || (o.press && !half0)) {
+        const auto q = pk1[i];
+        if (o.vel) { o.vel[b] = (H)q.x; o.vel[b + 1] = (H)q.y; if (D == 3) o.vel[b + 2] = (H)q.z; }
+        if (o.press && !half0) o.press[i] = (H)q.w;                 // before any step: Pressure!(ρ) of :835
+    }
+    if (o.press && half0) {
+        // SimParticles.Pressure holds Pressure!(ρₙ⁺) of the last step (src/SPHCellList.jl:789)
+        const T w = half0[i].w;
+        const T rr = sizeof(T) == 8 ? w / rho0 : w * inv_rho0;
+        const T r2 = rr * rr, r4 = r2 * r2;
+        o.press[i] = (H)(Cbe * (r4 * r2 * rr - T(1)));
+    }
+    if (o.acc) { const auto q = accv[i]; o.acc[b] = (H)q.x; o.acc[b + 1] = (H)q.y; if (D == 3) o.acc[b + 2] = (H)q.z; }
+    if (o.ghost) { const auto q = ghostv[i]; o.ghost[b] = (H)q.x; o.ghost[b + 1] = (H)q.y; if (D == 3) o.ghost[b + 2] = (H)q.z; }
+    if (o.cells) {
+        if (!have_grid) { o.cells[b] = 0; o.cells[b + 1] = 0; if (D == 3) o.cells[b + 2] = 0; }
+        else {
+            int kk = key[i];
+            const int cx = kk % g.np[0]; kk /= g.np[0];
+            const int cy = kk % g.np[1], cz = kk / g.np[1];
+            o.cells[b] = (long long)cx - 1 + g.gmin[0];
+            o.cells[b + 1] = (long long)cy - 1 + g.gmin[1];
+            if (D == 3) o.cells[b + 2] = (long long)cz - 1 + g.gmin[2];
+        }
+    }
+}
+
 // ProgressMotion, src/SPHCellList.jl:575-596: particles of Type Moving whose GroupMarker has a MotionDetails get
 // Velocity = v·dir·ShouldMove and Position += Velocity·dt/2 (state set A, in place).
 struct MotionTable {

@@ -452,3 +452,22 @@ def test_cutoff_other_than_2h(dam_break_2d, k, fb, tol):
     d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
     i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
     assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol
+
+
+def test_download_into_is_in_place_and_repeatable(dam_break_2d_mdbc):
+    """The output path of RunSimulation (src/SPHCellList.jl:891-894 reads the StructArray the loop mutated): the engine
+    writes every field straight into the caller's arrays; the second and later calls go through page-locked copies."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d_mdbc
+    eng = make_engine(p, s, device_float_bytes=8)
+    eng.advance(1e9, max_steps=5)
+    q = p.copy()
+    ptrs = {k: getattr(q, k).ctypes.data for k in ("Position", "Velocity", "Density", "Pressure", "ID", "Cells", "GhostPoints")}
+    for _ in range(3):
+        eng.download_into(q)
+        assert all(getattr(q, k).ctypes.data == v for k, v in ptrs.items())
+        d = eng.download()
+        for k, v in d.items():
+            np.testing.assert_array_equal(getattr(q, k), v, err_msg=k)
+        eng.advance(1e9, max_steps=2)
+    assert (q.Density > 900).all() and np.abs(q.GhostPoints).sum() > 0 and (q.Pressure != 0).any()
