@@ -471,3 +471,29 @@ def test_download_into_is_in_place_and_repeatable(dam_break_2d_mdbc):
             np.testing.assert_array_equal(getattr(q, k), v, err_msg=k)
         eng.advance(1e9, max_steps=2)
     assert (q.Density > 900).all() and np.abs(q.GhostPoints).sum() > 0 and (q.Pressure != 0).any()
+
+
+def test_run_simulation_config1_end_to_end(dam_break_2d):
+    """BASELINE config 1/2 through the reference's own driver shape: RunSimulation (src/SPHCellList.jl:808-911 mirror)
+    with the HIP engine against the same driver with the oracle as backend — 0.05 s of the 2-D dam break
+    (≈550 steps, 5 outputs), fp64 kernels."""
+    import copy
+    from oracle.oracle import Oracle
+    from sphexample_amd.simulation import RunSimulation
+    p, s = dam_break_2d
+    runs = {}
+    for name, kw in (("gpu", dict(device_float_bytes=8)), ("cpu", dict(backend_factory=Oracle))):
+        meta = copy.deepcopy(s.SimMetaData)
+        q = p.copy()
+        outs = []
+        steps = RunSimulation(SimGeometry=None, SimMetaData=meta, SimConstants=s.SimConstants, SimKernel=s.SimKernel,
+                              SimLogger=None, SimParticles=q, SimViscosity=s.SimViscosity,
+                              SimDensityDiffusion=s.SimDensityDiffusion,
+                              on_output=lambda m, pp: outs.append((m.OutputIterationCounter, m.TotalTime, m.Iteration)), **kw)
+        runs[name] = (meta, q, outs, steps)
+    (mg, qg, og, sg), (mc, qc, oc, sc) = runs["gpu"], runs["cpu"]
+    assert [c for c, _, _ in og] == [c for c, _, _ in oc] and len(og) >= 6
+    assert [i for _, _, i in og] == [i for _, _, i in oc] and mg.Iteration == mc.Iteration > 500
+    np.testing.assert_allclose([t for _, t, _ in og], [t for _, t, _ in oc], rtol=1e-10)
+    ig, ic = np.argsort(qg.ID), np.argsort(qc.ID)
+    assert relmax(qg.Density[ig], qc.Density[ic]) < 1e-8 and relmax(qg.Position[ig], qc.Position[ic]) < 1e-8
