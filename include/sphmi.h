@@ -47,7 +47,8 @@ enum {
 };
 
 /* model tags; values mirror the reference's dispatch types */
-enum { SPHMI_KERNEL_WENDLAND_C2 = 0 };                      /* src/SPHKernels.jl:13,75-87        */
+enum { SPHMI_KERNEL_WENDLAND_C2 = 0, SPHMI_KERNEL_CUBIC_SPLINE = 1 };   /* src/SPHKernels.jl:13-19,75-126 */
+enum { SPHMI_KOUT_NONE = 0, SPHMI_KOUT_STORE = 1 };         /* KMode: src/SPHCellList.jl:90-116 */
 enum { SPHMI_VISC_ZERO = 0, SPHMI_VISC_ARTIFICIAL = 1, SPHMI_VISC_LAMINAR = 2, SPHMI_VISC_LAMINAR_SPS = 3 };
                                                             /* src/SPHViscosityModels.jl:51-126  */
 enum { SPHMI_DDT_NONE = 0, SPHMI_DDT_ZERO_GRAVITY_LINEAR = 1, SPHMI_DDT_LINEAR = 2, SPHMI_DDT_COMPLEX = 3 };
@@ -75,7 +76,7 @@ typedef struct sphmi_config {
     int32_t mdbc;                /* SPHMI_MDBC_*                                                 */
     int32_t device;              /* HIP device ordinal                                           */
     int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
-    int32_t reserved1;
+    int32_t kernel_output;       /* SPHMI_KOUT_* (KMode of SimulationMetaData)                   */
     int64_t n_particles;         /* length(SimParticles)                                         */
     int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
     /* SimulationConstants */
@@ -84,6 +85,8 @@ typedef struct sphmi_config {
     double k, h, h_inv, H, H_inv, H2, alphaD, eta2;
     /* SimulationConstants, continued (LaminarSPS) */
     double blin_constant, smagorinsky_constant;
+    /* CubicSpline.eps (tensile correction, src/SPHKernels.jl:15-19,114-126) */
+    double cubic_eps;
 } sphmi_config;
 
 /* What the reference's SimulationLoop leaves in SimMetaData (src/SPHCellList.jl:679-685,:759). */
@@ -126,6 +129,12 @@ int sphmi_upload(sphmi_handle* h,
 
 /* Set / read SimMetaData.Iteration and SimMetaData.TotalTime (they live in the host struct). */
 int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
+
+/*
+ * StoreKernelOutput (src/SPHCellList.jl:106-116): Kernel[i] = Σⱼ Wᵢⱼ and KernelGradient[i] = Σⱼ ∇ᵢWᵢⱼ of the last
+ * neighbour pass, host float type, n and n×dims values, current (cell-sorted) order.  Needs kernel_output = STORE.
+ */
+int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient);
 
 /*
  * MotionDetails of the Geometry with this GroupMarker (src/SimulationGeometry.jl:17-22): particles of Type Moving

@@ -26,12 +26,12 @@ const LIB = get(ENV, "SPHMI_LIB", "libsphmi.so")
 struct SphmiConfig
     struct_size::Int32; abi_version::Int32; dims::Int32; host_float_bytes::Int32; device_float_bytes::Int32
     kernel::Int32; viscosity::Int32; density_diffusion::Int32; mdbc::Int32; device::Int32
-    shifting::Int32; reserved1::Int32
+    shifting::Int32; kernel_output::Int32
     n_particles::Int64; max_cells::Int64
     rho0::Float64; dx::Float64; m0::Float64; alpha::Float64; g::Float64; c0::Float64; gamma::Float64
     delta_phi::Float64; CFL::Float64; Cb::Float64; nu0::Float64
     k::Float64; h::Float64; h_inv::Float64; H::Float64; H_inv::Float64; H2::Float64; alphaD::Float64; eta2::Float64
-    blin_constant::Float64; smagorinsky_constant::Float64
+    blin_constant::Float64; smagorinsky_constant::Float64; cubic_eps::Float64
 end
 
 mutable struct SphmiProgress
@@ -61,7 +61,8 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
                              SimLogger, SimParticles::StructArray, SimViscosity, SimDensityDiffusion,
                              ParticleNormalsPath = nothing, DeviceFloatBytes::Int = 4, Device::Int = 0) where {D,T,S,K,B,L}
     vt, dt_ = visc_tag(SimViscosity), ddt_tag(SimDensityDiffusion)
-    if vt === nothing || dt_ === nothing || !(K <: NoKernelOutput) || !(SimKernel.kernel isa WendlandC2)
+    kt = SimKernel.kernel isa WendlandC2 ? Int32(0) : (SimKernel.kernel isa CubicSpline ? Int32(1) : nothing)
+    if vt === nothing || dt_ === nothing || kt === nothing
         @warn "model combination not implemented by libsphmi — running the reference CPU path"
         return RunSimulation(; SimGeometry, SimMetaData, SimConstants, SimKernel, SimLogger, SimParticles,
                              SimViscosity, SimDensityDiffusion, ParticleNormalsPath)
@@ -70,12 +71,13 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
     SPHExample.SPHCellList.LoadMDBCNormals!(SimMetaData, SimParticles, ParticleNormalsPath)
 
     N = length(SimParticles)
-    cfg = SphmiConfig(sizeof(SphmiConfig), 2, D, sizeof(T), DeviceFloatBytes, 0, vt, dt_, B <: SimpleMDBC ? 1 : 0,
-                      Device, S <: PlanarShifting ? 1 : 0, 0, N, 0,
+    cfg = SphmiConfig(sizeof(SphmiConfig), 2, D, sizeof(T), DeviceFloatBytes, kt, vt, dt_, B <: SimpleMDBC ? 1 : 0,
+                      Device, S <: PlanarShifting ? 1 : 0, K <: StoreKernelOutput ? 1 : 0, N, 0,
                       SimConstants.ρ₀, SimConstants.dx, SimConstants.m₀, SimConstants.α, SimConstants.g, SimConstants.c₀,
                       SimConstants.γ, SimConstants.δᵩ, SimConstants.CFL, SimConstants.Cb, SimConstants.ν₀,
                       SimKernel.k, SimKernel.h, SimKernel.h⁻¹, SimKernel.H, SimKernel.H⁻¹, SimKernel.H², SimKernel.αD, SimKernel.η²,
-                      SimConstants.BlinConstant, SimConstants.SmagorinskyConstant)
+                      SimConstants.BlinConstant, SimConstants.SmagorinskyConstant,
+                      SimKernel.kernel isa CubicSpline ? Float64(SimKernel.kernel.eps) : 0.0)
     href = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:sphmi_create, LIB), Cint, (Ref{SphmiConfig}, Ref{Ptr{Cvoid}}), cfg, href)
     rc == 0 || error("sphmi_create: " * unsafe_string(ccall((:sphmi_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -118,6 +120,10 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
                                h, pointer(P.Position), pointer(P.Velocity), pointer(P.Acceleration), pointer(P.Density),
                                pointer(P.Pressure), pointer(P.ID), pointer(typ), pointer(P.GroupMarker),
                                B <: SimpleMDBC ? pointer(P.GhostPoints) : C_NULL, pointer(cells)))
+                if K <: StoreKernelOutput
+                    check(h, ccall((:sphmi_download_kernel_output, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                                   h, pointer(P.Kernel), pointer(P.KernelGradient)))
+                end
             end
             @inbounds for i in 1:N
                 P.Type[i] = ParticleType(typ[i])

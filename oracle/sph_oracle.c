@@ -57,6 +57,8 @@ typedef struct orc_handle {
     double  *bgam, *Agam;
     /* PlanarShifting accumulators ∇Cᵢ (N*D) and ∇◌rᵢ (N) with their per-thread copies (src/PreProcess.jl:198-215) */
     double  *gradC, *divr, **gradC_thr, **divr_thr;
+    /* StoreKernelOutput: Kernel (N), KernelGradient (N*D) and their per-thread copies */
+    double  *kern, *kgrad, **kern_thr, **kgrad_thr;
     /* MotionDetails by GroupMarker (src/SimulationGeometry.jl:17-22) */
     int      n_motion;
     struct { uint64_t group; double vel, start, dur, dir[MAXD]; } motion[16];
@@ -70,14 +72,36 @@ typedef struct orc_handle {
 /* ---------------------------------------------------------------------------------------------
  * SPHKernels.jl:75-78 (Wᵢⱼ) and :80-87 (∇Wᵢⱼ factor), Wendland C2.
  * ------------------------------------------------------------------------------------------- */
-static inline double W_wendland(const sphmi_config *c, double q) {
+static inline double W_kernel(const sphmi_config *c, double q) {
+    if (c->kernel == SPHMI_KERNEL_CUBIC_SPLINE) {                              /* :89-92 */
+        double a = (0.0 <= q && q <= 1.0) ? (1.0 - 1.5 * q * q + 0.75 * q * q * q) : 0.0;
+        double b = (1.0 < q && q <= 2.0) ? 0.25 * (2.0 - q) * (2.0 - q) * (2.0 - q) : 0.0;
+        return c->alphaD * (a + b);
+    }
     double t = 1.0 - q / 2.0;
     double t2 = t * t;
     return c->alphaD * (t2 * t2) * (2.0 * q + 1.0);
 }
-static inline double gradW_factor(const sphmi_config *c, double q) {
+/* ∇Wᵢⱼ = factor(q, |xᵢⱼ|) · xᵢⱼ; the CubicSpline form divides by (|xᵢⱼ| + η²) as the reference does (:94-106) */
+static inline double gradW_factor_r(const sphmi_config *c, double q, double r) {
+    if (c->kernel == SPHMI_KERNEL_CUBIC_SPLINE) {
+        double dWdq;
+        if (0.0 <= q && q <= 1.0) dWdq = c->alphaD * (-3.0 * q + 2.25 * q * q);
+        else if (1.0 < q && q <= 2.0) dWdq = c->alphaD * (-0.75) * (2.0 - q) * (2.0 - q);
+        else dWdq = 0.0;
+        return dWdq * c->h_inv / (r + c->eta2);
+    }
     double t = q - 2.0;
     return c->alphaD * 5.0 * (t * t * t) / (8.0 * c->h * c->h);
+}
+static inline double W_wendland(const sphmi_config *c, double q) { return W_kernel(c, q); }
+static inline double gradW_factor(const sphmi_config *c, double q) { return gradW_factor_r(c, q, q * c->h); }
+/* tensile_correction, :108-126 — note Wᵢⱼ(instance, dx): the reference passes dx where q is expected */
+static inline double tensile_correction(const sphmi_config *c, double Pi, double ri, double Pj, double rj, double q) {
+    if (c->kernel != SPHMI_KERNEL_CUBIC_SPLINE) return 0.0;
+    double w = W_kernel(c, q) / W_kernel(c, c->dx);
+    double w2 = w * w;
+    return c->cubic_eps * ((Pi / (ri * ri)) + (Pj / (rj * rj))) * (w2 * w2);
 }
 
 /* SimulationEquations.jl:9-11  EquationOfStateGamma7 */
@@ -284,7 +308,7 @@ static inline double estimate_7th_root(double x) {
 static inline void compute_interactions(const orc_handle *o, const double *pos, const double *rho,
                                         const double *press, const double *vel,
                                         int64_t i, int64_t j, double *drho_t, double *acc_t,
-                                        double *gradC_t, double *divr_t) {
+                                        double *gradC_t, double *divr_t, double *kern_t, double *kgrad_t) {
     const sphmi_config *c = &o->cfg;
     const int D = o->D;
     double xij[MAXD], r2 = 0.0;
@@ -296,7 +320,7 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
     double dij = sqrt(fabs(r2));
     double q = dij * c->h_inv;
     q = q < 0.0 ? 0.0 : (q > 2.0 ? 2.0 : q);
-    double fac = gradW_factor(c, q);
+    double fac = gradW_factor_r(c, q, dij);
     double gW[MAXD];
     for (int d = 0; d < D; ++d) gW[d] = fac * xij[d];
 
@@ -336,7 +360,8 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
 
     double Pfac = (press[i] + press[j]) / (rho_i * rho_j);
     double um[MAXD];
-    for (int d = 0; d < D; ++d) um[d] = -c->m0 * (Pfac + 0.0) * gW[d];
+    double f_ab = tensile_correction(c, press[i], rho_i, press[j], rho_j, q);
+    for (int d = 0; d < D; ++d) um[d] = -c->m0 * (Pfac + f_ab) * gW[d];
 
     if (c->viscosity == SPHMI_VISC_ARTIFICIAL) {                              /* :56-74 */
         double rn_i = o->rho[i], rn_j = o->rho[j];
@@ -389,6 +414,11 @@ static inline void compute_interactions(const orc_handle *o, const double *pos, 
         acc_t[i * D + d] += um[d];
         acc_t[j * D + d] -= um[d];
     }
+    if (kern_t) {                                                             /* KernelOutput!, :106-116 */
+        double Wij = W_kernel(c, q);
+        kern_t[i] += Wij; kern_t[j] += Wij;
+        for (int d = 0; d < D; ++d) { kgrad_t[i * D + d] += gW[d]; kgrad_t[j * D + d] -= gW[d]; }
+    }
     if (gradC_t) {                                                            /* add_shifting_terms!, :73-88 */
         double mlc = o->ml[i] * o->ml[j];
         double xdg = 0.0;
@@ -430,15 +460,18 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
     int64_t nchunks = (nview + chunk - 1) / chunk;
 
     const int shift = o->cfg.shifting == SPHMI_SHIFT_PLANAR;
+    const int kout = o->cfg.kernel_output == SPHMI_KOUT_STORE;
     /* ResetStep! */
     memset(o->drhodt, 0, sizeof(double) * (size_t)N);
     memset(o->acc, 0, sizeof(double) * (size_t)N * D);
     if (shift) { memset(o->gradC, 0, sizeof(double) * (size_t)N * D); memset(o->divr, 0, sizeof(double) * (size_t)N); }
+    if (kout) { memset(o->kern, 0, sizeof(double) * (size_t)N); memset(o->kgrad, 0, sizeof(double) * (size_t)N * D); }
 #pragma omp parallel for num_threads(T) schedule(static)
     for (int t = 0; t < T; ++t) {
         memset(o->drhodt_thr[t], 0, sizeof(double) * (size_t)N);
         memset(o->acc_thr[t], 0, sizeof(double) * (size_t)N * D);
         if (shift) { memset(o->gradC_thr[t], 0, sizeof(double) * (size_t)N * D); memset(o->divr_thr[t], 0, sizeof(double) * (size_t)N); }
+        if (kout) { memset(o->kern_thr[t], 0, sizeof(double) * (size_t)N); memset(o->kgrad_thr[t], 0, sizeof(double) * (size_t)N * D); }
     }
 
 #pragma omp parallel for num_threads(T) schedule(static, 1)
@@ -448,6 +481,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
         double *drho_t = o->drhodt_thr[copy];
         double *acc_t = o->acc_thr[copy];
         double *gC_t = shift ? o->gradC_thr[copy] : NULL, *dr_t = shift ? o->divr_thr[copy] : NULL;
+        double *kn_t = kout ? o->kern_thr[copy] : NULL, *kg_t = kout ? o->kgrad_thr[copy] : NULL;
         int64_t it0 = ch * chunk + 1, it1 = it0 + chunk - 1;  /* 1-based iter as in the reference */
         if (it1 > nview) it1 = nview;
         for (int64_t iter = it0; iter <= it1; ++iter) {
@@ -455,7 +489,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
             int64_t s0 = o->ranges[iter - 1], e0 = o->ranges[iter] - 1;  /* 1-based inclusive */
             for (int64_t i = s0; i <= e0; ++i)
                 for (int64_t j = i + 1; j <= e0; ++j)
-                    compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t);
+                    compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t, kn_t, kg_t);
             for (int s = 0; s < ns; ++s) {
                 int64_t sc[MAXD];
                 for (int d = 0; d < D; ++d) sc[d] = cell[d] + stencil[s][d];
@@ -463,7 +497,7 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
                 int64_t s1 = o->ranges[nb - 1], e1 = o->ranges[nb] - 1;
                 for (int64_t i = s0; i <= e0; ++i)
                     for (int64_t j = s1; j <= e1; ++j)
-                        compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t);
+                        compute_interactions(o, pos, rho, press, vel, i - 1, j - 1, drho_t, acc_t, gC_t, dr_t, kn_t, kg_t);
             }
         }
     }
@@ -473,6 +507,10 @@ static void neighbor_loop(orc_handle *o, const double *pos, const double *rho, c
         for (int t = 0; t < T; ++t) {
             o->drhodt[i] += o->drhodt_thr[t][i];
             for (int d = 0; d < D; ++d) o->acc[i * D + d] += o->acc_thr[t][i * D + d];
+            if (kout) {
+                o->kern[i] += o->kern_thr[t][i];
+                for (int d = 0; d < D; ++d) o->kgrad[i * D + d] += o->kgrad_thr[t][i * D + d];
+            }
             if (shift) {
                 o->divr[i] += o->divr_thr[t][i];
                 for (int d = 0; d < D; ++d) o->gradC[i * D + d] += o->gradC_thr[t][i * D + d];
@@ -722,6 +760,7 @@ int orc_create(const sphmi_config *cfg, orc_handle **out) {
     o->perm = xcalloc(N, 8); o->perm_tmp = xcalloc(N, 8); o->scratch = xcalloc(N * D, 8);
     o->bgam = xcalloc(N * 4, 8); o->Agam = xcalloc(N * 16, 8);
     o->gradC = xcalloc(N * D, 8); o->divr = xcalloc(N, 8);
+    o->kern = xcalloc(N, 8); o->kgrad = xcalloc(N * D, 8);
     o->nthreads = 0;
     orc_set_threads(o, 1);
     *out = o;
@@ -731,29 +770,34 @@ int orc_create(const sphmi_config *cfg, orc_handle **out) {
 int orc_set_threads(orc_handle *o, int n) {
     if (n < 1) n = 1;
     if (o->drhodt_thr) {
-        for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); }
-        free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr);
+        for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); free(o->kern_thr[t]); free(o->kgrad_thr[t]); }
+        free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr); free(o->kern_thr); free(o->kgrad_thr);
     }
     o->nthreads = n;
     o->drhodt_thr = calloc((size_t)n, sizeof(double *));
     o->acc_thr = calloc((size_t)n, sizeof(double *));
     o->gradC_thr = calloc((size_t)n, sizeof(double *));
     o->divr_thr = calloc((size_t)n, sizeof(double *));
+    o->kern_thr = calloc((size_t)n, sizeof(double *));
+    o->kgrad_thr = calloc((size_t)n, sizeof(double *));
+    const int kout = o->cfg.kernel_output == SPHMI_KOUT_STORE;
     const int shift = o->cfg.shifting == SPHMI_SHIFT_PLANAR;
     for (int t = 0; t < n; ++t) {
         o->drhodt_thr[t] = xcalloc((size_t)o->N, 8);
         o->acc_thr[t] = xcalloc((size_t)o->N * o->D, 8);
         o->gradC_thr[t] = xcalloc(shift ? (size_t)o->N * o->D : 1, 8);
         o->divr_thr[t] = xcalloc(shift ? (size_t)o->N : 1, 8);
+        o->kern_thr[t] = xcalloc(kout ? (size_t)o->N : 1, 8);
+        o->kgrad_thr[t] = xcalloc(kout ? (size_t)o->N * o->D : 1, 8);
     }
     return SPHMI_OK;
 }
 
 int orc_destroy(orc_handle *o) {
     if (!o) return SPHMI_OK;
-    for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); }
-    free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr);
-    free(o->gradC); free(o->divr);
+    for (int t = 0; t < o->nthreads; ++t) { free(o->drhodt_thr[t]); free(o->acc_thr[t]); free(o->gradC_thr[t]); free(o->divr_thr[t]); free(o->kern_thr[t]); free(o->kgrad_thr[t]); }
+    free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr); free(o->kern_thr); free(o->kgrad_thr);
+    free(o->gradC); free(o->divr); free(o->kern); free(o->kgrad);
     free(o->pos); free(o->vel); free(o->acc); free(o->rho); free(o->press); free(o->gf); free(o->ml);
     free(o->ghost); free(o->type); free(o->id); free(o->group); free(o->cells);
     free(o->drhodt); free(o->vel_np); free(o->pos_np); free(o->rho_np);
@@ -788,6 +832,13 @@ int orc_upload(orc_handle *o, const double *position, const double *velocity, co
     pressure(o, o->press, o->rho);         /* src/SPHCellList.jl:835 */
     o->index_counter = 0;
     o->uploaded = 1;
+    return SPHMI_OK;
+}
+
+int orc_download_kernel_output(orc_handle *o, double *kernel, double *kernel_gradient) {
+    if (!o || o->cfg.kernel_output != SPHMI_KOUT_STORE) return SPHMI_ERR_STATE;
+    if (kernel) memcpy(kernel, o->kern, (size_t)o->N * 8);
+    if (kernel_gradient) memcpy(kernel_gradient, o->kgrad, (size_t)o->N * o->D * 8);
     return SPHMI_OK;
 }
 

@@ -3,7 +3,7 @@
 Host-side mirror of the names ``src/SPHExample.jl:19-62`` re-exports for the hot path; the compute
 lives in ``csrc/`` (HIP, gfx950) behind the C ABI of ``include/sphmi.h``.
 """
-from .config import (ArtificialViscosity, ComplexDensityDiffusion, Fixed, Fluid, Geometry,  # noqa: F401
+from .config import (ArtificialViscosity, ComplexDensityDiffusion, CubicSpline, Fixed, Fluid, Geometry,  # noqa: F401
                      KernelOutputMode, Laminar, LaminarSPS, LinearDensityDiffusion, LogMode,
                      MDBCMode, MotionDetails, Moving, NoKernelOutput, NoLog, NoMDBC, NoShifting,
                      ParticleType, PlanarShifting, ShiftingMode, SimpleMDBC, SimulationConstants,

@@ -23,14 +23,14 @@ class SphmiConfig(C.Structure):
         ("struct_size", C.c_int32), ("abi_version", C.c_int32), ("dims", C.c_int32),
         ("host_float_bytes", C.c_int32), ("device_float_bytes", C.c_int32), ("kernel", C.c_int32),
         ("viscosity", C.c_int32), ("density_diffusion", C.c_int32), ("mdbc", C.c_int32),
-        ("device", C.c_int32), ("shifting", C.c_int32), ("reserved1", C.c_int32),
+        ("device", C.c_int32), ("shifting", C.c_int32), ("kernel_output", C.c_int32),
         ("n_particles", C.c_int64), ("max_cells", C.c_int64),
         ("rho0", C.c_double), ("dx", C.c_double), ("m0", C.c_double), ("alpha", C.c_double),
         ("g", C.c_double), ("c0", C.c_double), ("gamma", C.c_double), ("delta_phi", C.c_double),
         ("CFL", C.c_double), ("Cb", C.c_double), ("nu0", C.c_double),
         ("k", C.c_double), ("h", C.c_double), ("h_inv", C.c_double), ("H", C.c_double),
         ("H_inv", C.c_double), ("H2", C.c_double), ("alphaD", C.c_double), ("eta2", C.c_double),
-        ("blin_constant", C.c_double), ("smagorinsky_constant", C.c_double),
+        ("blin_constant", C.c_double), ("smagorinsky_constant", C.c_double), ("cubic_eps", C.c_double),
     ]
 
 
@@ -59,8 +59,8 @@ def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: 
     for tag, what in ((SimViscosity, "viscosity"), (SimDensityDiffusion, "density diffusion")):
         if getattr(tag, "abi_value", None) is None:
             raise NotImplementedError(f"{type(tag).__name__}: {what} model not implemented by the engine")
-    if SimMetaData.KMode.__name__ != "NoKernelOutput":
-        raise NotImplementedError("StoreKernelOutput is not implemented by the engine")
+    if getattr(SimKernel.kernel, "abi_value", None) is None:
+        raise NotImplementedError(f"{type(SimKernel.kernel).__name__}: kernel not implemented by the engine")
     c = SphmiConfig()
     c.struct_size = C.sizeof(SphmiConfig)
     c.abi_version = ABI_VERSION
@@ -72,6 +72,8 @@ def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: 
     c.density_diffusion = SimDensityDiffusion.abi_value
     c.mdbc = 1 if SimMetaData.BMode is SimpleMDBC else 0
     c.shifting = 1 if SimMetaData.SMode.__name__ == "PlanarShifting" else 0
+    c.kernel_output = 1 if SimMetaData.KMode.__name__ == "StoreKernelOutput" else 0
+    c.cubic_eps = float(getattr(SimKernel.kernel, "eps", 0.0))
     c.blin_constant = SimConstants.BlinConstant
     c.smagorinsky_constant = SimConstants.SmagorinskyConstant
     c.device = device
@@ -110,6 +112,7 @@ class Backend:
         f("destroy").argtypes = [C.c_void_p]
         f("upload").argtypes = [C.c_void_p] * 9
         f("set_clock").argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        f("download_kernel_output").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         f("set_motion").argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
         f("advance").argtypes = [C.c_void_p, C.c_double, C.c_int64, C.POINTER(SphmiProgress)]
         f("download").argtypes = [C.c_void_p] * 11
@@ -211,6 +214,13 @@ class Backend:
             return
         for k, v in self.download().items():
             setattr(p, k, v)
+
+    def kernel_output(self):
+        """(Kernel, KernelGradient) of StoreKernelOutput runs, current order."""
+        k = np.empty(self.N, dtype=self._ft)
+        g = np.empty((self.N, self.D), dtype=self._ft)
+        self._check(self._fn("download_kernel_output")(self._h, _ptr(k), _ptr(g)))
+        return k, g
 
     def forces_once(self, apply_mdbc: bool = False):
         drho = np.empty(self.N, dtype=self._ft)

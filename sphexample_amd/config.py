@@ -36,6 +36,13 @@ class WendlandC2(SPHKernel):  # src/SPHKernels.jl:13
     abi_value = 0
 
 
+class CubicSpline(SPHKernel):  # src/SPHKernels.jl:15-19
+    abi_value = 1
+
+    def __init__(self, eps: float = 1.0):
+        self.eps = float(eps)
+
+
 class SPHViscosity:  # src/SPHViscosityModels.jl:13
     abi_value: Optional[int] = None
 
@@ -84,7 +91,7 @@ class NoShifting(ShiftingMode): ...
 class PlanarShifting(ShiftingMode): ...          # src/SPHCellList.jl:73-88,654-677
 class KernelOutputMode: ...
 class NoKernelOutput(KernelOutputMode): ...
-class StoreKernelOutput(KernelOutputMode): ...   # next (f1)
+class StoreKernelOutput(KernelOutputMode): ...   # src/SPHCellList.jl:106-116
 class MDBCMode: ...
 class NoMDBC(MDBCMode): ...
 class SimpleMDBC(MDBCMode): ...
@@ -166,7 +173,14 @@ def _alphaD(kernel_type, dims: int, h: float) -> float:
             return 7 / (4 * math.pi * h ** 2)
         if dims == 3:
             return 21 / (16 * math.pi * h ** 3)
-    raise NotImplementedError("only WendlandC2 in 2-D/3-D is in scope (SURVEY §2 row 2)")
+    if kernel_type is CubicSpline or isinstance(kernel_type, CubicSpline):          # :25-27
+        if dims == 1:
+            return 2 / (3 * h)
+        if dims == 2:
+            return 10 / (7 * math.pi * h ** 2)
+        if dims == 3:
+            return 1 / (math.pi * h ** 3)
+    raise NotImplementedError("kernel / dimension combination without a normalisation constant")
 
 
 class SPHKernelInstance:

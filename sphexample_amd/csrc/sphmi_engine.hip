@@ -51,6 +51,7 @@ struct EngineBase {
     virtual void advance(double t_target, int64_t max_steps, sphmi_progress* out) = 0;
     virtual void download(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
     virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
+    virtual void download_kernel_output(void* kernel, void* kernel_gradient) = 0;
     virtual void unique_cells(int64_t* out, int64_t cap, int64_t* n) = 0;
     virtual void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) = 0;
     virtual void force_stats(int reset, double* avg_ms, int64_t* launches) = 0;
@@ -103,6 +104,7 @@ struct Engine final : EngineBase {
     int *part_d = nullptr, *part_h = nullptr;       // 2 × 16 ints: run starts and run lengths per XCD
     uint8_t* tile_cls = nullptr;
     unsigned long long* trace_d = nullptr;
+    V4* kout_d = nullptr;              // StoreKernelOutput: { Σ∇W, ΣW } per particle
     MotionTable motions{};
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
@@ -150,6 +152,7 @@ struct Engine final : EngineBase {
         const size_t nt = n / kWave + 2;
         for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], nt * 4)); }
         HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt));
+        if (cfg.kernel_output == SPHMI_KOUT_STORE) { HC(hipMalloc(&kout_d, n * sizeof(V4))); HC(hipMemset(kout_d, 0, n * sizeof(V4))); }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
 #endif
@@ -171,6 +174,7 @@ struct Engine final : EngineBase {
         (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
+        (void)hipFree(kout_d);
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -254,6 +258,15 @@ struct Engine final : EngineBase {
         P.Kv2 = (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h);
         P.visc = cfg.viscosity; P.ddt = cfg.density_diffusion; P.shift = cfg.shifting == SPHMI_SHIFT_PLANAR;
         P.exact_cut = !(cfg.H >= 2.0 * cfg.h);
+        P.kernel = cfg.kernel; P.kout = kout_d;
+        P.alphaD = (T)cfg.alphaD; P.tens_eps = (T)cfg.cubic_eps;
+        {   // Wᵢⱼ(instance, dx) of tensile_correction: the reference passes dx where q is expected
+            const double q = cfg.dx;
+            const double w = cfg.kernel == SPHMI_KERNEL_CUBIC_SPLINE
+                ? cfg.alphaD * ((q <= 1.0 ? 1.0 - 1.5 * q * q + 0.75 * q * q * q : 0.0) + (q > 1.0 && q <= 2.0 ? 0.25 * (2 - q) * (2 - q) * (2 - q) : 0.0))
+                : 1.0;
+            P.inv_Wdx = (T)(1.0 / w);
+        }
         P.Klam = (T)(4.0 * cfg.m0 * cfg.nu0);
         P.sps_cs2 = (T)((cfg.smagorinsky_constant * cfg.dx) * (cfg.smagorinsky_constant * cfg.dx));
         P.sps_blin = (T)((2.0 / 3.0) * cfg.blin_constant * cfg.dx * cfg.dx);
@@ -284,7 +297,8 @@ struct Engine final : EngineBase {
     template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {
         // the compiled-in variant: the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
         const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
-                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h;
+                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h &&
+                          cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE;
         if (dflt) launch_force_model<PASS, kModelDefault>(P, list);
         else      launch_force_model<PASS, kModelGeneric>(P, list);
     }
@@ -407,7 +421,7 @@ struct Engine final : EngineBase {
         MdbcParams<T> M{};
         M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
-        M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0;
+        M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
         dim3 g((N + 63) / 64), b(64);
         if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
         else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
@@ -599,6 +613,16 @@ struct Engine final : EngineBase {
         else download_as<float>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
     }
 
+    void download_kernel_output(void* kernel, void* kernel_gradient) override {
+        if (!kout_d) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_kernel_output: the handle was not created with kernel_output = STORE");
+        HC(hipSetDevice(cfg.device));
+        HC(hipStreamSynchronize(stream));
+        std::vector<V4> tmp(N);
+        HC(hipMemcpy(tmp.data(), kout_d, (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        const bool h8 = cfg.host_float_bytes == 8;
+        if (kernel_gradient) { if (h8) unpack3(tmp, (double*)kernel_gradient, N, D); else unpack3(tmp, (float*)kernel_gradient, N, D); }
+        if (kernel) for (int i = 0; i < N; ++i) { if (h8) ((double*)kernel)[i] = (double)tmp[i].w; else ((float*)kernel)[i] = (float)tmp[i].w; }
+    }
     void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {
         if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once before sphmi_upload");
         HC(hipSetDevice(cfg.device));
@@ -843,7 +867,10 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: float_bytes must be 4 or 8");
     if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 30))
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^30]");
-    if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: only WendlandC2 is implemented");
+    if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2 && cfg->kernel != SPHMI_KERNEL_CUBIC_SPLINE)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: kernel not implemented");
+    if (cfg->kernel_output != SPHMI_KOUT_NONE && cfg->kernel_output != SPHMI_KOUT_STORE)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: kernel output mode not implemented");
     if (cfg->viscosity < SPHMI_VISC_ZERO || cfg->viscosity > SPHMI_VISC_LAMINAR_SPS)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: viscosity model not implemented");
     if (cfg->density_diffusion < SPHMI_DDT_NONE || cfg->density_diffusion > SPHMI_DDT_COMPLEX)
@@ -909,6 +936,9 @@ int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
                     out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));
 }
 
+int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient) {
+    SPHMI_GUARD(h, h->e->download_kernel_output(kernel, kernel_gradient));
+}
 int sphmi_set_motion(sphmi_handle* h, uint64_t group_marker, double velocity, double start_time, double duration,
                      const double* direction) {
     SPHMI_GUARD(h, h->e->set_motion(group_marker, velocity, start_time, duration, direction));

@@ -81,8 +81,11 @@ struct ForceParams {
     int N, nxp, nxyp;
     int visc, ddt, shift;    // model tags for the run-time variant of the kernel
     int exact_cut;           // H < 2h: apply r² ≤ H² per pair (the compiled-in variant requires H = 2h)
+    int kernel;              // 0 WendlandC2, 1 CubicSpline (run-time variant only)
+    V4* kout;                // StoreKernelOutput: { Σ∇W, ΣW } of the corrector pass, or null
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
+    T alphaD, tens_eps, inv_Wdx;   // CubicSpline: αD, CubicSpline.eps, 1 / W(q := dx) (src/SPHKernels.jl:114-126)
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
     double hyd_a, hyd_b; // ComplexDensityDiffusion: ρᴴ(z) = ρ₀·(⁷√(1 + hyd_a·z) − 1), hyd_a = ρ₀·g/Cb, hyd_b = ρ₀
@@ -285,6 +288,7 @@ k_neighbor_force(const ForceParams<T> P) {
 
     T drho = 0, ax = 0, ay = 0, az = 0;
     T gcx = 0, gcy = 0, gcz = 0, divr = 0;            // PlanarShifting: ∇Cᵢ, ∇◌rᵢ (corrector pass)
+    T kgx = 0, kgy = 0, kgz = 0, kw = 0;              // StoreKernelOutput: Σ∇W, ΣW (corrector pass)
     V4 vn_a = q1;                                       // SimParticles.Velocity of the target (LaminarSPS)
     if constexpr (PASS == PASS_CORRECTOR) { if (visc == kViscLaminarSPS) vn_a = P.a1[ac]; }
 
@@ -307,6 +311,20 @@ k_neighbor_force(const ForceParams<T> P) {
         const T r = fast_sqrt(r2);
         const T tq = min_raw(r * P.h_inv, T(2)) - T(2);
         T fac = P.Cgw * (tq * tq * tq);
+        T Wq = T(0);                                            // W(q): tensile correction / kernel output
+        const bool cubic = MODEL < 0 && P.kernel == 1;
+        if (MODEL < 0 && (cubic || P.kout)) {
+            const T q = tq + T(2);
+            if (cubic) {
+                // CubicSpline, src/SPHKernels.jl:89-106: ∇W = dW/dq·h⁻¹·xᵢⱼ/(|xᵢⱼ| + η²)
+                const T dWdq = q <= T(1) ? P.alphaD * (T(-3) * q + T(2.25) * q * q) : P.alphaD * T(-0.75) * (tq * tq);
+                fac = dWdq * P.h_inv / (r + P.eta2);
+                Wq = q <= T(1) ? P.alphaD * (T(1) - T(1.5) * q * q + T(0.75) * q * q * q) : P.alphaD * T(0.25) * (-(tq * tq * tq));
+            } else {
+                const T t1 = T(1) - q * T(0.5), t2 = t1 * t1;
+                Wq = P.alphaD * (t2 * t2) * (T(2) * q + T(1));
+            }
+        }
         // H = k·h with k < 2 (example/DucklingMDBC.jl: 1.5, MovingSquare2d.jl: √2) cuts the kernel off before it
         // vanishes: there the cut of :275 has to be applied for real (run-time variant of the kernel only)
         if (MODEL < 0 && P.exact_cut) fac = (r2 <= P.H2) ? fac : T(0);
@@ -341,6 +359,11 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
         T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
+        if (cubic) {
+            // tensile_correction, :114-126 (n = 4; the reference evaluates the reference kernel value at q := dx)
+            const T w = Wq * P.inv_Wdx, w2 = w * w;
+            coef -= P.m0 * (P.tens_eps * ((P_a * inv_rho_a * inv_rho_a) + (P_b * inv_rho_b * inv_rho_b)) * (w2 * w2));
+        }
         if (visc == kViscArtificial) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
             const T vneg = min_raw(vdx, T(0));
@@ -377,6 +400,12 @@ k_neighbor_force(const ForceParams<T> P) {
                 ay += pre * (c1 * gg * wy - c2 * gy);
                 az += pre * (c1 * gg * wz - c2 * gz);
             }
+        }
+        if (MODEL < 0 && P.kout && PASS == PASS_CORRECTOR) {
+            // KernelOutput!, src/SPHCellList.jl:106-116
+            const bool in = (r2 <= P.H2) && (j != a);              // the pair loop never meets i == j
+            kw += in ? Wq : T(0);
+            kgx += fac * dx; kgy += fac * dy; kgz += fac * dz;
         }
         if (shift) {
             // add_shifting_terms!, src/SPHCellList.jl:73-88 (loop densities; both orientations give these)
@@ -541,11 +570,12 @@ k_neighbor_force(const ForceParams<T> P) {
     }
     run_pairs(0, true);
     if constexpr (WPT > 1) {
-        __shared__ V4 s_part[2 * (WPT - 1) * kWave];        // partial sums of waves 1 … WPT−1
+        __shared__ V4 s_part[3 * (WPT - 1) * kWave];        // partial sums of waves 1 … WPT−1
         // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
         if (wv > 0) {
             V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_part[(wv - 1) * kWave + lane] = o;
             if (shift) { V4 g; g.x = gcx; g.y = gcy; g.z = gcz; g.w = divr; s_part[(WPT - 1 + wv - 1) * kWave + lane] = g; }
+            if (MODEL < 0 && P.kout) { V4 g; g.x = kgx; g.y = kgy; g.z = kgz; g.w = kw; s_part[(2 * (WPT - 1) + wv - 1) * kWave + lane] = g; }
         }
         __syncthreads();
         if (wv > 0) return;
@@ -554,6 +584,7 @@ k_neighbor_force(const ForceParams<T> P) {
             const V4 o = s_part[k * kWave + lane];
             ax += o.x; ay += o.y; az += o.z; drho += o.w;
             if (shift) { const V4 g = s_part[(WPT - 1 + k) * kWave + lane]; gcx += g.x; gcy += g.y; gcz += g.z; divr += g.w; }
+            if (MODEL < 0 && P.kout) { const V4 g = s_part[(2 * (WPT - 1) + k) * kWave + lane]; kgx += g.x; kgy += g.y; kgz += g.z; kw += g.w; }
         }
     }
     // ---- epilogue ---------------------------------------------------------------------------
@@ -603,6 +634,7 @@ k_neighbor_force(const ForceParams<T> P) {
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;
         if (owned) {
+            if (MODEL < 0 && P.kout) { V4 ko; ko.x = kgx; ko.y = kgy; ko.z = kgz; ko.w = kw; P.kout[a] = ko; }
             P.out0[a] = o0; P.out1[a] = o1; P.accbuf[a] = oa;
             // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
             if (!(rho_new > T(0))) atomicOr(&P.red[3], 1ull);

@@ -349,7 +349,8 @@ template <class T> struct MdbcParams {
     unsigned long long* red;   // red[3]: non-positive density flag
     int N;
     T H_inv;               // the cell hash stays in the handle's precision (same cells as the particles)
-    double H2, h_inv, h, alphaD, m0, rho0;
+    double H2, h_inv, h, alphaD, m0, rho0, eta2;
+    int kernel;            // 0 WendlandC2, 1 CubicSpline
 };
 
 template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22) {
@@ -397,11 +398,18 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
                 if (!(r2 <= M.H2)) continue;
                 R q = sqrt(r2) * M.h_inv;
                 q = q > R(2) ? R(2) : q;
-                const R t1 = R(1) - q / R(2);
-                const R t2 = t1 * t1;
-                const R Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));      // src/SPHKernels.jl:75-78
                 const R tq = q - R(2);
-                const R fac = M.alphaD * R(5) * (tq * tq * tq) / (R(8) * M.h * M.h);
+                R Wij, fac;
+                if (M.kernel == 1) {                                         // CubicSpline, src/SPHKernels.jl:89-106
+                    Wij = q <= R(1) ? M.alphaD * (R(1) - R(1.5) * q * q + R(0.75) * q * q * q) : M.alphaD * R(0.25) * (-(tq * tq * tq));
+                    const R dWdq = q <= R(1) ? M.alphaD * (R(-3) * q + R(2.25) * q * q) : M.alphaD * R(-0.75) * (tq * tq);
+                    fac = dWdq * M.h_inv / (sqrt(r2) + M.eta2);
+                } else {
+                    const R t1 = R(1) - q / R(2);
+                    const R t2 = t1 * t1;
+                    Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));          // src/SPHKernels.jl:75-78
+                    fac = M.alphaD * R(5) * (tq * tq * tq) / (R(8) * M.h * M.h);
+                }
                 const R Vj = M.m0 / (R)n0.w;
                 R fc[P];
                 fc[0] = Vj * Wij;

@@ -497,3 +497,42 @@ def test_run_simulation_config1_end_to_end(dam_break_2d):
     np.testing.assert_allclose([t for _, t, _ in og], [t for _, t, _ in oc], rtol=1e-10)
     ig, ic = np.argsort(qg.ID), np.argsort(qc.ID)
     assert relmax(qg.Density[ig], qc.Density[ic]) < 1e-8 and relmax(qg.Position[ig], qc.Position[ic]) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["dam_break_2d", "still_wedge", "dam_break_3d_shipped"])
+def test_cubic_spline_kernel_and_kernel_output(case, request):
+    """SURVEY §8 row f1, last items: the CubicSpline kernel with its tensile correction (src/SPHKernels.jl:89-126; mDBC
+    uses the same kernel) and StoreKernelOutput (src/SPHCellList.jl:106-116: ΣW and Σ∇W of the second pass)."""
+    import dataclasses
+    from sphexample_amd import CubicSpline, SPHKernelInstance, StoreKernelOutput
+    p, s = request.getfixturevalue(case)
+    p = perturbed(p, seed=17)
+    D = s.SimMetaData.Dimensions
+    kern = SPHKernelInstance(D, CubicSpline(0.2), h=s.SimKernel.h, k=s.SimKernel.k)
+    s = dataclasses.replace(s, SimKernel=kern, SimMetaData=dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput))
+    for fb, tol in ((8, 1e-10), (4, 5e-4)):
+        eng, orc = engines(p, s, fb)
+        d1, a1 = eng.forces_once(apply_mdbc=True); d2, a2 = orc.forces_once(apply_mdbc=True)
+        i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+        assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol
+    eng, orc = engines(p, s, 8)
+    eng.advance(1e9, max_steps=8); orc.advance(1e9, max_steps=8)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-9 and relmax(e["Position"], o["Position"]) < 1e-9
+    (k1, g1), (k2, g2) = eng.kernel_output(), orc.kernel_output()
+    i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    assert k2.max() > 0 and relmax(k1[i1], k2[i2]) < 1e-10 and relmax(g1[i1], g2[i2]) < 1e-9
+
+
+def test_kernel_output_with_the_default_kernel(dam_break_2d):
+    import dataclasses
+    from sphexample_amd import StoreKernelOutput
+    p, s = dam_break_2d
+    s = dataclasses.replace(s, SimMetaData=dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput))
+    eng, orc = engines(perturbed(p, seed=3), s, 8)
+    eng.advance(1e9, max_steps=4); orc.advance(1e9, max_steps=4)
+    (k1, g1), (k2, g2) = eng.kernel_output(), orc.kernel_output()
+    i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    assert relmax(k1[i1], k2[i2]) < 1e-10 and relmax(g1[i1], g2[i2]) < 1e-9
+    # interior Shepard sum Σ Vⱼ W ≈ 1 − self term on the lattice: ΣW·V of an interior fluid particle
+    assert 0.5 < np.median(k2) * s.SimConstants.m0 / 1000.0 < 1.1

@@ -57,9 +57,17 @@ def test_unsupported_model_raises(dam_break_2d):
         pass
     with pytest.raises(NotImplementedError):
         make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, UserViscosity(), s.SimDensityDiffusion)
+    from sphexample_amd.config import SPHKernel
+
+    class UserKernel(SPHKernel):             # neither WendlandC2 nor CubicSpline
+        pass
+    k = SPHKernelInstance(2, WendlandC2(), dx=0.02)
+    k.kernel = UserKernel()
     with pytest.raises(NotImplementedError):
-        make_config(len(p), s.SimConstants, s.SimKernel, dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput),
+        make_config(len(p), s.SimConstants, k, s.SimMetaData, s.SimViscosity, s.SimDensityDiffusion)
+    c = make_config(len(p), s.SimConstants, s.SimKernel, dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput),
                     s.SimViscosity, s.SimDensityDiffusion)
+    assert c.kernel_output == 1
     c = make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, Laminar(), s.SimDensityDiffusion)
     assert c.viscosity == 2 and c.shifting == 0 and c.blin_constant == 0.0066 and c.smagorinsky_constant == 0.12
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import perturbed
-from sphexample_amd import (ArtificialViscosity, LinearDensityDiffusion, SimulationConstants,
+from sphexample_amd import (ArtificialViscosity, LinearDensityDiffusion, SimulationConstants, ZeroViscosity, ZeroDensityDiffusion,
                             SimulationMetaData, SPHKernelInstance, WendlandC2, particles_from_arrays)
 from sphexample_amd._abi import make_config
 from sphexample_amd.cases import CaseSetup
@@ -335,3 +335,31 @@ def test_progress_motion():
     assert t_stop > 1.0e-4 > t_stop / 2         # step 1 started at 0, step 2 at ≈0.9e-4: both inside the window
     np.testing.assert_allclose(st["Velocity"][i], [0.0, 0.0])
     np.testing.assert_allclose(st["Position"][i], np.array([0.3, 0.4]) * t_stop, rtol=1e-12)
+
+
+def test_two_particle_cubic_spline_with_tensile_correction():
+    """src/SPHKernels.jl:89-126: the CubicSpline gradient divides by (|xᵢⱼ| + η²) and the tensile term evaluates the
+    reference kernel value as Wᵢⱼ(instance, dx) — dx where q is expected; both kept."""
+    import dataclasses
+    from sphexample_amd import CubicSpline
+    base = default_2d_setup()
+    k = SPHKernelInstance(2, CubicSpline(0.3), dx=base.SimConstants.dx)
+    s = dataclasses.replace(base, SimKernel=k, SimViscosity=ZeroViscosity(), SimDensityDiffusion=ZeroDensityDiffusion())
+    p = two_particle_state()
+    o = make_oracle(p, s)
+    drho, acc = o.forces_once()
+    st = o.download(("ID",))
+    i, j = int(np.where(st["ID"] == 1)[0][0]), int(np.where(st["ID"] == 2)[0][0])
+    c = s.SimConstants
+    xij = p.Position[0] - p.Position[1]; vij = p.Velocity[0] - p.Velocity[1]
+    r = np.sqrt(xij @ xij); q = r * k.h_inv
+    assert 1.0 < q < 2.0
+    W = lambda qq: k.alphaD * ((1 - 1.5 * qq ** 2 + 0.75 * qq ** 3) if qq <= 1 else 0.25 * (2 - qq) ** 3)    # noqa: E731
+    gW = k.alphaD * (-0.75) * (2 - q) ** 2 * k.h_inv * xij / (r + k.eta2)
+    ri, rj = p.Density[0], p.Density[1]
+    P = lambda rr: c.Cb * ((rr / c.rho0) ** 7 - 1)                                                            # noqa: E731
+    f_ab = 0.3 * (P(ri) / ri ** 2 + P(rj) / rj ** 2) * (W(q) / W(c.dx)) ** 4
+    um = -c.m0 * ((P(ri) + P(rj)) / (ri * rj) + f_ab) * gW
+    assert acc[i] == pytest.approx(um, rel=1e-11) and acc[j] == pytest.approx(-um, rel=1e-11)
+    assert drho[i] == pytest.approx(-ri * (c.m0 / rj) * (-vij @ gW), rel=1e-11)
+    assert abs(f_ab) > 1e-6 * abs((P(ri) + P(rj)) / (ri * rj))          # 4e-5 of the pressure term: far above the 1e-11 of the comparison
