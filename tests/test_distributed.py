@@ -91,7 +91,8 @@ def test_comm_over_gloo_world3():
     ("dam_break_3d_shipped", 30, 8, 1e-9, None, True), ("dam_break_3d_shipped", 30, 4, 1e-5, None, True),
     ("dam_break_3d_shipped", 30, 8, 1e-9, 0, True), ("dam_break_3d_shipped", 30, 8, 1e-9, 1, False),
     ("dam_break_3d_shipped", 30, 8, 1e-9, 2, True),
-    ("dam_break_2d", 60, 8, 1e-9, None, True), ("dam_break_2d", 60, 8, 1e-9, 0, False), ("dam_break_2d", 60, 8, 1e-9, 1, True)])
+    ("dam_break_2d", 60, 8, 1e-9, None, True), ("dam_break_2d", 60, 8, 1e-9, 0, False), ("dam_break_2d", 60, 8, 1e-9, 1, True),
+    ("dam_break_2d_variants", 40, 8, 1e-9, None, True)])
 def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
