@@ -40,9 +40,9 @@ FLOP_PER_UPDATE_3D = 4.5e4       # SURVEY.md §8d estimate (2 passes × (≈1120
 
 def measured_traffic(n_local):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_v6_hbm_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+    (profiles/r01_final_hbm_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
     plus WRITE_SIZE), scaled from the profiled particle count.  None when the record is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v6_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
     try:
         rec = json.load(open(path))
         return rec["bytes_per_particle_per_launch_corrected"] * n_local
@@ -154,7 +154,7 @@ def main():
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
-                         "traffic_source": "profiles/r01_v6_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                         "traffic_source": "profiles/r01_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "valu": {"achieved_tflops": FLOP_PER_UPDATE_3D / 2.0 * n_local / (kern_ms * 1e-3) / 1e12
