@@ -275,16 +275,20 @@ k_neighbor_force(const ForceParams<T> P) {
     // form  |c − t|² − H'² = |c|² − 2c·t + (|t|² − H'²)  with a slightly generous cut-off
     // H'² = H²(1+ε); ε covers the fp32 cancellation error of the expanded form (≈ 4·2⁻²⁴·R², R = largest
     // local coordinate).  Phase 2 redoes the exact r² ≤ H² test of src/SPHCellList.jl:275.
+    // The mask only has to be a SUPERSET of the pairs within H (the pair loop is exact), so fp64 handles run the same
+    // fp32 matrix: local coordinates are formed in T and rounded to fp32 (2.27 → ≈1.8 ms per launch at 1 M particles
+    // against one target per iteration through SGPRs on the fp64 vector ALU).
     const T ox = rl(xa, 0), oy = rl(ya, 0), oz = rl(za, 0);
-    const T txl = xa - ox, tyl = ya - oy, tzl = za - oz;
-    const T tt = txl * txl + tyl * tyl + tzl * tzl;
-    T thr;
+    const float txl = (float)(xa - ox), tyl = (float)(ya - oy), tzl = (float)(za - oz);
+    const float tt = txl * txl + tyl * tyl + tzl * tzl;
+    float thr;
     {
-        const T Rm = fast_sqrt(wave_max(valid ? tt : T(0))) + T(3) * P.h * T(2);
-        const T eps = T(1e-5) + T(1e-6) * (Rm * Rm) / P.H2;
-        thr = owned ? P.H2 * (T(1) + eps) - tt : T(-1e30);
+        const float H2f = (float)P.H2;
+        const float Rm = fast_sqrt(wave_max(valid ? tt : 0.0f)) + 6.0f * (float)P.h;
+        const float eps = 1e-5f + 1e-6f * (Rm * Rm) / H2f;
+        thr = owned ? H2f * (1.0f + eps) - tt : -1e30f;
     }
-    const T m2x = T(-2) * txl, m2y = T(-2) * tyl, m2z = T(-2) * tzl;
+    const float m2x = -2.0f * txl, m2y = -2.0f * tyl, m2z = -2.0f * tzl;
 
     T drho = 0, ax = 0, ay = 0, az = 0;
     T gcx = 0, gcy = 0, gcz = 0, divr = 0;            // PlanarShifting: ∇Cᵢ, ∇◌rᵢ (corrector pass)
@@ -484,59 +488,39 @@ k_neighbor_force(const ForceParams<T> P) {
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
     const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
-    float B0[2], B1[2], B2[2], A2 = 0.f;
-    if constexpr (sizeof(T) == 4) {
-        B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
-        B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
-        B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
-        A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
-    }
+    float B0[2], B1[2], B2[2], A2;
+    B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
+    B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
+    B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
+    A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
     auto scan_chunk = [&](const int cb, const int HI) -> unsigned long long {
-        if constexpr (sizeof(T) == 4) {
-            const int c = cb + bperm;
-            const bool cv = c < HI;
-            const V4 cpk = P.src0[cv ? c : cb];
-            float A0[2], A1[2];
-            A0[0] = cpk.x - ox; A0[1] = cpk.y - oy; A1[0] = cpk.z - oz;
-            A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
-            swap_halves(A0[0], A0[1]);                              // [C]: {k0: cx | k1: cy}
-            swap_halves(A1[0], A1[1]);                              //      {k2: cz | k3: |c|²}
-            unsigned W[2] = {0u, 0u};
+        const int c = cb + bperm;
+        const bool cv = c < HI;
+        const V4 cpk = P.src0[cv ? c : cb];
+        float A0[2], A1[2];
+        A0[0] = (float)(cpk.x - ox); A0[1] = (float)(cpk.y - oy); A1[0] = (float)(cpk.z - oz);
+        A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
+        swap_halves(A0[0], A0[1]);                              // [C]: {k0: cx | k1: cy}
+        swap_halves(A1[0], A1[1]);                              //      {k2: cz | k3: |c|²}
+        unsigned W[2] = {0u, 0u};
 #pragma unroll
-            for (int C = 1; C >= 0; --C) {
+        for (int C = 1; C >= 0; --C) {
 #pragma unroll
-                for (int Tb = 0; Tb < 2; ++Tb) {
-                    f32x16 d = {0};
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[Tb], d, 0, 0, 0);
+            for (int Tb = 0; Tb < 2; ++Tb) {
+                f32x16 d = {0};
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[Tb], d, 0, 0, 0);
 #pragma unroll
-                    for (int r = 15; r >= 0; --r)
-                        W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
+                for (int r = 15; r >= 0; --r)
+                    W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
 #if SPHMI_SEQ_BLOCKS
-                    __builtin_amdgcn_sched_barrier(0);      // one 32×32 block in flight: 16 accumulator registers
+                __builtin_amdgcn_sched_barrier(0);      // one 32×32 block in flight: 16 accumulator registers
 #endif
-                }
             }
-            swap_halves(W[0], W[1]);
-            return ((unsigned long long)W[1] << 32) | W[0];
-        } else {
-            // fp64 build: same matrix on the vector ALU, one target per iteration through SGPRs
-            const int c = cb + lane;
-            const bool cv = c < HI;
-            const V4 cpk = P.src0[cv ? c : cb];
-            const T cx = cpk.x - ox, cy = cpk.y - oy, cz = cpk.z - oz;
-            const T cc = cv ? cx * cx + cy * cy + cz * cz : T(1e300);
-            unsigned long long m = 0;
-#pragma unroll 1
-            for (int t = 0; t <= last_lane; ++t) {
-                const T sx = rl(m2x, t), sy = rl(m2y, t), sz = rl(m2z, t), st = rl(thr, t);
-                const T d = cz * sz + (cy * sy + (cx * sx + cc));
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(d < st);
-                m = (lane == t) ? bal : m;
-            }
-            return m;
         }
+        swap_halves(W[0], W[1]);
+        return ((unsigned long long)W[1] << 32) | W[0];
     };
 
 #pragma unroll 1
