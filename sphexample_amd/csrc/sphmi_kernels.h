@@ -17,7 +17,7 @@
 //            coalesced.  fp32: the 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores
 //            (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain); every lane ends up with the results of ITS
 //            target, packs their sign bits with v_alignbit and holds a 64-bit accept mask per chunk.
-//            fp64: the same matrix on the vector ALU, targets broadcast through SGPRs.
+//            fp64 handles use the same fp32 matrix (the mask only has to be a superset; the pair loop is exact).
 //   phase 2  "pair physics".  The masks of the last few rows sit in an LDS ring; every lane walks the set
 //            bits of its own masks at its own pace, gathers the accepted neighbour packets, redoes the
 //            exact r² ≤ H² test and accumulates dρ/dt and acceleration — no divergence on the accept
@@ -95,7 +95,20 @@ struct ForceParams {
 // small helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float  fast_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+#ifndef SPHMI_F64_DIV
+#define SPHMI_F64_DIV 0
+#endif
+__device__ __forceinline__ double fast_rcp(double x) {
+#if SPHMI_F64_DIV
+    return 1.0 / x;
+#else
+    // v_rcp_f64 (≈2⁻²⁶ relative) + two Newton steps: ≤ 1 ulp for the normal, positive arguments of the pair loop
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+#endif
+}
 __device__ __forceinline__ float  fast_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 
