@@ -313,8 +313,9 @@ k_neighbor_force(const ForceParams<T> P) {
     const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.a1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     // ---- pair physics for one accepted neighbour j ------------------------------------------
     auto pair = [&](const int j, const V4& n0, const V4& n1) {
-        const T dx = xa - n0.x, dy = ya - n0.y, dz = za - n0.z;
-        const T r2 = dx * dx + dy * dy + dz * dz;
+        // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
+        const T dx = xa - n0.x, dy = ya - n0.y, dz = (D == 3) ? za - n0.z : T(0);
+        const T r2 = (D == 3) ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
         T rho_b, rhon_b, P_b, s_b;
         if constexpr (PASS == PASS_CORRECTOR) {
             rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w;
@@ -345,8 +346,8 @@ k_neighbor_force(const ForceParams<T> P) {
         // H = k·h with k < 2 (example/DucklingMDBC.jl: 1.5, MovingSquare2d.jl: √2) cuts the kernel off before it
         // vanishes: there the cut of :275 has to be applied for real (run-time variant of the kernel only)
         if (MODEL < 0 && P.exact_cut) fac = (r2 <= P.H2) ? fac : T(0);
-        const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = q1.z - n1.z;
-        const T vdx = dvx * dx + dvy * dy + dvz * dz;          // vᵢⱼ·xᵢⱼ
+        const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = (D == 3) ? q1.z - n1.z : T(0);
+        const T vdx = (D == 3) ? dvx * dx + dvy * dy + dvz * dz : dvx * dx + dvy * dy;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
         // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
         drho += rm_a * inv_rho_b * (fac * vdx);
@@ -387,7 +388,8 @@ k_neighbor_force(const ForceParams<T> P) {
             coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
         }
         coef *= fac;
-        ax += coef * dx; ay += coef * dy; az += coef * dz;
+        ax += coef * dx; ay += coef * dy;
+        if constexpr (D == 3) az += coef * dz;
         if (visc == kViscLaminar || visc == kViscLaminarSPS) {
             // Laminar, :77-87: term·vᵢⱼ with term = 4m₀ν₀(xᵢⱼ·∇W)/((ρᵢ+ρⱼ) + (d²+η²)) — the reference ADDS the
             // two brackets; ρ from SimParticles.Density
