@@ -286,8 +286,9 @@ struct Engine final : EngineBase {
     template <int PASS, int MODEL> void launch_force_model(ForceParams<T> P, int list) {
         if (part_max[list] == 0) return;
         P.order = tile_order[list]; P.part = part_d + 16 * list; P.trace = trace_d;
-        // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip
-        const int ntile = (N + kWave - 1) / kWave;
+        // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip (per list: the
+        // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
+        const int ntile = std::min((N + kWave - 1) / kWave, 8 * part_max[list]);
         const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
         if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);

@@ -237,6 +237,7 @@ class DistributedEngine:
         self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(lo, -INF)), C.c_int64(min(hi, INF)),
                    C.c_int(rank > 0), C.c_int(rank < world - 1))
         self.overlap = overlap
+        self._side = torch.cuda.Stream(device=self.device)
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
         keep = [f(particles.Position[mine]), f(particles.Velocity[mine]), f(particles.Acceleration[mine]),
                 f(particles.Density[mine]), np.ascontiguousarray(particles.Type[mine], dtype=np.uint8),
@@ -396,15 +397,28 @@ class DistributedEngine:
         self._keep[which] = (rl, rr, token)   # receive / send buffers stay alive until this set is exchanged again
 
     def _pass(self, which: int, dt: float):
-        """One neighbour pass with its halo: interior tiles run while the messages are in flight."""
+        """One neighbour pass with its halo.  Interior tiles run on the main stream while the messages are in
+        flight; the unpack and the slab-edge tiles go to a SIDE stream that only waits for the messages, so the
+        edge tiles start as soon as the halo has landed and share the chip with the interior launch instead of
+        forming a second, poorly filled launch behind it."""
+        torch = self.torch
         token = self._halo_start(which - 1)
-        if self.overlap:
-            self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(1))
-            self._halo_finish(which - 1, token)
-            self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(2))
-        else:
+        if not self.overlap:
             self._halo_finish(which - 1, token)
             self._call("dd_pass", C.c_int(which), C.c_double(dt))
+            return
+        main = torch.cuda.current_stream(self.device)
+        side = self._side
+        side.wait_stream(main)                       # everything queued so far: the previous pass, the pack
+        self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(1))
+        with torch.cuda.stream(side):
+            self._call("dd_set_stream", C.c_void_p(side.cuda_stream))
+            try:
+                self._halo_finish(which - 1, token)  # the side stream waits for the transfers, then unpacks
+                self._call("dd_pass_part", C.c_int(which), C.c_double(dt), C.c_int(2))
+            finally:
+                self._call("dd_set_stream", C.c_void_p(main.cuda_stream))
+        main.wait_stream(side)                       # the next pack / the reductions need the edge tiles
 
     # -- the SimulationLoop of src/SPHCellList.jl:727-805, distributed --------------------------------
     def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
