@@ -31,8 +31,10 @@ rank → sort → send copies of the slab's first / last column as the neighbour
 rebuild the halo index lists.  Both sorts are stable, so the k-th boundary particle of the sender is the
 k-th ghost slot of the receiver and the per-step halo needs no indices on the wire.
 
-Known limits: static cuts and axis (no re-balancing while the fluid moves), migration to
-adjacent ranks only, no mDBC, per-step control on the host.
+The cuts move with the fluid: at a rebuild whose max/mean owned count exceeds 1.05 the ranks sum their column
+histograms and re-cut (every cut stays between its old neighbours, so migration remains a neighbour exchange).
+
+Known limits: static slab axis, no mDBC / moving bodies, per-step control on the host.
 """
 from __future__ import annotations
 
@@ -102,6 +104,28 @@ class SlabPlan:
         cx_hi = [(INF if r == world - 1 else cuts[r + 1] - 1) for r in range(world)]
         return SlabPlan(cx_lo, cx_hi)
 
+    def cuts(self) -> List[int]:
+        """Interior cut positions: cut r (1 ≤ r < world) is the first column of rank r."""
+        return [self.cx_lo[r] for r in range(1, self.world)]
+
+    def recut(self, col0: int, hist: np.ndarray) -> "SlabPlan":
+        """Equal-count cuts for the CURRENT global column histogram (`hist[k]` = particles in column col0 + k), with
+        every cut kept between its two old neighbours (so a particle changes rank by at most one — migration stays a
+        neighbour exchange) and every slab at least two columns wide."""
+        world = self.world
+        cum = np.cumsum(hist)
+        total = int(cum[-1])
+        old = [col0] + self.cuts() + [col0 + len(hist)]
+        new = [old[0]]
+        for r in range(1, world):
+            c = col0 + int(np.searchsorted(cum, total * r / world, side="left")) + 1
+            lo = max(old[r - 1] + 2, new[-1] + 2)               # not past the old cut on the left, slab r−1 ≥ 2 columns
+            hi = old[r + 1] - 2                                  # not past the old cut on the right
+            new.append(min(max(c, lo), hi) if lo <= hi else old[r])
+        INF = 1 << 30
+        return SlabPlan([(-INF if r == 0 else new[r]) for r in range(world)],
+                        [(INF if r == world - 1 else new[r + 1] - 1) for r in range(world)])
+
     def owner_of(self, cx: np.ndarray) -> np.ndarray:
         bounds = np.array([self.cx_lo[r] for r in range(1, self.world)], dtype=np.int64)
         return np.searchsorted(bounds, cx, side="right")
@@ -139,6 +163,15 @@ class _Comm:
         if self.on_device:
             t = t.to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    def allreduce_i64(self, values: np.ndarray, op: str) -> np.ndarray:
+        """Elementwise SUM / MIN / MAX of a small int64 host array over the ranks (rebuild-time bookkeeping)."""
+        t = self.torch.as_tensor(np.ascontiguousarray(values, dtype=np.int64))
+        if self.world > 1:
+            if self.on_device:
+                t = t.to(self.device)
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return t.cpu().numpy()
 
     def allreduce_max_bits(self, t):
@@ -202,7 +235,7 @@ class DistributedEngine:
 
     def __init__(self, particles, setup, rank: int, world: int, local_device: int = 0,
                  device_float_bytes: int = 4, capacity_factor: float = 1.6, axis: Optional[int] = None,
-                 overlap: bool = True):
+                 overlap: bool = True, recut_imbalance: float = 1.05, plan: Optional[SlabPlan] = None):
         import torch
         from .engine import Engine, load_library
         self.torch = torch
@@ -216,7 +249,7 @@ class DistributedEngine:
         cols = [cell_x_of(particles.Position[:, a].astype(ft).astype(np.float64), H_inv) for a in range(D)]
         self.axis = choose_axis(cols, world) if axis is None else int(axis)
         cx = cols[self.axis]
-        self.plan = SlabPlan.from_columns(cx, world)
+        self.plan = plan if plan is not None else SlabPlan.from_columns(cx, world)    # `plan`: start from given cuts
         mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
         self.n_total = len(particles)
         n_own = len(mine)
@@ -237,6 +270,8 @@ class DistributedEngine:
         self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(lo, -INF)), C.c_int64(min(hi, INF)),
                    C.c_int(rank > 0), C.c_int(rank < world - 1))
         self.overlap = overlap
+        self.recut_imbalance = recut_imbalance          # re-cut the slabs at a rebuild when max/mean owned count exceeds this
+        self.n_recuts = 0
         self._side = torch.cuda.Stream(device=self.device)
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
         keep = [f(particles.Position[mine]), f(particles.Velocity[mine]), f(particles.Acceleration[mine]),
@@ -320,11 +355,26 @@ class DistributedEngine:
     # -- collective rebuild ------------------------------------------------------------------------
     def _rebuild(self):
         torch = self.torch
-        lo, hi = self.plan.cx_lo[self.rank], self.plan.cx_hi[self.rank]
-        # 1. ghosts die, leavers migrate to the adjacent rank
         cx = self._cell_x()
         ty = self._types()
         owned = (ty & GHOST_MASK) == 0
+        # 0. load balance: the rebuild is the only time particles change cells, so it is also when the cuts may move
+        if self.world > 1 and self.recut_imbalance is not None:
+            co = cx[owned].astype(np.int64)
+            ext = self.comm.allreduce_i64(np.array([-co.min(), co.max(), len(co), -len(co)]), "MAX")
+            gmin, gmax, nmax, nmin = -int(ext[0]), int(ext[1]), int(ext[2]), -int(ext[3])
+            total = self.comm.allreduce_i64(np.array([len(co)]), "SUM")[0]
+            if nmax * self.world > self.recut_imbalance * total:
+                hist = self.comm.allreduce_i64(np.bincount(co - gmin, minlength=gmax - gmin + 1), "SUM")
+                plan = self.plan.recut(gmin, hist)
+                if plan.cuts() != self.plan.cuts():
+                    self.plan = plan
+                    INF = 1 << 30
+                    self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(plan.cx_lo[self.rank], -INF)),
+                               C.c_int64(min(plan.cx_hi[self.rank], INF)), C.c_int(self.rank > 0), C.c_int(self.rank < self.world - 1))
+                    self.n_recuts += 1
+        lo, hi = self.plan.cx_lo[self.rank], self.plan.cx_hi[self.rank]
+        # 1. ghosts die, leavers migrate to the adjacent rank
         go_l = np.nonzero(owned & (cx < lo))[0]
         go_r = np.nonzero(owned & (cx > hi))[0]
         if len(go_l) and (cx[go_l] < self.plan.cx_lo[self.rank - 1]).any() or \

@@ -45,17 +45,26 @@ def comm_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overlap=True):
+def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overlap=True, recut=1.05, cut_shift=0):
     """2 ranks sharing GPU 0 (gloo staging): slab engines vs nothing — rank 0 stores the gathered result."""
     dist = _init(rank, world, port)
     import conftest
     from sphexample_amd.distributed import DistributedEngine
     p, s = getattr(conftest, "load_" + case)()
-    eng = DistributedEngine(p, s, rank, world, local_device=0, device_float_bytes=fb, axis=axis, overlap=overlap)
+    plan = None
+    if cut_shift:
+        # start from deliberately unbalanced cuts (the balanced ones moved by `cut_shift` columns)
+        from sphexample_amd.distributed import SlabPlan, cell_x_of
+        cx = cell_x_of(p.Position[:, axis], s.SimKernel.H_inv)
+        b = SlabPlan.from_columns(cx, world)
+        INF = 1 << 30
+        c = [x + cut_shift for x in b.cuts()]
+        plan = SlabPlan([-INF] + c, [x - 1 for x in c] + [INF])
+    eng = DistributedEngine(p, s, rank, world, local_device=0, plan=plan, device_float_bytes=fb, axis=axis, overlap=overlap, recut_imbalance=recut)
     pr = eng.advance(1e9, max_steps=steps)
     res = eng.gather_all()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dd.npz"), iteration=pr.iteration, total_time=pr.total_time,
-                 n_rebuilds=pr.n_rebuilds, axis=eng.axis, **res)
+                 n_rebuilds=pr.n_rebuilds, axis=eng.axis, n_recuts=eng.n_recuts, **res)
     dist.barrier()
     dist.destroy_process_group()

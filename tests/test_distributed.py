@@ -55,6 +55,27 @@ def test_choose_axis_prefers_the_evenly_filled_direction(dam_break_3d_shipped):
         choose_axis([np.zeros(10, dtype=np.int64)], 2)          # one column cannot be split
 
 
+def test_recut_keeps_migration_between_neighbours():
+    """SlabPlan.recut: equal-count cuts for the current histogram, every cut between its old neighbours, slabs ≥ 2
+    columns; repeated re-cuts converge to the balanced plan."""
+    rng = np.random.default_rng(0)
+    cx = rng.integers(0, 40, 100000)
+    plan = SlabPlan.from_columns(cx, 4)
+    cx2 = np.concatenate([cx, rng.integers(0, 10, 60000)])          # the fluid piles up on the left
+    hist = np.bincount(cx2, minlength=40)
+    before = np.bincount(plan.owner_of(cx2), minlength=4).max()
+    for _ in range(3):
+        new = plan.recut(0, hist)
+        old_c, new_c = [0] + plan.cuts() + [40], [0] + new.cuts() + [40]
+        assert all(old_c[r - 1] <= new_c[r] <= old_c[r + 1] for r in range(1, 4))
+        assert all(new_c[r + 1] - new_c[r] >= 2 for r in range(4))
+        # a particle changes rank by at most one
+        assert np.abs(new.owner_of(cx2) - plan.owner_of(cx2)).max() <= 1
+        plan = new
+    assert np.bincount(plan.owner_of(cx2), minlength=4).max() < 0.6 * before
+    assert plan.recut(0, hist).cuts() == plan.cuts()                   # converged
+
+
 def test_step_control_matches_oracle_dt(dam_break_2d):
     """The host-side Δt / Δx arithmetic used by the distributed driver = the oracle's (TimeStepping.jl:30-43)."""
     from oracle.oracle import make_oracle
@@ -94,6 +115,18 @@ def test_comm_over_gloo_world3():
     ("dam_break_2d", 60, 8, 1e-9, None, True), ("dam_break_2d", 60, 8, 1e-9, 0, False), ("dam_break_2d", 60, 8, 1e-9, 1, True),
     ("dam_break_2d_variants", 40, 8, 1e-9, None, True)])
 def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request):
+    _two_slabs(case, steps, fb, tol, axis, overlap, 1.05, request)
+
+
+@pytest.mark.gpu
+def test_two_slabs_with_moving_cuts(request):
+    """Start from cuts that are four columns off balance: the first rebuilds move them back (particles migrate, the
+    ghost layers and halo lists are rebuilt) and the result is still the single-GPU one."""
+    dd = _two_slabs("dam_break_3d_shipped", 80, 8, 1e-9, 0, True, 1.05, request, cut_shift=4)
+    assert int(dd["n_recuts"]) >= 1
+
+
+def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
     import torch.multiprocessing as mp
@@ -104,7 +137,7 @@ def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request
     pr = ref.advance(1e9, max_steps=steps)
     r = ref.download(("Position", "Density", "ID", "Velocity"))
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(engine_worker, args=(2, _free_port(), d, case, steps, fb, axis, overlap), nprocs=2, join=True)
+        mp.spawn(engine_worker, args=(2, _free_port(), d, case, steps, fb, axis, overlap, recut, cut_shift), nprocs=2, join=True)
         dd = dict(np.load(os.path.join(d, "dd.npz")))
     assert axis is None or int(dd["axis"]) == axis
     assert int(dd["iteration"]) == pr.iteration == steps
@@ -114,3 +147,4 @@ def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request
     i1, i2 = np.argsort(r["ID"]), np.argsort(dd["ID"])
     assert np.abs(dd["Density"][i2] - r["Density"][i1]).max() / np.abs(r["Density"]).max() < tol
     assert np.abs(dd["Position"][i2] - r["Position"][i1]).max() / np.abs(r["Position"]).max() < tol
+    return dd
