@@ -77,7 +77,7 @@ typedef struct sphmi_config {
     int32_t device;              /* HIP device ordinal                                           */
     int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
     int32_t kernel_output;       /* SPHMI_KOUT_* (KMode of SimulationMetaData)                   */
-    int64_t n_particles;         /* length(SimParticles)                                         */
+    int64_t n_particles;         /* length(SimParticles); at most 2^27 per handle (32-bit gather offsets) */
     int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
     /* SimulationConstants */
     double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;

@@ -866,8 +866,9 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
     if ((cfg->host_float_bytes != 4 && cfg->host_float_bytes != 8) ||
         (cfg->device_float_bytes != 4 && cfg->device_float_bytes != 8))
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: float_bytes must be 4 or 8");
-    if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 30))
-        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^30]");
+    // the neighbour gathers use 32-bit buffer offsets: n × sizeof(packet) must stay below 4 GB
+    if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 27))
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27]");
     if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2 && cfg->kernel != SPHMI_KERNEL_CUBIC_SPLINE)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: kernel not implemented");
     if (cfg->kernel_output != SPHMI_KOUT_NONE && cfg->kernel_output != SPHMI_KOUT_STORE)
