@@ -194,7 +194,7 @@ class Backend:
         self._check(self._fn("download")(self._h, *[_ptr(out[k]) for k in spec]))
         return {k: v for k, v in out.items() if v is not None}
 
-    def download_into(self, p) -> None:
+    def download_into(self, p, begin_only: bool = False) -> None:
         """Write the engine state back into the arrays of a SimParticles IN PLACE (what the reference's loop leaves in
         its StructArray).  The same host arrays are used at every output, so the engine page-locks them the second
         time it sees them and the copies run at PCIe speed."""
@@ -210,10 +210,24 @@ class Backend:
                 a = None                       # field absent or in another layout: fall back to the copying path below
             args.append(a)
         if all(a is not None for a in args):
-            self._check(self._fn("download")(self._h, *[_ptr(a) for a in args]))
+            name = "download_begin" if begin_only and self._has("download_begin") else "download"
+            self._fn(name).argtypes = [C.c_void_p] * 11
+            self._check(self._fn(name)(self._h, *[_ptr(a) for a in args]))
             return
         for k, v in self.download().items():
             setattr(p, k, v)
+
+    def download_into_begin(self, p) -> None:
+        """Start an asynchronous download_into: the arrays of `p` must not be touched until download_end()."""
+        self.download_into(p, begin_only=True)
+
+    def download_end(self) -> None:
+        if self._has("download_end"):
+            self._fn("download_end").argtypes = [C.c_void_p]
+            self._check(self._fn("download_end")(self._h))
+
+    def _has(self, name: str) -> bool:
+        return hasattr(self._lib, self._p + name)
 
     def kernel_output(self):
         """(Kernel, KernelGradient) of StoreKernelOutput runs, current order."""

@@ -50,6 +50,8 @@ struct EngineBase {
                         const uint64_t*, const void*) = 0;
     virtual void advance(double t_target, int64_t max_steps, sphmi_progress* out) = 0;
     virtual void download(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
+    virtual void download_begin(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
+    virtual void download_end() = 0;
     virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
     virtual void download_kernel_output(void* kernel, void* kernel_gradient) = 0;
     virtual void unique_cells(int64_t* out, int64_t cap, int64_t* n) = 0;
@@ -170,6 +172,7 @@ struct Engine final : EngineBase {
             (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]);
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
         }
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); (void)hipEventDestroy(ev_packed); }
         for (auto& e : host_pinned) (void)hipHostUnregister(e.first);
         (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
@@ -569,11 +572,16 @@ struct Engine final : EngineBase {
         if (host_seen.size() > 64) host_seen.clear();
         host_seen.emplace_back(p, bytes);
     }
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_packed = nullptr; bool download_pending = false;
+    // begin: snapshot every requested field into the arena IN STREAM ORDER (so later steps cannot disturb it), then
+    // hand the device→host copies to a second stream; end: wait for them.  Between the two the caller may advance.
     template <class H>
-    void download_as(void* position, void* velocity, void* acceleration, void* density, void* pressure,
-                     int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) {
+    void download_begin_as(void* position, void* velocity, void* acceleration, void* density, void* pressure,
+                           int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) {
+        if (!copy_stream) { HC(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); HC(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)); }
+        if (download_pending) { HC(hipStreamSynchronize(copy_stream)); download_pending = false; }
         const size_t n = (size_t)N, nd = n * (size_t)D;
-        const size_t need = (4 * nd + 2 * n) * sizeof(H) + nd * 8 + 256 * 8;
+        const size_t need = (4 * nd + 2 * n) * sizeof(H) + nd * 8 + n * 17 + 256 * 12;
         if (need > out_arena_bytes) {
             (void)hipFree(out_arena);
             out_arena = nullptr; out_arena_bytes = 0;
@@ -590,28 +598,45 @@ struct Engine final : EngineBase {
         o.acc = (H*)take(acceleration, nd * sizeof(H)); o.rho = (H*)take(density, n * sizeof(H));
         o.press = (H*)take(pressure, n * sizeof(H)); o.ghost = (H*)take(ghost_points, nd * sizeof(H));
         o.cells = (long long*)take(cells, nd * 8);
+        char* a_id = take(ids, n * 8); char* a_ty = take(ty, n); char* a_grp = take(groups, n * 8);
         hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
                            stepped ? pk0[iH] : (const V4*)nullptr, acc[cur], ghost[cur], key[cur], N, D, grid, have_grid ? 1 : 0,
                            (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
         HC(hipGetLastError());
+        if (a_id) HC(hipMemcpyAsync(a_id, id[cur], n * 8, hipMemcpyDeviceToDevice, stream));
+        if (a_ty) HC(hipMemcpyAsync(a_ty, type[cur], n, hipMemcpyDeviceToDevice, stream));
+        if (a_grp) HC(hipMemcpyAsync(a_grp, grp[cur], n * 8, hipMemcpyDeviceToDevice, stream));
+        HC(hipEventRecord(ev_packed, stream));
+        HC(hipStreamWaitEvent(copy_stream, ev_packed, 0));
         auto copy = [&](void* dst, const void* src, size_t bytes) {
             if (!dst) return;
             maybe_pin(dst, bytes);
-            HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+            HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, copy_stream));
         };
         copy(position, o.pos, nd * sizeof(H)); copy(velocity, o.vel, nd * sizeof(H));
         copy(acceleration, o.acc, nd * sizeof(H)); copy(density, o.rho, n * sizeof(H));
         copy(pressure, o.press, n * sizeof(H)); copy(ghost_points, o.ghost, nd * sizeof(H));
         copy(cells, o.cells, nd * 8);
-        copy(ids, id[cur], n * 8); copy(ty, type[cur], n); copy(groups, grp[cur], n * 8);
-        HC(hipStreamSynchronize(stream));
+        copy(ids, a_id, n * 8); copy(ty, a_ty, n); copy(groups, a_grp, n * 8);
+        download_pending = true;
+    }
+    void download_begin(void* position, void* velocity, void* acceleration, void* density, void* pressure,
+                        int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
+        HC(hipSetDevice(cfg.device));
+        if (cfg.host_float_bytes == 8) download_begin_as<double>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+        else download_begin_as<float>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+    }
+    void download_end() override {
+        if (!download_pending) return;
+        HC(hipSetDevice(cfg.device));
+        HC(hipStreamSynchronize(copy_stream));
+        download_pending = false;
     }
     void download(void* position, void* velocity, void* acceleration, void* density, void* pressure,
                   int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
-        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
-        HC(hipSetDevice(cfg.device));
-        if (cfg.host_float_bytes == 8) download_as<double>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
-        else download_as<float>(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+        download_begin(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+        download_end();
     }
 
     void download_kernel_output(void* kernel, void* kernel_gradient) override {
@@ -938,6 +963,13 @@ int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
                     out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));
 }
 
+int sphmi_download_begin(sphmi_handle* h, void* position, void* velocity, void* acceleration, void* density,
+                         void* pressure, int64_t* id, uint8_t* type, uint64_t* group_marker, void* ghost_points,
+                         int64_t* cells) {
+    SPHMI_GUARD(h, h->e->download_begin(position, velocity, acceleration, density, pressure, id, type, group_marker,
+                                        ghost_points, cells));
+}
+int sphmi_download_end(sphmi_handle* h) { SPHMI_GUARD(h, h->e->download_end()); }
 int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient) {
     SPHMI_GUARD(h, h->e->download_kernel_output(kernel, kernel_gradient));
 }

@@ -8,6 +8,7 @@ Restates the bookkeeping of /root/reference/src/SPHCellList.jl:808-930 that surr
 """
 from __future__ import annotations
 
+import copy
 from typing import Callable, List, Optional
 
 from ._abi import make_config
@@ -22,7 +23,8 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
                   SimViscosity: SPHViscosity, SimDensityDiffusion: SPHDensityDiffusion,
                   ParticleNormalsPath: Optional[str] = None,
                   on_output: Optional[Callable[[SimulationMetaData, SimParticles], None]] = None,
-                  device_float_bytes: int = 4, device: int = 0, backend_factory=None) -> List[float]:
+                  device_float_bytes: int = 4, device: int = 0, backend_factory=None,
+                  async_output: bool = False) -> List[float]:
     """Same keyword signature as the reference (src/SPHCellList.jl:808-817); returns the list of
     time steps the reference collects in ``TimeSteps`` (:823,:884).  ``SimParticles`` is updated in
     place at every output time, in the engine's cell-sorted order, as the reference's is."""
@@ -40,6 +42,7 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
     SimMetaData.OutputIterationCounter = 1                                       # :849
     if on_output:
         on_output(SimMetaData, SimParticles)                                     # :850
+    pending = None       # async_output: metadata of the snapshot whose copies are in flight
     while True:                                                                  # :881
         prog = eng.advance(next_output_time(SimMetaData))                        # :883
         SimMetaData.Iteration = prog.iteration
@@ -48,10 +51,24 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
         SimMetaData.IndexCounter = prog.index_counter
         time_steps.append(prog.last_dt)                                          # :884
         SimMetaData.OutputIterationCounter += 1                                  # :888
+        done = SimMetaData.TotalTime > SimMetaData.SimulationTime               # :909
+        if on_output and async_output:
+            # The copies of snapshot k run while interval k+1 is computed: the callback for k is made after the
+            # NEXT advance, with the metadata captured at the snapshot.
+            if pending is not None:
+                eng.download_end()
+                on_output(pending, SimParticles)
+            eng.download_into_begin(SimParticles)
+            pending = copy.copy(SimMetaData)
+            if done:
+                eng.download_end()
+                on_output(pending, SimParticles)
+                break
+            continue
         if on_output:
             eng.download_into(SimParticles)
             on_output(SimMetaData, SimParticles)                                 # :891-894
-        if SimMetaData.TotalTime > SimMetaData.SimulationTime:                   # :909
+        if done:
             eng.download_into(SimParticles)
             break
     eng.close()

@@ -536,3 +536,28 @@ def test_kernel_output_with_the_default_kernel(dam_break_2d):
     assert relmax(k1[i1], k2[i2]) < 1e-10 and relmax(g1[i1], g2[i2]) < 1e-9
     # interior Shepard sum Σ Vⱼ W ≈ 1 − self term on the lattice: ΣW·V of an interior fluid particle
     assert 0.5 < np.median(k2) * s.SimConstants.m0 / 1000.0 < 1.1
+
+
+def test_async_output_delivers_the_same_snapshots(dam_break_2d):
+    """sphmi_download_begin / _end: the copies of an output overlap the next interval; every snapshot (state AND
+    metadata) equals what the synchronous driver hands to the callback."""
+    import copy
+    from sphexample_amd.simulation import RunSimulation
+    p, s = dam_break_2d
+    got = {}
+    for mode in (False, True):
+        meta = copy.deepcopy(s.SimMetaData)
+        meta.SimulationTime, meta.OutputTimes = 0.004, 0.001
+        q = p.copy()
+        snaps = []
+        RunSimulation(SimGeometry=None, SimMetaData=meta, SimConstants=s.SimConstants, SimKernel=s.SimKernel, SimLogger=None,
+                      SimParticles=q, SimViscosity=s.SimViscosity, SimDensityDiffusion=s.SimDensityDiffusion,
+                      device_float_bytes=8, async_output=mode,
+                      on_output=lambda m, pp: snaps.append((m.OutputIterationCounter, m.Iteration, m.TotalTime,
+                                                            pp.Position.copy(), pp.Density.copy(), pp.ID.copy())))
+        got[mode] = snaps
+    assert len(got[True]) == len(got[False]) >= 5
+    for a, b in zip(got[True][1:], got[False][1:]):          # [0] is the initial output (:850), same object state
+        assert a[:3] == b[:3]
+        for x, y in zip(a[3:], b[3:]):
+            np.testing.assert_array_equal(x, y)

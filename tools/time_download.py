@@ -15,3 +15,8 @@ print(f"N={len(p)}: 25 steps {1e3*(t1-t0):.1f} ms; download(all fields) {1e3*(t2
 q = p.copy()
 for k in range(4):
     t = time.perf_counter(); e.download_into(q); print(f"download_into #{k}: {1e3 * (time.perf_counter() - t):.1f} ms")
+# asynchronous output: begin → advance → end
+t = time.perf_counter(); e.download_into_begin(q); tb = time.perf_counter() - t
+t = time.perf_counter(); e.advance(1e9, max_steps=25); ta = time.perf_counter() - t
+t = time.perf_counter(); e.download_end(); te = time.perf_counter() - t
+print(f"async: begin {1e3 * tb:.2f} ms, 25 steps {1e3 * ta:.1f} ms, end {1e3 * te:.2f} ms")
