@@ -108,6 +108,8 @@ struct Engine final : EngineBase {
     unsigned long long* trace_d = nullptr;
     V4* kout_d = nullptr;              // StoreKernelOutput: { Σ∇W, ΣW } per particle
     MotionTable motions{};
+    StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control + its pinned mirror
+    static constexpr int kBatch = 8;   // steps queued between two looks at the control flags
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
     static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
@@ -159,6 +161,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
 #endif
         HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
+        HC(hipMalloc(&ctrl_d, sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
@@ -199,6 +202,7 @@ struct Engine final : EngineBase {
                         st[8], st[9], st[10], st[11], st[12], st[13]);
         }
 #endif
+        (void)hipFree(ctrl_d); (void)hipHostFree(ctrl_h);
         (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
         (void)hipFree(cellx_d);
@@ -249,7 +253,7 @@ struct Engine final : EngineBase {
         P.out0 = pk0[out]; P.out1 = pk1[out];
         P.accbuf = acc[cur];
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
-        P.red = red_d;
+        P.red = red_d; P.ctrl = nullptr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
@@ -317,10 +321,10 @@ struct Engine final : EngineBase {
         for (int d = 0; d < 3; ++d) motions.dir[m][d] = d < D ? dir[d] : 0.0;
     }
     // ProgressMotion (src/SPHCellList.jl:765,787) on state set A
-    void progress_motion(double dt2) {
+    void progress_motion(double dt2, const StepCtrl* ctrl = nullptr) {
         if (motions.n == 0) return;
         hipLaunchKernelGGL(k_progress_motion<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA], type[cur],
-                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2);
+                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2, ctrl);
         HC(hipGetLastError());
     }
 
@@ -420,9 +424,10 @@ struct Engine final : EngineBase {
         end_phase(ev);
     }
 
-    void run_mdbc() {
+    void run_mdbc(const StepCtrl* ctrl = nullptr) {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
+        M.ctrl = ctrl;
         M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
@@ -439,46 +444,30 @@ struct Engine final : EngineBase {
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
     }
 
-    // ---- one iteration of the while loop at src/SPHCellList.jl:742-802 -------------------------
-    void step_once() {
-        Ev ev = begin_phase(PH_TIMESTEP);
-        HC(hipMemcpyAsync(red_h, red_d, 4 * 8, hipMemcpyDeviceToHost, stream));
-        end_phase(ev);
-        sync_and_collect();
-        if (red_h[3]) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
-        const double maxdisp = std::sqrt(decode(red_h[0]));
-        const double visc = decode(red_h[1]);
-        const double amax = std::sqrt(decode(red_h[2]));
-        delta_x += 4.0 * maxdisp;                                            // update_delta_x!, :706-724
-        const double dt1 = std::sqrt(cfg.h / amax);                          // Δt, src/TimeStepping.jl:30-43
-        const double dt2 = cfg.h / (cfg.c0 + visc);
-        const double dt = cfg.CFL * std::min(dt1, dt2);
-        if (!(dt > 0.0) || std::isnan(dt) || std::isnan(delta_x)) {
-            char buf[160];
-            snprintf(buf, sizeof(buf), "non-positive or NaN dt (%g) at iteration %lld (visc %g, |a|max %g, Δx %g)",
-                     dt, (long long)iteration, visc, amax, delta_x);
-            throw EngineError(SPHMI_ERR_NUMERIC, buf);
-        }
-        if (delta_x >= cfg.h) { rebuild(); delta_x = 0.0; }                   // :758-762
-        progress_motion(dt * 0.5);                                            // :765
-        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
-        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();                        // :772 (Pressure! of :771 is in pk1.w)
-        Ev e1 = begin_phase(PH_PASS1);
-        launch_force<PASS_PREDICTOR>(force_params(iA, iA, iH, dt));          // :774-781
-        end_phase(e1);
-        progress_motion(dt * 0.5);                                            // :787
-        Ev e2 = begin_phase(PH_PASS2);
-        launch_force<PASS_CORRECTOR>(force_params(iH, iA, iB, dt));          // :789-798
-        end_phase(e2);
-        std::swap(iA, iB);
-        stepped = true;
-        iteration += 1; last_dt = dt; total_time += dt;                       // UpdateMetaData!, :679-685
+    void fill(sphmi_progress* out, int64_t steps) {
+        if (!out) return;
+        out->iteration = iteration; out->steps_done = steps; out->n_rebuilds = n_rebuilds;
+        out->index_counter = index_counter; out->total_time = total_time; out->last_dt = last_dt; out->delta_x = delta_x;
     }
 
-    void fill(sphmi_progress* p, int64_t steps) {
-        if (!p) return;
-        p->iteration = iteration; p->steps_done = steps; p->n_rebuilds = n_rebuilds;
-        p->index_counter = index_counter; p->total_time = total_time; p->last_dt = last_dt; p->delta_x = delta_x;
+    // Queue one step of the while loop at src/SPHCellList.jl:742-802 with every per-step decision on the device
+    // (k_step_control): Δx, Δt, the loop bound and the rebuild criterion.  Kernels of a cancelled step return at once.
+    void enqueue_step() {
+        Ev ev = begin_phase(PH_TIMESTEP);
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, red_d, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
+        end_phase(ev);
+        progress_motion(0.0, ctrl_d);                                          // :765
+        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_d);                    // :772
+        ForceParams<T> P1 = force_params(iA, iA, iH, 0.0); P1.ctrl = ctrl_d;
+        Ev e1 = begin_phase(PH_PASS1);
+        launch_force<PASS_PREDICTOR>(P1);                                      // :774-781
+        end_phase(e1);
+        progress_motion(0.0, ctrl_d);                                          // :787
+        ForceParams<T> P2 = force_params(iH, iA, iB, 0.0); P2.ctrl = ctrl_d;
+        Ev e2 = begin_phase(PH_PASS2);
+        launch_force<PASS_CORRECTOR>(P2);                                      // :789-798
+        end_phase(e2);
+        std::swap(iA, iB);
     }
 
     void advance(double t_target, int64_t max_steps, sphmi_progress* out) override {
@@ -486,9 +475,44 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(cfg.device));
         delta_x = 1.0 + cfg.h;                                                // :739
         int64_t steps = 0;
+        StepCtrl c{};
+        c.delta_x = delta_x; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
+        c.max_steps = max_steps; c.last_dt = last_dt;
         try {
-            while (total_time <= t_target && (max_steps < 0 || steps < max_steps)) { step_once(); ++steps; }
-            sync_and_collect();
+            *ctrl_h = c;
+            HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+            for (;;) {
+                const int a0 = iA, b0 = iB;
+                const int64_t before = steps;
+                int batch = kBatch;
+                if (max_steps >= 0) batch = (int)std::min<int64_t>(batch, std::max<int64_t>(max_steps - steps, 1));
+                for (int k = 0; k < batch; ++k) { enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
+                HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
+                sync_and_collect();
+                c = *ctrl_h;
+                steps = c.steps_done;
+                const int64_t executed = steps - before;
+                iteration += executed - batch;                                    // what really ran
+                // the state sets rotate once per EXECUTED step
+                iA = (executed & 1) ? b0 : a0; iB = (executed & 1) ? a0 : b0;
+                if (executed > 0) stepped = true;
+                total_time = c.total_time; last_dt = c.last_dt; delta_x = c.delta_x;
+                if (c.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
+                if (c.error) {
+                    char buf[160];
+                    snprintf(buf, sizeof(buf), "non-positive or NaN dt (%g) at iteration %lld (visc %g, |a|max %g, Δx %g)",
+                             c.dt, (long long)iteration, c.last_visc, c.last_amax, c.delta_x);
+                    throw EngineError(SPHMI_ERR_NUMERIC, buf);
+                }
+                if (c.need_rebuild) {                                             // :758-762
+                    rebuild();
+                    c.delta_x = 0.0; c.need_rebuild = 0; delta_x = 0.0;           // resume stays set: the queued step re-uses its Δt
+                    *ctrl_h = c;
+                    HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+                    continue;
+                }
+                if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) break;
+            }
         } catch (...) { fill(out, steps); throw; }
         fill(out, steps);
     }

@@ -61,6 +61,54 @@ enum { kViscZero = 0, kViscArtificial = 1, kViscLaminar = 2, kViscLaminarSPS = 3
 enum { kDdtNone = 0, kDdtZeroGravityLinear = 1, kDdtLinear = 2, kDdtComplex = 3 };
 constexpr int kModelDefault = kViscArtificial | (kDdtLinear << 4), kModelGeneric = -1;
 
+// Device-side step control (Engine::advance): everything the while loop of src/SPHCellList.jl:742-802 decides per
+// step lives here, so the host can queue several steps without a round trip and look at the flags afterwards.
+struct StepCtrl {
+    double dt, dt2;            // Δt of the step being executed
+    double delta_x;            // Δx accumulator of update_delta_x! (:706-724)
+    double total_time;         // SimMetaData.TotalTime
+    double t_step_start;       // TotalTime at the start of the current step (ProgressMotion's clock)
+    double t_target;           // loop bound: `while TotalTime <= t_target`
+    double last_visc, last_amax;
+    double last_dt;            // Δt of the last step that was actually executed (SimMetaData.CurrentTimeStep)
+    long long steps_done, max_steps;
+    int active;                // 1: the kernels of this step run; 0: they return at once
+    int need_rebuild;          // Δx ≥ h: the host rebuilds the cell list, clears the flag and re-queues the step
+    int resume;                // the step after a rebuild re-uses the Δt already computed
+    int stop;                  // TotalTime > t_target or max_steps reached
+    int error;                 // 1: non-positive / NaN Δt, 2: non-positive density
+    int pad;
+};
+
+// one thread: the per-step decisions of Δt (src/TimeStepping.jl:30-43) and update_delta_x! on the reduction slots the
+// previous corrector filled (bit patterns of non-negative values)
+template <class T>
+__global__ void k_step_control(unsigned long long* red, StepCtrl* c, double h, double c0, double CFL) {
+    if (c->stop || c->error || c->need_rebuild) { c->active = 0; return; }
+    if (!c->resume) {
+        if (!(c->total_time <= c->t_target) || (c->max_steps >= 0 && c->steps_done >= c->max_steps)) { c->stop = 1; c->active = 0; return; }
+        auto dec = [](unsigned long long b) -> double {
+            if constexpr (sizeof(T) == 4) return (double)__uint_as_float((unsigned)b); else return __longlong_as_double((long long)b);
+        };
+        if (red[3]) { c->error = 2; c->active = 0; return; }
+        const double maxdisp = sqrt(dec(red[0])), visc = dec(red[1]), amax = sqrt(dec(red[2]));
+        c->delta_x += 4.0 * maxdisp;
+        const double dt1 = sqrt(h / amax), dt2 = h / (c0 + visc);
+        const double dt = CFL * (dt1 < dt2 ? dt1 : dt2);
+        c->last_visc = visc; c->last_amax = amax;
+        c->dt = dt; c->dt2 = dt * 0.5;
+        if (!(dt > 0.0) || dt != dt || c->delta_x != c->delta_x) { c->error = 1; c->active = 0; return; }
+        if (c->delta_x >= h) { c->need_rebuild = 1; c->resume = 1; c->active = 0; return; }
+    }
+    c->resume = 0;
+    red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0;
+    c->t_step_start = c->total_time;
+    c->total_time += c->dt;                                 // UpdateMetaData!, :679-685 (nothing reads it before the
+    c->steps_done += 1;                                     // next control kernel except through t_step_start)
+    c->last_dt = c->dt;
+    c->active = 1;
+}
+
 template <class T>
 struct ForceParams {
     using V4 = typename Vec4<T>::type;
@@ -75,6 +123,7 @@ struct ForceParams {
     const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
     const uint8_t* type;
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
+    const StepCtrl* ctrl;      // device-side step control (null: dt / dt2 below are used, the kernel always runs)
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
@@ -225,6 +274,8 @@ __device__ __forceinline__ void wave_sync() {
 template <class T, int D, int PASS, int MODEL, int WPT>
 __global__ void __launch_bounds__(kWave * WPT)
 k_neighbor_force(const ForceParams<T> P) {
+    if (P.ctrl && !P.ctrl->active) return;                 // a queued step that the control kernel cancelled
+    const T step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt, step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
     const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;
     const int ddt = MODEL >= 0 ? ((MODEL >> 4) & 15) : P.ddt;
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
@@ -597,9 +648,9 @@ k_neighbor_force(const ForceParams<T> P) {
         // HalfTimeStep (src/SPHCellList.jl:624-638) + LimitDensityAtBoundary! (SimulationEquations.jl:36-42)
         if constexpr (D == 3) az += P.g * gf; else ay += P.g * gf;
         V4 o0, o1;
-        o0.x = xa + q1.x * P.dt2 * ml; o0.y = ya + q1.y * P.dt2 * ml; o0.z = za + q1.z * P.dt2 * ml;
-        o1.x = q1.x + ax * P.dt2 * ml; o1.y = q1.y + ay * P.dt2 * ml; o1.z = q1.z + az * P.dt2 * ml;
-        T rho_h = rho_a + drho * P.dt2;
+        o0.x = xa + q1.x * step_dt2 * ml; o0.y = ya + q1.y * step_dt2 * ml; o0.z = za + q1.z * step_dt2 * ml;
+        o1.x = q1.x + ax * step_dt2 * ml; o1.y = q1.y + ay * step_dt2 * ml; o1.z = q1.z + az * step_dt2 * ml;
+        T rho_h = rho_a + drho * step_dt2;
         if (!fluid_a && rho_h < P.rho0) rho_h = P.rho0;
         o0.w = rho_h;
         o1.w = s_a;                         // ρⁿ·s travels with the half-step stream
@@ -611,10 +662,10 @@ k_neighbor_force(const ForceParams<T> P) {
         const V4 s1 = P.a1[ac];
         T rho_n = absT(s0.w);
         if (!fluid_a && rho_n < P.rho0) rho_n = P.rho0;
-        const T epsi = -(drho / rho_a) * P.dt;
+        const T epsi = -(drho / rho_a) * step_dt;
         const T rho_new = rho_n * ((T(2) - epsi) / (T(2) + epsi));
         if constexpr (D == 3) az += P.g * gf; else ay += P.g * gf;
-        const T adx = ax * P.dt * ml, ady = ay * P.dt * ml, adz = az * P.dt * ml;
+        const T adx = ax * step_dt * ml, ady = ay * step_dt * ml, adz = az * step_dt * ml;
         V4 o0, o1, oa;
         o1.x = s1.x + adx; o1.y = s1.y + ady; o1.z = s1.z + adz;
         T sx = 0, sy = 0, sz = 0;
@@ -622,13 +673,13 @@ k_neighbor_force(const ForceParams<T> P) {
             // FullTimeStep with PlanarShifting, src/SPHCellList.jl:654-677 (A = 2, A_FST = 0, A_FSM = D)
             const T A_FSC = divr / T(D);
             if (!(A_FSC < T(0))) {
-                const T k = -A_FSC * T(2) * P.h * fast_sqrt(o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * P.dt;
+                const T k = -A_FSC * T(2) * P.h * fast_sqrt(o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * step_dt;
                 sx = k * gcx; sy = k * gcy; sz = k * gcz;
             }
         }
-        o0.x = s0.x + (((o1.x + (o1.x - adx)) / T(2)) * P.dt + sx) * ml;
-        o0.y = s0.y + (((o1.y + (o1.y - ady)) / T(2)) * P.dt + sy) * ml;
-        o0.z = s0.z + (((o1.z + (o1.z - adz)) / T(2)) * P.dt + sz) * ml;
+        o0.x = s0.x + (((o1.x + (o1.x - adx)) / T(2)) * step_dt + sx) * ml;
+        o0.y = s0.y + (((o1.y + (o1.y - ady)) / T(2)) * step_dt + sy) * ml;
+        o0.z = s0.z + (((o1.z + (o1.z - adz)) / T(2)) * step_dt + sz) * ml;
         o0.w = fluid_a ? rho_new : -rho_new;
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;

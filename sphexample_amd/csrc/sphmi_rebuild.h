@@ -351,6 +351,7 @@ template <class T> struct MdbcParams {
     T H_inv;               // the cell hash stays in the handle's precision (same cells as the particles)
     double H2, h_inv, h, alphaD, m0, rho0, eta2;
     int kernel;            // 0 WendlandC2, 1 CubicSpline
+    const StepCtrl* ctrl;  // device-side step control (null: always run)
 };
 
 template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22) {
@@ -364,6 +365,7 @@ template <class T, int D>
 __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
     constexpr int P = D + 1;
     using R = double;
+    if (M.ctrl && !M.ctrl->active) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M.N) return;
     const auto gq = M.ghost[i];
@@ -565,8 +567,9 @@ struct MotionTable {
 template <class T>
 __global__ void __launch_bounds__(256) k_progress_motion(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
                                                          const uint8_t* type, const unsigned long long* group, int N,
-                                                         MotionTable M, double total_time, double dt2) {
+                                                         MotionTable M, double total_time, double dt2, const StepCtrl* ctrl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ctrl) { if (!ctrl->active) return; total_time = ctrl->t_step_start; dt2 = ctrl->dt2; }
     if (i >= N || (type[i] & 0x3F) != 3) return;
     const unsigned long long g = group[i];
     for (int m = 0; m < M.n; ++m) {
