@@ -134,12 +134,16 @@ int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
  * Output without stalling the run: sphmi_download_begin snapshots the requested fields on the
  * device in stream order and starts the device→host copies on a second stream; the caller may call sphmi_advance
  * right away and must not touch the host arrays until sphmi_download_end returns.  sphmi_download = begin + end.
- * Host arrays that are handed in repeatedly are page-locked by the library.
+ * sphmi_host_register page-locks a host array the caller will hand in again and again (the fields of the
+ * StructArray live for the whole run): it removes the runtime's staging copy where the platform needs one.
+ * The caller must unregister (or destroy the handle) before freeing the array.
  */
 int sphmi_download_begin(sphmi_handle* h,
                          void* position, void* velocity, void* acceleration, void* density, void* pressure,
                          int64_t* id, uint8_t* type, uint64_t* group_marker, void* ghost_points, int64_t* cells);
 int sphmi_download_end(sphmi_handle* h);
+int sphmi_host_register(sphmi_handle* h, void* ptr, int64_t bytes);
+int sphmi_host_unregister(sphmi_handle* h, void* ptr);
 
 /*
  * StoreKernelOutput (src/SPHCellList.jl:106-116): Kernel[i] = Σⱼ Wᵢⱼ and KernelGradient[i] = Σⱼ ∇ᵢWᵢⱼ of the last

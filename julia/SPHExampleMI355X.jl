@@ -104,6 +104,10 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
         output = SetupVTKOutput(SimMetaData, SimParticles, SimKernel, D)          # :846
         SimMetaData.OutputIterationCounter = 1                                     # :849
         output.save_particles(SimMetaData.OutputIterationCounter)
+        # the StructArray's columns receive every output: page-lock them once (released by sphmi_destroy)
+        for col in (P.Position, P.Velocity, P.Acceleration, P.Density, P.Pressure, P.ID, P.GroupMarker)
+            ccall((:sphmi_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), h, pointer(col), sizeof(col))
+        end
         prog = SphmiProgress()
         cells = Vector{Int64}(undef, N * D)
         while true                                                                 # :881

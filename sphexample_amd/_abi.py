@@ -196,8 +196,7 @@ class Backend:
 
     def download_into(self, p, begin_only: bool = False) -> None:
         """Write the engine state back into the arrays of a SimParticles IN PLACE (what the reference's loop leaves in
-        its StructArray).  The same host arrays are used at every output, so the engine page-locks them the second
-        time it sees them and the copies run at PCIe speed."""
+        its StructArray).  Call pin(p) once when the same arrays receive every output."""
         order = ("Position", "Velocity", "Acceleration", "Density", "Pressure", "ID", "Type", "GroupMarker",
                  "GhostPoints", "Cells")
         want = {"Position": self._ft, "Velocity": self._ft, "Acceleration": self._ft, "Density": self._ft,
@@ -225,6 +224,27 @@ class Backend:
         if self._has("download_end"):
             self._fn("download_end").argtypes = [C.c_void_p]
             self._check(self._fn("download_end")(self._h))
+
+    def pin(self, p) -> None:
+        """Page-lock the field arrays of a SimParticles that will receive every output (engine backend only).  The
+        arrays must stay alive until unpin() / close()."""
+        if not self._has("host_register"):
+            return
+        self._fn("host_register").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self._pinned = getattr(self, "_pinned", [])
+        for k in ("Position", "Velocity", "Acceleration", "Density", "Pressure", "ID", "Type", "GroupMarker", "GhostPoints", "Cells"):
+            a = getattr(p, k, None)
+            if isinstance(a, np.ndarray) and a.flags.c_contiguous and a.nbytes:
+                self._check(self._fn("host_register")(self._h, _ptr(a), a.nbytes))
+                self._pinned.append(a)
+
+    def unpin(self) -> None:
+        if not self._has("host_unregister"):
+            return
+        self._fn("host_unregister").argtypes = [C.c_void_p, C.c_void_p]
+        for a in getattr(self, "_pinned", []):
+            self._fn("host_unregister")(self._h, _ptr(a))
+        self._pinned = []
 
     def _has(self, name: str) -> bool:
         return hasattr(self._lib, self._p + name)

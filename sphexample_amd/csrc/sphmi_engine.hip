@@ -52,6 +52,8 @@ struct EngineBase {
     virtual void download(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
     virtual void download_begin(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
     virtual void download_end() = 0;
+    virtual void host_register(void* p, size_t bytes) = 0;
+    virtual void host_unregister(void* p) = 0;
     virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
     virtual void download_kernel_output(void* kernel, void* kernel_gradient) = 0;
     virtual void unique_cells(int64_t* out, int64_t cap, int64_t* n) = 0;
@@ -583,18 +585,22 @@ struct Engine final : EngineBase {
 
     // ---- output side: device-packed fields, one copy per field ----------------------------------
     char* out_arena = nullptr; size_t out_arena_bytes = 0;
-    std::vector<std::pair<void*, size_t>> host_seen, host_pinned;
-    // A host array handed in for the second time is page-locked (the StructArray of the caller lives for the
-    // whole run; temporaries are not worth the registration), so its copies run at PCIe speed.
-    void maybe_pin(void* p, size_t bytes) {
-        for (auto& e : host_pinned) if (e.first == p && e.second >= bytes) return;
-        for (auto& e : host_seen) if (e.first == p && e.second == bytes) {
-            if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) host_pinned.emplace_back(p, bytes);
-            else (void)hipGetLastError();
+    std::vector<std::pair<void*, size_t>> host_pinned;
+    // Page-locking is the CALLER's decision (sphmi_host_register): only the caller knows that an array outlives the
+    // handle's use of it — a registration that survived a free + reuse of the address range would be a stale mapping.
+    void host_register(void* p, size_t bytes) override {
+        if (!p || !bytes) return;
+        for (auto& e : host_pinned) if (e.first == p) return;
+        HC(hipSetDevice(cfg.device));
+        if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) host_pinned.emplace_back(p, bytes);
+        else { (void)hipGetLastError(); throw EngineError(SPHMI_ERR_DEVICE, "sphmi_host_register: hipHostRegister failed"); }
+    }
+    void host_unregister(void* p) override {
+        for (size_t k = 0; k < host_pinned.size(); ++k) if (host_pinned[k].first == p) {
+            (void)hipHostUnregister(p);
+            host_pinned.erase(host_pinned.begin() + (long)k);
             return;
         }
-        if (host_seen.size() > 64) host_seen.clear();
-        host_seen.emplace_back(p, bytes);
     }
     hipStream_t copy_stream = nullptr; hipEvent_t ev_packed = nullptr; bool download_pending = false;
     // begin: snapshot every requested field into the arena IN STREAM ORDER (so later steps cannot disturb it), then
@@ -634,7 +640,6 @@ struct Engine final : EngineBase {
         HC(hipStreamWaitEvent(copy_stream, ev_packed, 0));
         auto copy = [&](void* dst, const void* src, size_t bytes) {
             if (!dst) return;
-            maybe_pin(dst, bytes);
             HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, copy_stream));
         };
         copy(position, o.pos, nd * sizeof(H)); copy(velocity, o.vel, nd * sizeof(H));
@@ -994,6 +999,8 @@ int sphmi_download_begin(sphmi_handle* h, void* position, void* velocity, void* 
                                         ghost_points, cells));
 }
 int sphmi_download_end(sphmi_handle* h) { SPHMI_GUARD(h, h->e->download_end()); }
+int sphmi_host_register(sphmi_handle* h, void* ptr, int64_t bytes) { SPHMI_GUARD(h, h->e->host_register(ptr, (size_t)bytes)); }
+int sphmi_host_unregister(sphmi_handle* h, void* ptr) { SPHMI_GUARD(h, h->e->host_unregister(ptr)); }
 int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient) {
     SPHMI_GUARD(h, h->e->download_kernel_output(kernel, kernel_gradient));
 }

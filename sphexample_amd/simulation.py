@@ -37,6 +37,8 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
     eng = (backend_factory or Engine)(cfg)
     eng.upload_particles(SimParticles)
     eng.set_motions(SimGeometry)                      # MotionDefinition, src/SPHCellList.jl:846-850
+    if on_output:
+        eng.pin(SimParticles)                          # the same arrays receive every output
     eng.set_clock(SimMetaData.Iteration, SimMetaData.TotalTime)
     time_steps: List[float] = []
     SimMetaData.OutputIterationCounter = 1                                       # :849
@@ -71,5 +73,6 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
         if done:
             eng.download_into(SimParticles)
             break
+    eng.unpin()
     eng.close()
     return time_steps

@@ -456,20 +456,23 @@ def test_cutoff_other_than_2h(dam_break_2d, k, fb, tol):
 
 def test_download_into_is_in_place_and_repeatable(dam_break_2d_mdbc):
     """The output path of RunSimulation (src/SPHCellList.jl:891-894 reads the StructArray the loop mutated): the engine
-    writes every field straight into the caller's arrays; the second and later calls go through page-locked copies."""
+    writes every field straight into the caller's arrays, page-locked on request (sphmi_host_register)."""
     from sphexample_amd.engine import make_engine
     p, s = dam_break_2d_mdbc
     eng = make_engine(p, s, device_float_bytes=8)
     eng.advance(1e9, max_steps=5)
     q = p.copy()
     ptrs = {k: getattr(q, k).ctypes.data for k in ("Position", "Velocity", "Density", "Pressure", "ID", "Cells", "GhostPoints")}
-    for _ in range(3):
+    for it in range(3):
+        if it == 1:
+            eng.pin(q)                           # page-locked from here on
         eng.download_into(q)
         assert all(getattr(q, k).ctypes.data == v for k, v in ptrs.items())
         d = eng.download()
         for k, v in d.items():
             np.testing.assert_array_equal(getattr(q, k), v, err_msg=k)
         eng.advance(1e9, max_steps=2)
+    eng.unpin()
     assert (q.Density > 900).all() and np.abs(q.GhostPoints).sum() > 0 and (q.Pressure != 0).any()
 
 

@@ -14,6 +14,8 @@ d = e.download(("Position", "Velocity", "Density", "Pressure", "ID", "Type")); t
 print(f"N={len(p)}: 25 steps {1e3*(t1-t0):.1f} ms; download(all fields) {1e3*(t2-t1):.1f} ms; download(6 fields) {1e3*(t3-t2):.1f} ms")
 q = p.copy()
 for k in range(4):
+    if k == 2:
+        e.pin(q); print('pinned')
     t = time.perf_counter(); e.download_into(q); print(f"download_into #{k}: {1e3 * (time.perf_counter() - t):.1f} ms")
 # asynchronous output: begin → advance → end
 t = time.perf_counter(); e.download_into_begin(q); tb = time.perf_counter() - t
