@@ -10,20 +10,23 @@
 // reference (src/SPHCellList.jl:168-217, 268-317, 367-381, 624-652, 706-724;
 // src/SimulationEquations.jl:9-42; src/TimeStepping.jl:24-46) with ONE launch per pass.
 //
-// Mapping (one TILE = 64 consecutive sorted target particles = one wave = one workgroup):
+// Mapping (one TILE = 64 consecutive sorted target particles = one workgroup of 1, 2 or 4 waves; which tile a
+// block takes comes from the tile schedule built with the cell list — sphmi_rebuild.h):
 //   phase 1  "who is within H".  For each of the 3^(D-1) cell rows around the tile the three x-adjacent
 //            cells of every target are one contiguous particle range (x is the fastest sort axis); the
 //            union over the tile is scanned in 64-candidate chunks, one candidate per lane, loaded
-//            coalesced.  fp32: the 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores
-//            (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain); every lane ends up with the results of ITS
-//            target, packs their sign bits with v_alignbit and holds a 64-bit accept mask per chunk.
-//            fp64 handles use the same fp32 matrix (the mask only has to be a superset; the pair loop is exact).
-//   phase 2  "pair physics".  The masks of the last few rows sit in an LDS ring; every lane walks the set
-//            bits of its own masks at its own pace, gathers the accepted neighbour packets, redoes the
-//            exact r² ≤ H² test and accumulates dρ/dt and acceleration — no divergence on the accept
-//            branch, no atomics, each output written once.
-//   epilogue predictor or corrector fused in; wave-level max-reductions for Δt / Δx.
-// Measured history and the experiments behind these choices: DESIGN.md §kernels.
+//            coalesced.  The 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores
+//            (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain) in tile-local coordinates, for fp32 AND fp64 handles
+//            (the mask only has to be a superset; the pair loop is exact); every lane ends up with the results
+//            of ITS target, packs their sign bits with v_alignbit, clears the bits outside its own three cells
+//            and pushes each non-empty 32-candidate half as { mask, index of bit 0 } onto its private LDS queue.
+//   phase 2  "pair physics".  A lane fetches its next non-empty mask the moment the current one is used up,
+//            walks the set bits, gathers the two neighbour packets through buffer loads and accumulates the
+//            pair terms — no intra-wave synchronisation, no iterations on empty masks, no atomics, each output
+//            written once.  Phase 1 resumes when some lane's queue is full.
+//   epilogue predictor or corrector fused in; wave-level max-reductions for Δt / Δx (consumed on the device by
+//            k_step_control).
+// Measured history and the experiments behind these choices: DESIGN.md §4.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,17 +39,8 @@ template <> struct Vec4<float>  { using type = float4;  };
 template <> struct Vec4<double> { using type = double4; };
 
 constexpr int kWave = 64;
-#ifndef SPHMI_ABL_NO_CONSUME
-#define SPHMI_ABL_NO_CONSUME 0
-#endif
 #ifndef SPHMI_SEQ_BLOCKS
 #define SPHMI_SEQ_BLOCKS 1
-#endif
-#ifndef SPHMI_ABL_GATHER
-#define SPHMI_ABL_GATHER 0
-#endif
-#ifndef SPHMI_ABL_NO_P2
-#define SPHMI_ABL_NO_P2 0
 #endif
 #ifndef SPHMI_QUEUE
 #define SPHMI_QUEUE 8           // per-lane queue of non-empty 32-candidate accept masks (entries; power of two)
@@ -487,9 +481,6 @@ k_neighbor_force(const ForceParams<T> P) {
     };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
-    // The masks of the last RB cell rows live in an LDS ring.  Lanes consume at their own pace: a lane
-    // with few neighbours in the old rows runs ahead into the newer ones instead of idling, and a ring
-    // row is only recycled once EVERY lane is through with it.
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -505,10 +496,6 @@ k_neighbor_force(const ForceParams<T> P) {
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
     // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
     auto run_pairs = [&](const int keep, const bool drain) {
-#if SPHMI_ABL_NO_CONSUME
-        ax += T(s_q[0].x & 1); rpos = wpos;
-        return;
-#endif
         auto any_owes = [&]() -> bool {
             bool owes = (wpos - rpos) > keep;
             if (drain) owes |= (cm != 0);
@@ -528,19 +515,9 @@ k_neighbor_force(const ForceParams<T> P) {
             if (cm != 0) {
                 const int j = cbase + __builtin_ctz(cm);
                 cm &= cm - 1;
-#if SPHMI_ABL_NO_P2
-                ax += T(j);
-#else
-#if SPHMI_ABL_GATHER == 1
-                const V4 n0 = gather_packet(rs0, j, T()); const V4 n1 = q1;
-#elif SPHMI_ABL_GATHER == 2
-                const V4 n0 = q0; const V4 n1 = q1;
-#else
                 const V4 n0 = gather_packet(rs0, j, T());
                 const V4 n1 = gather_packet(rs1, j, T());
-#endif
                 pair(j, n0, n1);
-#endif
             }
             go = any_owes();
         }
