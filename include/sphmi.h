@@ -245,6 +245,22 @@ int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev);
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt);            /* 1: predictor pass, 2: corrector   */
 /* part 0 = whole pass (same as sphmi_dd_pass), 1 = interior tiles, 2 = slab-edge tiles (completes the pass) */
 int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part);
+/* Device-side step control for the slab driver (the k_step_control of sphmi_advance, fed with the MAX-allreduced
+ * slots): init once per advance, then per step  reductions_dev → allreduce → step_control → passes (dt argument
+ * ignored); sphmi_dd_ctrl_sync waits for everything queued and reports the flags; after a collective rebuild call
+ * sphmi_dd_ctrl_resume (the pending step re-uses its Δt). */
+typedef struct sphmi_dd_control {
+    int64_t steps_done;       /* steps executed since sphmi_dd_ctrl_init                                  */
+    double  total_time, last_dt, delta_x;
+    int32_t need_rebuild;     /* Δx ≥ h: rebuild (collectively), resume, keep queueing                     */
+    int32_t stop;             /* loop bound reached                                                        */
+    int32_t error;            /* 1: non-positive / NaN Δt, 2: non-positive density                         */
+    int32_t reserved;
+} sphmi_dd_control;
+int sphmi_dd_ctrl_init(sphmi_handle* h, double delta_x, double t_target, int64_t max_steps);
+int sphmi_dd_step_control(sphmi_handle* h, void* red4_dev);
+int sphmi_dd_ctrl_sync(sphmi_handle* h, sphmi_dd_control* out);
+int sphmi_dd_ctrl_resume(sphmi_handle* h);
 int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id,
                             int64_t* n_out);                          /* host fp64 arrays, owned only      */
 int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out);

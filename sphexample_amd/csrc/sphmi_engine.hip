@@ -81,6 +81,10 @@ struct EngineBase {
     virtual void dd_reductions_dev(void* out4_dev) = 0;
     virtual void dd_pass(int which, double dt, int part) = 0;
     virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) = 0;
+    virtual void dd_ctrl_init(double delta_x, double t_target, int64_t max_steps) = 0;
+    virtual void dd_step_control(void* red4_dev) = 0;
+    virtual void dd_ctrl_sync(sphmi_dd_control* out) = 0;
+    virtual void dd_ctrl_resume() = 0;
     virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) = 0;
 };
 
@@ -813,8 +817,47 @@ struct Engine final : EngineBase {
     // into a caller-owned device buffer of 4 × int64, then reset — no host round trip before the allreduce
     void dd_reductions_dev(void* out4_dev) override {
         HC(hipSetDevice(cfg.device));
-        HC(hipMemcpyAsync(out4_dev, red_d, 4 * 8, hipMemcpyDeviceToDevice, stream));
-        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+        hipLaunchKernelGGL(k_take_reductions, dim3(1), dim3(64), 0, stream, red_d, (unsigned long long*)out4_dev);
+        HC(hipGetLastError());
+    }
+    // ---- device-side step control for the slab driver: same k_step_control as Engine::advance, fed with the
+    // MAX-allreduced reduction slots, so the host looks at the flags once per batch of queued steps --------------
+    bool dd_ctrl_on = false; int dd_a0 = 0, dd_b0 = 0; int64_t dd_steps_at_sync = 0;
+    void dd_ctrl_init(double dx0, double t_target, int64_t max_steps) override {
+        HC(hipSetDevice(cfg.device));
+        StepCtrl c{};
+        c.delta_x = dx0; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
+        c.max_steps = max_steps; c.last_dt = last_dt;
+        *ctrl_h = c;
+        HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+        dd_ctrl_on = true; dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = 0;
+    }
+    void dd_step_control(void* red4_dev) override {
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, (unsigned long long*)red4_dev, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
+        HC(hipGetLastError());
+    }
+    void dd_ctrl_sync(sphmi_dd_control* out) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
+        sync_and_collect();
+        const StepCtrl c = *ctrl_h;
+        const int64_t executed = c.steps_done - dd_steps_at_sync;
+        // the state sets rotate once per EXECUTED step (the host rotated them once per QUEUED step)
+        iA = (executed & 1) ? dd_b0 : dd_a0; iB = (executed & 1) ? dd_a0 : dd_b0;
+        dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = c.steps_done;
+        iteration += executed; total_time = c.total_time; last_dt = c.last_dt;
+        if (executed > 0) stepped = true;
+        if (out) {
+            out->steps_done = c.steps_done; out->total_time = c.total_time; out->last_dt = c.last_dt; out->delta_x = c.delta_x;
+            out->need_rebuild = c.need_rebuild; out->stop = c.stop; out->error = c.error; out->reserved = 0;
+        }
+    }
+    void dd_ctrl_resume() override {
+        HC(hipSetDevice(cfg.device));
+        ctrl_h->delta_x = 0.0; ctrl_h->need_rebuild = 0;          // `resume` stays set: the queued step re-uses its Δt
+        HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+        dd_a0 = iA; dd_b0 = iB;                                  // the rebuild may have swapped the sets
     }
     void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) override {
         if (axis < 0 || axis >= D) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_set_slab: axis out of range");
@@ -824,7 +867,8 @@ struct Engine final : EngineBase {
     void dd_pass(int which, double dt, int part) override {
         HC(hipSetDevice(cfg.device));
         if (which != 1 && which != 2) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_pass: which must be 1 or 2");
-        const ForceParams<T> P = which == 1 ? force_params(iA, iA, iH, dt) : force_params(iH, iA, iB, dt);
+        ForceParams<T> P = which == 1 ? force_params(iA, iA, iH, dt) : force_params(iH, iA, iB, dt);
+        if (dd_ctrl_on) P.ctrl = ctrl_d;
         if (part == 0 || part == 1) {
             Ev e = begin_phase(which == 1 ? PH_PASS1 : PH_PASS2);
             if (which == 1) launch_force<PASS_PREDICTOR>(P, 0); else launch_force<PASS_CORRECTOR>(P, 0);
@@ -837,8 +881,7 @@ struct Engine final : EngineBase {
         }
         if (which == 2 && part != 1) {
             std::swap(iA, iB);
-            stepped = true;
-            iteration += 1; last_dt = dt; total_time += dt;
+            if (!dd_ctrl_on) { stepped = true; iteration += 1; last_dt = dt; total_time += dt; }   // else: dd_ctrl_sync
         }
     }
     void dd_download_owned(void* pos, void* vel, void* rho, int64_t* ids, int64_t* n_out) override {
@@ -980,6 +1023,10 @@ int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev) { SPHMI_GUARD(h, h-
 int sphmi_dd_reductions(sphmi_handle* h, double* out8) { SPHMI_GUARD(h, h->e->dd_reductions(out8)); }
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, 0)); }
 int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, part)); }
+int sphmi_dd_ctrl_init(sphmi_handle* h, double delta_x, double t_target, int64_t max_steps) { SPHMI_GUARD(h, h->e->dd_ctrl_init(delta_x, t_target, max_steps)); }
+int sphmi_dd_step_control(sphmi_handle* h, void* red4_dev) { SPHMI_GUARD(h, h->e->dd_step_control(red4_dev)); }
+int sphmi_dd_ctrl_sync(sphmi_handle* h, sphmi_dd_control* out) { SPHMI_GUARD(h, h->e->dd_ctrl_sync(out)); }
+int sphmi_dd_ctrl_resume(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_ctrl_resume()); }
 int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi, int has_lower_neighbour, int has_upper_neighbour) {
     SPHMI_GUARD(h, h->e->dd_set_slab(axis, col_lo, col_hi, has_lower_neighbour, has_upper_neighbour));
 }

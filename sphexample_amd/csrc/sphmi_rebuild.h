@@ -557,6 +557,12 @@ __global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::typ
     }
 }
 
+// the four reduction slots → a caller-owned buffer, slots reset (one launch instead of a copy and a fill)
+__global__ void k_take_reductions(unsigned long long* red, unsigned long long* out) {
+    const int i = threadIdx.x;
+    if (i < 4) { out[i] = red[i]; red[i] = 0; }
+}
+
 // ProgressMotion, src/SPHCellList.jl:575-596: particles of Type Moving whose GroupMarker has a MotionDetails get
 // Velocity = v·dir·ShouldMove and Position += Velocity·dt/2 (state set A, in place).
 struct MotionTable {

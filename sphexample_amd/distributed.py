@@ -18,7 +18,8 @@ only collective in the step is one MAX-allreduce of four scalars that makes dt a
 bit-identical on all ranks.
 
 Per step (mirrors ``Engine::step_once`` in csrc/sphmi_engine.hip):
-    reductions → allreduce(MAX) → Δx, dt → [rebuild: migrate, re-ghost, sort] →
+    reductions → allreduce(MAX) → k_step_control on the device (Δx, dt, rebuild / stop flags; the host looks at
+    them once per batch of 8 queued steps) → [rebuild: migrate, re-ghost, sort] →
     halo(state A) ‖ predictor on interior tiles → predictor on slab-edge tiles →
     halo(half-step state H) ‖ corrector on interior tiles → corrector on slab-edge tiles
 Ghost copies are ordinary entries of the rank's sorted particle array (type bits 0x80 / 0x40); the
@@ -34,7 +35,7 @@ k-th ghost slot of the receiver and the per-step halo needs no indices on the wi
 The cuts move with the fluid: at a rebuild whose max/mean owned count exceeds 1.05 the ranks sum their column
 histograms and re-cut (every cut stays between its old neighbours, so migration remains a neighbour exchange).
 
-Known limits: static slab axis, no mDBC / moving bodies, per-step control on the host.
+Known limits: static slab axis, no mDBC / moving bodies.
 """
 from __future__ import annotations
 
@@ -230,6 +231,11 @@ class _Comm:
         return g(rl), g(rr)
 
 
+class SphmiDdControl(C.Structure):
+    _fields_ = [("steps_done", C.c_int64), ("total_time", C.c_double), ("last_dt", C.c_double), ("delta_x", C.c_double),
+                ("need_rebuild", C.c_int32), ("stop", C.c_int32), ("error", C.c_int32), ("reserved", C.c_int32)]
+
+
 class DistributedEngine:
     """Same ``advance`` / ``force_kernel_stats`` surface as ``engine.Engine``, on a slab of the domain."""
 
@@ -264,7 +270,10 @@ class DistributedEngine:
         self.lib = load_library()
         self.h = self.eng._h
         self._declare()
-        self._call("dd_set_stream", C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        # everything of this engine — kernels, torch copies, RCCL transfers — is ordered on ONE non-default stream
+        # (the legacy default stream synchronises implicitly with every blocking stream: ≈0.1 ms per step)
+        self._main = torch.cuda.Stream(device=self.device)
+        self._call("dd_set_stream", C.c_void_p(self._main.cuda_stream))
         INF = 1 << 30
         lo, hi = self.plan.cx_lo[rank], self.plan.cx_hi[rank]
         self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(lo, -INF)), C.c_int64(min(hi, INF)),
@@ -310,6 +319,10 @@ class DistributedEngine:
         L.sphmi_dd_pass.argtypes = [vp, C.c_int, C.c_double]
         L.sphmi_dd_pass_part.argtypes = [vp, C.c_int, C.c_double, C.c_int]
         L.sphmi_dd_set_slab.argtypes = [vp, C.c_int, i64, i64, C.c_int, C.c_int]
+        L.sphmi_dd_ctrl_init.argtypes = [vp, C.c_double, C.c_double, i64]
+        L.sphmi_dd_step_control.argtypes = [vp, vp]
+        L.sphmi_dd_ctrl_sync.argtypes = [vp, C.POINTER(SphmiDdControl)]
+        L.sphmi_dd_ctrl_resume.argtypes = [vp]
         L.sphmi_dd_download_owned.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i64)]
         L.sphmi_dd_progress.argtypes = [vp, C.POINTER(SphmiProgress)]
 
@@ -471,31 +484,52 @@ class DistributedEngine:
         main.wait_stream(side)                       # the next pack / the reductions need the edge tiles
 
     # -- the SimulationLoop of src/SPHCellList.jl:727-805, distributed --------------------------------
+    BATCH = 8      # steps queued between two looks at the control flags
+
     def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
+        with self.torch.cuda.stream(self._main):
+            return self._advance(t_target, max_steps)
+
+    def _advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
+        """Every per-step decision (Δx, Δt, loop bound, rebuild criterion) is taken on the device by the engine's
+        k_step_control from the MAX-allreduced reduction slots — identical on every rank — so the host queues BATCH
+        steps (reductions → allreduce → control → two passes with their halos) and synchronises once per batch; the
+        kernels of a step the control cancelled return at once, the exchanges still match on both sides."""
         cfg = self.cfg
         self.delta_x = 1.0 + cfg.h                                   # :739
         steps = 0
         red_t = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
-        while self.total_time <= t_target and (max_steps < 0 or steps < max_steps):
-            # local maxima → global maxima without leaving the device; ONE host sync per step (the .cpu())
-            self._call("dd_reductions_dev", C.c_void_p(red_t.data_ptr()))
-            bits = self.comm.allreduce_max_bits(red_t).cpu().numpy()
-            g = (bits.astype(np.uint32).view(np.float32) if cfg.device_float_bytes == 4 else bits.view(np.float64)).astype(np.float64)
-            g[3] = float(bits[3] != 0)
-            if g[3] > 0:
+        self._call("dd_ctrl_init", C.c_double(self.delta_x), C.c_double(t_target), C.c_int64(max_steps))
+        st = SphmiDdControl()
+        first = True
+        while True:
+            batch = self.BATCH if max_steps < 0 else max(1, min(self.BATCH, max_steps - steps))
+            if first:
+                batch = 1          # the loop re-arms Δx = 1 + h: the first control of a call always asks for a rebuild
+                first = False
+            for _ in range(batch):
+                # local maxima → global maxima → decisions, without leaving the device
+                self._call("dd_reductions_dev", C.c_void_p(red_t.data_ptr()))
+                self.comm.allreduce_max_bits(red_t)
+                self._call("dd_step_control", C.c_void_p(red_t.data_ptr()))
+                if self._halo is not None:          # before the first rebuild there is no ghost layer to exchange
+                    self._pass(1, 0.0)
+                    self._pass(2, 0.0)
+            self._call("dd_ctrl_sync", C.byref(st))                   # the one host synchronisation of the batch
+            steps = st.steps_done
+            self.total_time, self.last_dt, self.delta_x = st.total_time, st.last_dt, st.delta_x
+            if st.error == 2:
                 raise RuntimeError("non-positive density produced on some rank")
-            self.delta_x, dt, rebuild = step_control(g, self.delta_x, cfg)
-            if not (dt > 0.0) or np.isnan(dt):
-                raise RuntimeError(f"non-positive or NaN dt {dt} at iteration {self.iteration}")
-            if rebuild:
+            if st.error:
+                raise RuntimeError(f"non-positive or NaN dt at iteration {self.iteration + steps}")
+            if st.need_rebuild:
                 self._rebuild()
                 self.delta_x = 0.0
-            self._pass(1, dt)
-            self._pass(2, dt)
-            self.iteration += 1
-            self.last_dt = dt
-            self.total_time += dt
-            steps += 1
+                self._call("dd_ctrl_resume")
+                continue
+            if st.stop or not (self.total_time <= t_target) or (0 <= max_steps <= steps):
+                break
+        self.iteration += steps
         self.torch.cuda.current_stream(self.device).synchronize()
         prog = SphmiProgress()
         self._call("dd_progress", C.byref(prog))
@@ -507,6 +541,7 @@ class DistributedEngine:
         return self.eng.force_kernel_stats(reset)
 
     def download_owned(self) -> dict:
+        self._main.synchronize()
         n = self._count()
         pos = np.empty((n, self.D)); vel = np.empty((n, self.D)); rho = np.empty(n); ids = np.empty(n, dtype=np.int64)
         m = C.c_int64()
