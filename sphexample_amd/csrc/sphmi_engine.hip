@@ -129,7 +129,8 @@ struct Engine final : EngineBase {
     GridDesc grid{};
     bool have_grid = false, stepped = false, nonempty_pending = false;
     // timing
-    struct Ev { hipEvent_t a, b; int phase; int weight; };   // weight 0: not sampled (no events recorded)
+    struct Ev { hipEvent_t a, b; int phase; int weight; int bstep; };   // weight 0: not sampled; bstep: index of the step inside a queued batch (−1: none)
+    int batch_step = -1;
     std::vector<Ev> ev_pool, ev_pending;
     double ph_secs[PH_COUNT] = {};
     int64_t ph_calls[PH_COUNT] = {};
@@ -222,18 +223,21 @@ struct Engine final : EngineBase {
     static constexpr int kEvSample = 8;
     Ev begin_phase(int phase) {
         Ev e{};
-        e.phase = phase;
+        e.phase = phase; e.bstep = batch_step;
         e.weight = (phase == PH_REBUILD || iteration < ev_always_until) ? 1 : ((iteration % kEvSample) == 0 ? kEvSample : 0);
         if (e.weight == 0) return e;
-        if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; }
+        if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; e.bstep = batch_step; }
         else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
         HC(hipEventRecord(e.a, stream));
         return e;
     }
     void end_phase(Ev e) { if (e.weight == 0) return; HC(hipEventRecord(e.b, stream)); ev_pending.push_back(e); }
-    void collect_events() {   // call only after a stream sync
+    // call only after a stream sync.  `executed`: steps of the queued batch that really ran — the launches of the
+    // steps the device-side control cancelled returned at once and must not enter the averages
+    void collect_events(int64_t executed = INT64_MAX) {
         for (auto& e : ev_pending) {
             float ms = 0;
+            if (e.bstep >= 0 && e.bstep >= executed) { ev_pool.push_back(e); continue; }
             if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
                 // the edge-tile launch of a split pass is part of that pass: its time is added, it is not a call
                 const bool edge = e.phase == PH_PASS1_EDGE || e.phase == PH_PASS2_EDGE;
@@ -444,9 +448,9 @@ struct Engine final : EngineBase {
         end_phase(ev);
     }
 
-    void sync_and_collect() {
+    void sync_and_collect(const StepCtrl* batch_ctrl = nullptr, int64_t steps_before = 0) {
         HC(hipStreamSynchronize(stream));
-        collect_events();
+        collect_events(batch_ctrl ? batch_ctrl->steps_done - steps_before : INT64_MAX);
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
     }
 
@@ -492,9 +496,10 @@ struct Engine final : EngineBase {
                 const int64_t before = steps;
                 int batch = kBatch;
                 if (max_steps >= 0) batch = (int)std::min<int64_t>(batch, std::max<int64_t>(max_steps - steps, 1));
-                for (int k = 0; k < batch; ++k) { enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
+                for (int k = 0; k < batch; ++k) { batch_step = k; enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
+                batch_step = -1;
                 HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
-                sync_and_collect();
+                sync_and_collect(ctrl_h, before);
                 c = *ctrl_h;
                 steps = c.steps_done;
                 const int64_t executed = steps - before;
@@ -830,17 +835,19 @@ struct Engine final : EngineBase {
         c.max_steps = max_steps; c.last_dt = last_dt;
         *ctrl_h = c;
         HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
-        dd_ctrl_on = true; dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = 0;
+        dd_ctrl_on = true; dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = 0; batch_step = -1;
     }
     void dd_step_control(void* red4_dev) override {
         HC(hipSetDevice(cfg.device));
+        batch_step += 1;
         hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, (unsigned long long*)red4_dev, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
         HC(hipGetLastError());
     }
     void dd_ctrl_sync(sphmi_dd_control* out) override {
         HC(hipSetDevice(cfg.device));
         HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
-        sync_and_collect();
+        sync_and_collect(ctrl_h, dd_steps_at_sync);
+        batch_step = -1;
         const StepCtrl c = *ctrl_h;
         const int64_t executed = c.steps_done - dd_steps_at_sync;
         // the state sets rotate once per EXECUTED step (the host rotated them once per QUEUED step)

@@ -12,8 +12,19 @@ def main(path, kernel_filter=""):
     rows = db.execute(f"select {name_col}, dispatch_id, counter_name, value from counters_collection").fetchall()
     agg = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
+    # per (kernel, dispatch, counter) totals first: dispatches of cancelled steps (queued, then told by the device-side
+    # step control to return at once) show ≈0 in every counter and are left out of the averages
+    per = defaultdict(float)
     for k, d, c, v in rows:
         if kernel_filter and kernel_filter not in k:
+            continue
+        per[(k, d, c)] += v
+    peak = defaultdict(float)
+    for (k, d, c), v in per.items():
+        peak[(k, c)] = max(peak[(k, c)], v)
+    dead = {(k, d) for (k, d, c), v in per.items() if peak[(k, c)] > 0 and v < 0.05 * peak[(k, c)]}
+    for (k, d, c), v in per.items():
+        if (k, d) in dead:
             continue
         agg[k][c] += v
         disp[k].add(d)
