@@ -119,6 +119,13 @@ def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [3, 4])
+def test_more_slabs_match_single_gpu(world, request):
+    """Middle ranks have two neighbours (two ghost layers, two halo messages per pass, migration both ways)."""
+    _two_slabs("dam_break_3d_shipped", 40, 8, 1e-9, None, True, 1.05, request, world=world)
+
+
+@pytest.mark.gpu
 def test_two_slabs_with_moving_cuts(request):
     """Start from cuts that are four columns off balance: the first rebuilds move them back (particles migrate, the
     ghost layers and halo lists are rebuilt) and the result is still the single-GPU one."""
@@ -126,7 +133,7 @@ def test_two_slabs_with_moving_cuts(request):
     assert int(dd["n_recuts"]) >= 1
 
 
-def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0):
+def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0, world=2):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
     import torch.multiprocessing as mp
@@ -137,7 +144,7 @@ def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0)
     pr = ref.advance(1e9, max_steps=steps)
     r = ref.download(("Position", "Density", "ID", "Velocity"))
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(engine_worker, args=(2, _free_port(), d, case, steps, fb, axis, overlap, recut, cut_shift), nprocs=2, join=True)
+        mp.spawn(engine_worker, args=(world, _free_port(), d, case, steps, fb, axis, overlap, recut, cut_shift), nprocs=world, join=True)
         dd = dict(np.load(os.path.join(d, "dd.npz")))
     assert axis is None or int(dd["axis"]) == axis
     assert int(dd["iteration"]) == pr.iteration == steps
