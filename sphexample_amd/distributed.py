@@ -259,9 +259,16 @@ class DistributedEngine:
         mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
         self.n_total = len(particles)
         n_own = len(mine)
-        halo_guess = max(1024, int(0.25 * n_own))
-        cap = int(capacity_factor * (self.n_total / world)) + halo_guess
-        cap = max(cap, int(1.2 * n_own) + halo_guess)
+        # capacity: owned + the two ghost columns, with room for the fluid to pile up and for the cuts to move
+        # (thin slabs of small cases carry ghost layers as large as the slab itself)
+        lo_c, hi_c = int(cx.min()), int(cx.max())
+        hist = np.bincount(cx - lo_c, minlength=hi_c - lo_c + 1)
+        col = lambda c: int(hist[c - lo_c]) if lo_c <= c <= hi_c else 0          # noqa: E731
+        s_lo, s_hi = max(self.plan.cx_lo[rank], lo_c), min(self.plan.cx_hi[rank], hi_c)
+        ghosts = col(s_lo - 1) + col(s_hi + 1)
+        slack = col(s_lo - 2) + col(s_hi + 2) + 2 * int(hist.max())             # two more columns per side may arrive
+        cap = int(capacity_factor * (n_own + ghosts)) + slack + 1024
+        cap = max(cap, int(capacity_factor * (self.n_total / world)))
         cfg = make_config(cap, setup.SimConstants, setup.SimKernel, setup.SimMetaData, setup.SimViscosity,
                           setup.SimDensityDiffusion, device_float_bytes=device_float_bytes, host_float_bytes=8,
                           device=local_device)
