@@ -441,7 +441,7 @@ struct Engine final : EngineBase {
         M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
-        dim3 g((N + 63) / 64), b(64);
+        dim3 g((N + 3) / 4), b(256);               // one wave per particle, four per block
         if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
         else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
         HC(hipGetLastError());

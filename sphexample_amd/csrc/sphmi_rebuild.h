@@ -362,11 +362,15 @@ template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10,
 // boundary layers are ill-conditioned, and fp32 accumulation flipped the |det| ≥ 1e-3 branch for a handful
 // of particles of example/Dambreak2dMDBC.jl (density off by 3e-3); the kernel is a negligible part of a step.
 template <class T, int D>
-__global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
+__global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
+    // ONE WAVE per boundary particle: the lanes split the candidates of the ghost node's 3^D cells, the partial
+    // moment sums are combined with a fixed shuffle tree (deterministic), lane 0 solves.  One thread per particle
+    // ran the ≈300-candidate loop serially in fp64: 206 of the 288 µs of a DucklingMDBC step.
     constexpr int P = D + 1;
     using R = double;
     if (M.ctrl && !M.ctrl->active) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= M.N) return;
     const auto gq = M.ghost[i];
     if (gq.w == T(0)) return;
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
             if (x0 > x1) continue;
             const int row = M.g.np[0] * (cy + M.g.np[1] * cz);
             const int s = M.cstart[row + x0], e = M.cstart[row + x1 + 1];
-            for (int j = s; j < e; ++j) {
+            for (int j = s + lane; j < e; j += 64) {
                 const auto n0 = M.pk0[j];
                 if (!(n0.w > T(0))) continue;                 // ParticleType[j] == Fluid
                 const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
@@ -430,6 +434,18 @@ __global__ void __launch_bounds__(64) k_mdbc(const MdbcParams<T> M) {
                 }
             }
         }
+    // combine the 64 partial sums (xor tree: every lane ends with the same totals)
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) b[r] += __shfl_xor(b[r], o, 64);
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) A[r][c] += __shfl_xor(A[r][c], o, 64);
+        }
+    }
+    if (lane != 0) return;
     // ApplyMDBCCorrection, src/SPHCellList.jl:598-622
     R det;
     if constexpr (P == 3) {
