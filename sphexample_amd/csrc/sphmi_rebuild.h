@@ -384,19 +384,41 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
     for (int r = 0; r < P; ++r) { b[r] = 0;
 #pragma unroll
         for (int c = 0; c < P; ++c) A[r][c] = 0; }
-    const int nz = D == 3 ? 3 : 1;
-    for (int sz = 0; sz < nz; ++sz)
-        for (int sy = 0; sy < 3; ++sy) {
-            // the three x-adjacent cells of a row are one contiguous range; clip to the padded grid
-            const int cy = gc[1] + sy - 1, cz = D == 3 ? gc[2] + sz - 1 : 0;
-            if (cy < 0 || cy >= M.g.np[1] || cz < 0 || cz >= M.g.np[2]) continue;
-            int x0 = gc[0] - 1, x1 = gc[0] + 1;
-            if (x0 < 0) x0 = 0;
-            if (x1 > M.g.np[0] - 1) x1 = M.g.np[0] - 1;
-            if (x0 > x1) continue;
+    // The 3^(D-1) rows of the ghost node's neighbourhood are flattened into ONE candidate list: lane r < NROW
+    // looks up row r's range, a wave scan gives every row its offset, and every lane then strides through the
+    // whole list — a handful of independent loads per lane instead of one dependent load chain per row.
+    constexpr int NROW = D == 3 ? 9 : 3;
+    int rs = 0, rc = 0;                                    // start / count of "my" row (lanes ≥ NROW: empty)
+    if (lane < NROW) {
+        const int sy = lane % 3, sz = lane / 3;
+        // the three x-adjacent cells of a row are one contiguous range; clip to the padded grid
+        const int cy = gc[1] + sy - 1, cz = D == 3 ? gc[2] + sz - 1 : 0;
+        int x0 = gc[0] - 1, x1 = gc[0] + 1;
+        if (x0 < 0) x0 = 0;
+        if (x1 > M.g.np[0] - 1) x1 = M.g.np[0] - 1;
+        if (cy >= 0 && cy < M.g.np[1] && cz >= 0 && cz < M.g.np[2] && x0 <= x1) {
             const int row = M.g.np[0] * (cy + M.g.np[1] * cz);
-            const int s = M.cstart[row + x0], e = M.cstart[row + x1 + 1];
-            for (int j = s + lane; j < e; j += 64) {
+            rs = M.cstart[row + x0];
+            rc = M.cstart[row + x1 + 1] - rs;
+        }
+    }
+    int incl = rc;                                         // inclusive scan of the row counts
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    const int total = __shfl(incl, NROW - 1, 64);
+    const int excl = incl - rc, shift = rs - excl;         // candidate g of row r is particle g + shift_r
+        {
+            // the row table goes to SGPRs HERE, with every lane active: the compiler is free to sink the
+            // computation of `excl` / `shift` into the divergent loop below, where the lanes of the later rows
+            // may be switched off (lane ≥ total) — a readlane in there returned garbage for them
+            int ex[NROW], sf[NROW];
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) { ex[r] = __builtin_amdgcn_readlane(excl, r); sf[r] = __builtin_amdgcn_readlane(shift, r); }
+            for (int gidx = lane; gidx < total; gidx += 64) {
+                int sh = sf[0];
+#pragma unroll
+                for (int r = 1; r < NROW; ++r) sh = gidx >= ex[r] ? sf[r] : sh;
+                const int j = gidx + sh;
                 const auto n0 = M.pk0[j];
                 if (!(n0.w > T(0))) continue;                 // ParticleType[j] == Fluid
                 const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
