@@ -221,7 +221,10 @@ int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int
 int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream);   /* run on the caller's HIP stream (torch's) */
 int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity,
                     const void* acceleration, const void* density, const uint8_t* type, const int64_t* id,
-                    const uint64_t* group_marker);
+                    const uint64_t* group_marker, const void* ghost_points /* mDBC handles; else nullable */,
+                    const int64_t* upload_index /* index of each particle in the UNSPLIT particle set: the in-cell
+                                                   order after the first sort (and with it the "i" role of same-cell
+                                                   pairs) then equals the single-process one; nullable = 0 … n-1 */);
 int sphmi_dd_count(sphmi_handle* h, int64_t* n_out);                 /* live particles incl. ghosts      */
 /* Slab of this rank: cell columns col_lo … col_hi (inclusive) along `axis` (0 = x, 1 = y, 2 = z); has_* say
  * whether a neighbour rank exists on that side.  Takes effect at the next sphmi_dd_rebuild. */
@@ -245,6 +248,15 @@ int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev);
 int sphmi_dd_pass(sphmi_handle* h, int which, double dt);            /* 1: predictor pass, 2: corrector   */
 /* part 0 = whole pass (same as sphmi_dd_pass), 1 = interior tiles, 2 = slab-edge tiles (completes the pass) */
 int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part);
+/* Moving bodies and mDBC on a slab (both need the device-side step control below).
+ * sphmi_dd_progress_motion: ProgressMotion (src/SPHCellList.jl:765,787) of the queued step on owned particles and
+ * ghost copies alike; call it before packing the halo of either pass.
+ * sphmi_dd_mdbc: the mDBC density of EVERY boundary particle held (src/SPHCellList.jl:772), ghost copies included,
+ * after the halo of state A has been unpacked and before pass 1.  A ghost copy in the column next to the slab gets
+ * the owner's value (up to summation order) when the halo is 2 + max |column(ghost node) − column(particle)|
+ * columns wide — the driver's job (sphexample_amd/distributed.py: halo_width). */
+int sphmi_dd_progress_motion(sphmi_handle* h);
+int sphmi_dd_mdbc(sphmi_handle* h);
 /* Device-side step control for the slab driver (the k_step_control of sphmi_advance, fed with the MAX-allreduced
  * slots): init once per advance, then per step  reductions_dev → allreduce → step_control → passes (dt argument
  * ignored); sphmi_dd_ctrl_sync waits for everything queued and reports the flags; after a collective rebuild call

@@ -65,7 +65,9 @@ struct EngineBase {
     virtual void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) = 0;
     virtual void dd_set_stream(void* s) = 0;
     virtual void dd_upload(int64_t n, const void*, const void*, const void*, const void*, const uint8_t*,
-                           const int64_t*, const uint64_t*) = 0;
+                           const int64_t*, const uint64_t*, const void*, const int64_t*) = 0;
+    virtual void dd_progress_motion() = 0;
+    virtual void dd_mdbc() = 0;
     virtual int64_t dd_count() = 0;
     virtual void dd_cell_x(int32_t* out_host) = 0;
     virtual void dd_types(uint8_t* out_host) = 0;
@@ -103,6 +105,7 @@ struct Engine final : EngineBase {
     uint8_t* type[2] = {};
     long long* id[2] = {};
     unsigned long long* grp[2] = {};
+    unsigned long long* otag[2] = {};  // order tags (sphmi_rebuild.h, k_rankfix_tag): slab handles only
     int* key[2] = {};
     int cur = 0;                       // which of the [2] copies is live
     int *slot = nullptr, *tmp_idx = nullptr, *perm = nullptr;
@@ -179,7 +182,7 @@ struct Engine final : EngineBase {
         for (auto& e : ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (int k = 0; k < 3; ++k) { (void)hipFree(pk0[k]); (void)hipFree(pk1[k]); }
         for (int k = 0; k < 2; ++k) {
-            (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]);
+            (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]); (void)hipFree(otag[k]);
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
         }
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); (void)hipEventDestroy(ev_packed); }
@@ -386,7 +389,8 @@ struct Engine final : EngineBase {
         hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, misc_d + 1);
         hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, stream, cstart, nscan, tsum, misc_d + 1);
         hipLaunchKernelGGL(k_scatter, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, tmp_idx);
-        hipLaunchKernelGGL(k_rankfix, dim3(nb256), dim3(256), 0, stream, N, key[cur], cstart, tmp_idx, perm);
+        if (otag[0]) hipLaunchKernelGGL(k_rankfix_tag, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, (int)ncell, tmp_idx, otag[cur], perm);
+        else         hipLaunchKernelGGL(k_rankfix, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, (int)ncell, tmp_idx, perm);
         PermuteArgs<T> A{};
         const int nxt = cur ^ 1;
         A.pk0_in = pk0[iA]; A.pk1_in = pk1[iA]; A.acc_in = acc[cur]; A.ghost_in = ghost[cur];
@@ -395,8 +399,15 @@ struct Engine final : EngineBase {
         A.id_in = id[cur]; A.id_out = id[nxt];
         A.grp_in = grp[cur]; A.grp_out = grp[nxt];
         A.key_in = key[cur]; A.key_out = key[nxt];
+        A.tag_in = otag[cur]; A.tag_out = otag[nxt];
         A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
+        if (otag[0]) {
+            for (int d = 0; d < D; ++d)
+                if (grid.gmin[d] < -32000 || grid.gmin[d] + grid.np[d] > 32000)
+                    throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: cell coordinates beyond ±32000 (order tags hold 16 bits per axis)");
+            hipLaunchKernelGGL(k_make_tags, dim3(nb256), dim3(256), 0, stream, N, key[nxt], cstart, grid, otag[nxt]);
+        }
         HC(hipGetLastError());
         std::swap(iA, iB);
         cur = nxt;
@@ -738,12 +749,33 @@ struct Engine final : EngineBase {
         own_stream = false;
     }
     void dd_upload(int64_t n, const void* position, const void* velocity, const void* acceleration,
-                   const void* density, const uint8_t* ty, const int64_t* ids, const uint64_t* groups) override {
+                   const void* density, const uint8_t* ty, const int64_t* ids, const uint64_t* groups,
+                   const void* ghost_points, const int64_t* upload_index) override {
         if (n < 1 || n > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: particle count exceeds the handle's capacity");
-        if (cfg.mdbc != SPHMI_MDBC_NONE) throw EngineError(SPHMI_ERR_ARGUMENT, "mDBC is not supported under domain decomposition yet");
-        if (motions.n) throw EngineError(SPHMI_ERR_ARGUMENT, "moving bodies are not supported under domain decomposition yet");
+        if (cfg.mdbc != SPHMI_MDBC_NONE && !ghost_points)
+            throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: mDBC handle without ghost points");
         N = (int)n;
-        upload(position, velocity, acceleration, density, ty, ids, groups, nullptr);
+        upload(position, velocity, acceleration, density, ty, ids, groups, ghost_points);
+        // order tags: before the first sort a particle's "previous sorted index" is its index in the caller's arrays
+        for (int k = 0; k < 2; ++k) if (!otag[k]) HC(hipMalloc(&otag[k], (size_t)cap * 8));
+        std::vector<unsigned long long> t((size_t)n);
+        for (int64_t i = 0; i < n; ++i) t[i] = upload_index ? (unsigned long long)upload_index[i] : (unsigned long long)i;
+        HC(hipMemcpyAsync(otag[cur], t.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
+        HC(hipStreamSynchronize(stream));
+    }
+    // ProgressMotion of the queued step (src/SPHCellList.jl:765,787) on owned particles AND ghost copies — a prescribed
+    // motion is the same function of time on every rank — before the halo of the pass is packed
+    void dd_progress_motion() override {
+        if (!dd_ctrl_on) throw EngineError(SPHMI_ERR_STATE, "sphmi_dd_progress_motion needs sphmi_dd_ctrl_init");
+        HC(hipSetDevice(cfg.device));
+        progress_motion(0.0, ctrl_d);
+    }
+    // mDBC (:772) for every boundary particle held, ghost copies included: with a halo wide enough (distributed.py)
+    // the copies a pass can see get the owner's value up to summation order, and nothing has to travel twice
+    void dd_mdbc() override {
+        if (cfg.mdbc != SPHMI_MDBC_SIMPLE) return;
+        HC(hipSetDevice(cfg.device));
+        run_mdbc(dd_ctrl_on ? ctrl_d : nullptr);
     }
     int64_t dd_count() override { return N; }
     void reset_count() override { N = cap; }
@@ -765,7 +797,7 @@ struct Engine final : EngineBase {
         if (n <= 0) return;
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           id[cur], grp[cur], type[cur], idx_dev, (int)n, buf_dev);
+                           ghost[cur], id[cur], grp[cur], otag[cur], type[cur], idx_dev, (int)n, buf_dev);
         HC(hipGetLastError());
     }
     void dd_kill(const int32_t* idx_dev, int64_t n) override {
@@ -784,7 +816,7 @@ struct Engine final : EngineBase {
         if ((int64_t)N + n > cap) throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: rank capacity exceeded (too many arrivals)");
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_append<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           id[cur], grp[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
+                           ghost[cur], id[cur], grp[cur], otag[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
         HC(hipGetLastError());
         N += (int)n;
     }
@@ -1012,9 +1044,12 @@ int sphmi_upload(sphmi_handle* h, const void* position, const void* velocity, co
 
 int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream) { SPHMI_GUARD(h, h->e->dd_set_stream(hip_stream)); }
 int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity, const void* acceleration,
-                    const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker) {
-    SPHMI_GUARD(h, h->e->dd_upload(n, position, velocity, acceleration, density, type, id, group_marker));
+                    const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker,
+                    const void* ghost_points, const int64_t* upload_index) {
+    SPHMI_GUARD(h, h->e->dd_upload(n, position, velocity, acceleration, density, type, id, group_marker, ghost_points, upload_index));
 }
+int sphmi_dd_progress_motion(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_progress_motion()); }
+int sphmi_dd_mdbc(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_mdbc()); }
 int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
 int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }

@@ -265,16 +265,52 @@ __global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const in
     if (i < N) tmp_idx[cstart[key[i]] + slot[i]] = i;
 }
 
-// stable in-cell order: rank = #{cell mates whose previous index is smaller}
-__global__ void __launch_bounds__(256) k_rankfix(int N, const int* key, const int* cstart, const int* tmp_idx,
-                                                 int* perm) {
+// stable in-cell order: rank = #{cell mates whose previous index is smaller}.  The graveyard (dead particles:
+// key == ncell, a whole ghost layer under domain decomposition) needs no order and keeps its scatter slots.
+__global__ void __launch_bounds__(256) k_rankfix(int N, const int* key, const int* slot, const int* cstart, int ncell,
+                                                 const int* tmp_idx, int* perm) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int k = key[i];
     const int s = cstart[k], e = cstart[k + 1];
+    if (k == ncell) { perm[s + slot[i]] = i; return; }
     int rank = 0;
     for (int q = s; q < e; ++q) rank += tmp_idx[q] < i;
     perm[s + rank] = i;
+}
+
+// Domain decomposition: the reference's in-cell order is a history — a stable sort keeps cell mates in the order of
+// their PREVIOUS sorted index (src/SPHCellList.jl:142), and that order decides which particle of a same-cell pair
+// plays "i" (the density-diffusion term is not symmetric).  A slab's local index is not the global
+// one (migrants arrive at the end of the array), so every particle carries an ORDER TAG that compares like its
+// previous global sorted index: (global cell in sort order, rank in that cell) after a rebuild, the upload index
+// before the first one.  Tags travel with migration and ghost-layer records.
+__global__ void __launch_bounds__(256) k_rankfix_tag(int N, const int* key, const int* slot, const int* cstart, int ncell,
+                                                     const int* tmp_idx, const unsigned long long* tag, int* perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int k = key[i];
+    const int s = cstart[k], e = cstart[k + 1];
+    if (k == ncell) { perm[s + slot[i]] = i; return; }
+    const unsigned long long t = tag[i];
+    int rank = 0;
+    for (int q = s; q < e; ++q) {
+        const int j = tmp_idx[q];
+        const unsigned long long u = tag[j];
+        rank += (u < t) | ((u == t) & (j < i));
+    }
+    perm[s + rank] = i;
+}
+// tags of the new order: 16 bits per global cell coordinate (z, y, x: the sort order of cells), 16 bits in-cell rank
+__global__ void __launch_bounds__(256) k_make_tags(int N, const int* key, const int* cstart, GridDesc g, unsigned long long* tag) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int k = key[p];
+    if (k >= g.ncell) { tag[p] = ~0ull; return; }
+    const int cx = k % g.np[0], cy = (k / g.np[0]) % g.np[1], cz = k / (g.np[0] * g.np[1]);
+    const unsigned long long X = (unsigned long long)(cx - 1 + g.gmin[0] + 32768), Y = (unsigned long long)(cy - 1 + g.gmin[1] + 32768),
+                             Z = (unsigned long long)(cz - 1 + g.gmin[2] + 32768);
+    tag[p] = (((Z << 16 | Y) << 16 | X) << 16) | (unsigned long long)((p - cstart[k]) & 0xFFFF);
 }
 
 template <class T>
@@ -286,6 +322,7 @@ struct PermuteArgs {
     const long long* id_in; long long* id_out;
     const unsigned long long* grp_in; unsigned long long* grp_out;
     const int* key_in; int* key_out;
+    const unsigned long long* tag_in; unsigned long long* tag_out;     // order tags (domain decomposition only)
     const int* perm;
     int N, has_ghost;
 };
@@ -303,6 +340,7 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     A.id_out[p] = A.id_in[i];
     A.grp_out[p] = A.grp_in[i];
     A.key_out[p] = A.key_in[i];
+    if (A.tag_in) A.tag_out[p] = A.tag_in[i];
 }
 
 // Pressure! (src/SimulationEquations.jl:18-24) on a state set: pk1.w = EOS(|pk0.w|)
@@ -639,22 +677,26 @@ __global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* 
     }
 }
 
-// Migration record buffer for n particles: [n×V4 pk0][n×V4 pk1][n×V4 acc][n×i64 id][n×u64 group][n×u8 type]
+// Migration record buffer for n particles:
+// [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][n×i64 id][n×u64 group][n×u64 order tag][n×u8 type]
 template <class T> struct DdRecord {
     using V4 = typename Vec4<T>::type;
-    static __host__ __device__ size_t bytes(size_t n) { return n * (3 * sizeof(V4) + 16) + ((n + 7) & ~size_t(7)); }
+    static __host__ __device__ size_t bytes(size_t n) { return n * (4 * sizeof(V4) + 24) + ((n + 7) & ~size_t(7)); }
     static __host__ __device__ V4* pk0(void* b, size_t) { return (V4*)b; }
     static __host__ __device__ V4* pk1(void* b, size_t n) { return (V4*)b + n; }
     static __host__ __device__ V4* acc(void* b, size_t n) { return (V4*)b + 2 * n; }
-    static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + 3 * n); }
+    static __host__ __device__ V4* ghost(void* b, size_t n) { return (V4*)b + 3 * n; }
+    static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + 4 * n); }
     static __host__ __device__ unsigned long long* grp(void* b, size_t n) { return (unsigned long long*)id(b, n) + n; }
-    static __host__ __device__ uint8_t* type(void* b, size_t n) { return (uint8_t*)(grp(b, n) + n); }
+    static __host__ __device__ unsigned long long* tag(void* b, size_t n) { return grp(b, n) + n; }
+    static __host__ __device__ uint8_t* type(void* b, size_t n) { return (uint8_t*)(tag(b, n) + n); }
 };
 
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_gather(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
-                                                   const typename Vec4<T>::type* acc, const long long* id,
-                                                   const unsigned long long* grp, const uint8_t* type,
+                                                   const typename Vec4<T>::type* acc, const typename Vec4<T>::type* ghost,
+                                                   const long long* id, const unsigned long long* grp,
+                                                   const unsigned long long* tag, const uint8_t* type,
                                                    const int* idx, int n, void* buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -662,22 +704,27 @@ __global__ void __launch_bounds__(256) k_dd_gather(const typename Vec4<T>::type*
     DdRecord<T>::pk0(buf, n)[k] = pk0[i];
     DdRecord<T>::pk1(buf, n)[k] = pk1[i];
     DdRecord<T>::acc(buf, n)[k] = acc[i];
+    DdRecord<T>::ghost(buf, n)[k] = ghost[i];
     DdRecord<T>::id(buf, n)[k] = id[i];
     DdRecord<T>::grp(buf, n)[k] = grp[i];
+    DdRecord<T>::tag(buf, n)[k] = tag[i];
     DdRecord<T>::type(buf, n)[k] = type[i] & kTypeMask;
 }
 
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_append(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
-                                                   typename Vec4<T>::type* acc, long long* id, unsigned long long* grp,
-                                                   uint8_t* type, int at, int n, void* buf, uint8_t flag) {
+                                                   typename Vec4<T>::type* acc, typename Vec4<T>::type* ghost, long long* id,
+                                                   unsigned long long* grp, unsigned long long* tag, uint8_t* type, int at, int n,
+                                                   void* buf, uint8_t flag) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     pk0[at + k] = DdRecord<T>::pk0(buf, n)[k];
     pk1[at + k] = DdRecord<T>::pk1(buf, n)[k];
     acc[at + k] = DdRecord<T>::acc(buf, n)[k];
+    ghost[at + k] = DdRecord<T>::ghost(buf, n)[k];
     id[at + k] = DdRecord<T>::id(buf, n)[k];
     grp[at + k] = DdRecord<T>::grp(buf, n)[k];
+    tag[at + k] = DdRecord<T>::tag(buf, n)[k];
     type[at + k] = DdRecord<T>::type(buf, n)[k] | flag;
 }
 

@@ -35,7 +35,12 @@ k-th ghost slot of the receiver and the per-step halo needs no indices on the wi
 The cuts move with the fluid: at a rebuild whose max/mean owned count exceeds 1.05 the ranks sum their column
 histograms and re-cut (every cut stays between its old neighbours, so migration remains a neighbour exchange).
 
-Known limits: static slab axis, no mDBC / moving bodies.
+Moving bodies: ProgressMotion runs on owned particles and ghost copies alike before each halo pack (a prescribed
+motion is the same function of time everywhere).  mDBC: the ghost layers are 2 + off columns wide (off = the largest
+column distance between a boundary particle and its ghost node), every rank corrects the boundary particles it holds —
+ghost copies included — after the halo of state A has landed, and pass 1 then runs without overlap.
+
+Known limits: static slab axis.
 """
 from __future__ import annotations
 
@@ -55,20 +60,21 @@ def cell_x_of(x: np.ndarray, H_inv: float) -> np.ndarray:
     return (np.sign(x) * np.trunc(np.abs(x) * H_inv + 0.5)).astype(np.int64)
 
 
-def choose_axis(cols: List[np.ndarray], world: int) -> int:
+def choose_axis(cols: List[np.ndarray], world: int, min_width=2) -> int:
     """Slab axis: the one whose equal-count column cuts leave the lightest heaviest rank.  Ties go to the
-    slowest sort axis (its ghost layers are contiguous runs of the cell-sorted arrays)."""
+    slowest sort axis (its ghost layers are contiguous runs of the cell-sorted arrays).  `min_width`: columns a
+    slab must keep — a number, or one number per axis (the halo width, which depends on the axis with mDBC)."""
     best, best_load = 0, None
     for ax, cx in enumerate(cols):
         try:
-            plan = SlabPlan.from_columns(cx, world)
+            plan = SlabPlan.from_columns(cx, world, min_width if np.isscalar(min_width) else min_width[ax])
         except ValueError:
             continue
         load = np.bincount(plan.owner_of(cx), minlength=world).max()
         if best_load is None or load <= best_load:
             best, best_load = ax, load
     if best_load is None:
-        raise ValueError("no axis has two cell columns per rank: too many ranks for this domain")
+        raise ValueError("no axis has enough cell columns per rank: too many ranks for this domain")
     return best
 
 
@@ -77,13 +83,14 @@ class SlabPlan:
     """Static slab cuts along one axis: rank r owns the cell columns cx_lo[r] … cx_hi[r] (inclusive)."""
     cx_lo: List[int]
     cx_hi: List[int]
+    min_width: int = 2          # columns per slab: at least the halo width (a ghost layer comes from ONE neighbour)
 
     @property
     def world(self) -> int:
         return len(self.cx_lo)
 
     @staticmethod
-    def from_columns(cx: np.ndarray, world: int) -> "SlabPlan":
+    def from_columns(cx: np.ndarray, world: int, min_width: int = 2) -> "SlabPlan":
         """Equal-particle-count cuts on column boundaries (a uniform spatial cut would put the whole
         initial water column on a quarter of the ranks)."""
         lo, hi = int(cx.min()), int(cx.max())
@@ -94,16 +101,16 @@ class SlabPlan:
         for r in range(1, world):
             # first column whose cumulative count reaches r/world of the particles
             c = lo + int(np.searchsorted(cum, total * r / world, side="left")) + 1
-            c = max(c, cuts[-1] + 2)            # every slab at least two columns wide
+            c = max(c, cuts[-1] + min_width)    # every slab at least two (or halo-width) columns wide
             cuts.append(c)
         cuts.append(hi + 1)
         for r in range(world):
-            if cuts[r + 1] - cuts[r] < 2:
-                raise ValueError(f"slab {r} would be narrower than two cell columns: too many ranks for this domain")
+            if cuts[r + 1] - cuts[r] < min_width:
+                raise ValueError(f"slab {r} would be narrower than {min_width} cell columns: too many ranks for this domain")
         INF = 1 << 30
         cx_lo = [(-INF if r == 0 else cuts[r]) for r in range(world)]
         cx_hi = [(INF if r == world - 1 else cuts[r + 1] - 1) for r in range(world)]
-        return SlabPlan(cx_lo, cx_hi)
+        return SlabPlan(cx_lo, cx_hi, min_width)
 
     def cuts(self) -> List[int]:
         """Interior cut positions: cut r (1 ≤ r < world) is the first column of rank r."""
@@ -112,20 +119,20 @@ class SlabPlan:
     def recut(self, col0: int, hist: np.ndarray) -> "SlabPlan":
         """Equal-count cuts for the CURRENT global column histogram (`hist[k]` = particles in column col0 + k), with
         every cut kept between its two old neighbours (so a particle changes rank by at most one — migration stays a
-        neighbour exchange) and every slab at least two columns wide."""
-        world = self.world
+        neighbour exchange) and every slab at least `min_width` columns wide."""
+        world, w = self.world, self.min_width
         cum = np.cumsum(hist)
         total = int(cum[-1])
         old = [col0] + self.cuts() + [col0 + len(hist)]
         new = [old[0]]
         for r in range(1, world):
             c = col0 + int(np.searchsorted(cum, total * r / world, side="left")) + 1
-            lo = max(old[r - 1] + 2, new[-1] + 2)               # not past the old cut on the left, slab r−1 ≥ 2 columns
-            hi = old[r + 1] - 2                                  # not past the old cut on the right
+            lo = max(old[r - 1] + w, new[-1] + w)               # not past the old cut on the left, slab r−1 ≥ w columns
+            hi = old[r + 1] - w                                  # not past the old cut on the right
             new.append(min(max(c, lo), hi) if lo <= hi else old[r])
         INF = 1 << 30
         return SlabPlan([(-INF if r == 0 else new[r]) for r in range(world)],
-                        [(INF if r == world - 1 else new[r + 1] - 1) for r in range(world)])
+                        [(INF if r == world - 1 else new[r + 1] - 1) for r in range(world)], w)
 
     def owner_of(self, cx: np.ndarray) -> np.ndarray:
         bounds = np.array([self.cx_lo[r] for r in range(1, self.world)], dtype=np.int64)
@@ -253,9 +260,22 @@ class DistributedEngine:
         ft = np.float32 if device_float_bytes == 4 else np.float64
         D = particles.Position.shape[1]
         cols = [cell_x_of(particles.Position[:, a].astype(ft).astype(np.float64), H_inv) for a in range(D)]
-        self.axis = choose_axis(cols, world) if axis is None else int(axis)
+        # halo width per axis: one column for the pair forces; with mDBC the ghost node of a boundary particle sits up
+        # to `off` columns from it and is summed over its own 3 columns, and the ghost COPIES next to the slab are
+        # corrected locally too (sphmi_dd_mdbc), so their ghost nodes' columns must be held as well: 2 + off
+        from .config import SimpleMDBC
+        self.mdbc = setup.SimMetaData.BMode is SimpleMDBC
+        widths = [1] * D
+        if self.mdbc:
+            has = np.any(particles.GhostPoints != 0, axis=1)
+            for a in range(D):
+                gx = cell_x_of(particles.GhostPoints[has, a].astype(ft).astype(np.float64), H_inv)
+                widths[a] = 2 + (int(np.abs(gx - cols[a][has]).max()) if has.any() else 0)
+        self.axis = choose_axis(cols, world, [max(2, w) for w in widths]) if axis is None else int(axis)
+        self.halo_width = W = widths[self.axis]
         cx = cols[self.axis]
-        self.plan = plan if plan is not None else SlabPlan.from_columns(cx, world)    # `plan`: start from given cuts
+        self.plan = plan if plan is not None else SlabPlan.from_columns(cx, world, max(2, W))   # `plan`: start from given cuts
+        self.plan.min_width = max(self.plan.min_width, W)
         mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
         self.n_total = len(particles)
         n_own = len(mine)
@@ -265,8 +285,8 @@ class DistributedEngine:
         hist = np.bincount(cx - lo_c, minlength=hi_c - lo_c + 1)
         col = lambda c: int(hist[c - lo_c]) if lo_c <= c <= hi_c else 0          # noqa: E731
         s_lo, s_hi = max(self.plan.cx_lo[rank], lo_c), min(self.plan.cx_hi[rank], hi_c)
-        ghosts = col(s_lo - 1) + col(s_hi + 1)
-        slack = col(s_lo - 2) + col(s_hi + 2) + 2 * int(hist.max())             # two more columns per side may arrive
+        ghosts = sum(col(s_lo - k) + col(s_hi + k) for k in range(1, W + 1))
+        slack = col(s_lo - W - 1) + col(s_hi + W + 1) + 2 * int(hist.max())     # two more columns per side may arrive
         cap = int(capacity_factor * (n_own + ghosts)) + slack + 1024
         cap = max(cap, int(capacity_factor * (self.n_total / world)))
         cfg = make_config(cap, setup.SimConstants, setup.SimKernel, setup.SimMetaData, setup.SimViscosity,
@@ -294,7 +314,11 @@ class DistributedEngine:
                 f(particles.Density[mine]), np.ascontiguousarray(particles.Type[mine], dtype=np.uint8),
                 np.ascontiguousarray(particles.ID[mine], dtype=np.int64),
                 np.ascontiguousarray(particles.GroupMarker[mine], dtype=np.uint64)]
-        self._call("dd_upload", C.c_int64(n_own), *[a.ctypes.data_as(C.c_void_p) for a in keep])
+        gp = f(particles.GhostPoints[mine]) if self.mdbc else None
+        order = np.ascontiguousarray(mine, dtype=np.int64)
+        self._call("dd_upload", C.c_int64(n_own), *[a.ctypes.data_as(C.c_void_p) for a in keep],
+                   gp.ctypes.data_as(C.c_void_p) if gp is not None else None, order.ctypes.data_as(C.c_void_p))
+        self.moving = False
         self.comm = _Comm(rank, world, self.device)
         self.D = cfg.dims
         self.vbytes = 4 * cfg.device_float_bytes            # one V4 packet
@@ -309,7 +333,9 @@ class DistributedEngine:
         L = self.lib
         vp, i64, i32p = C.c_void_p, C.c_int64, C.c_void_p
         L.sphmi_dd_set_stream.argtypes = [vp, vp]
-        L.sphmi_dd_upload.argtypes = [vp, i64] + [vp] * 7
+        L.sphmi_dd_upload.argtypes = [vp, i64] + [vp] * 9
+        L.sphmi_dd_progress_motion.argtypes = [vp]
+        L.sphmi_dd_mdbc.argtypes = [vp]
         L.sphmi_dd_count.argtypes = [vp, C.POINTER(i64)]
         L.sphmi_dd_cell_x.argtypes = [vp, vp]
         L.sphmi_dd_types.argtypes = [vp, vp]
@@ -335,6 +361,11 @@ class DistributedEngine:
 
     def _call(self, name, *args):
         self.eng._check(getattr(self.lib, "sphmi_" + name)(self.h, *args))
+
+    def set_motions(self, geometries):
+        """MotionDetails of the Moving geometries (RunSimulation's MotionDefinition, src/SPHCellList.jl:846-850)."""
+        self.eng.set_motions(geometries)
+        self.moving = any(getattr(g, "Motion", None) is not None for g in geometries or ())
 
     def _count(self) -> int:
         n = C.c_int64()
@@ -413,10 +444,11 @@ class DistributedEngine:
                 self._call("dd_append", C.c_void_p(buf.data_ptr()), C.c_int64(n), C.c_int(0))
         torch.cuda.current_stream(self.device).synchronize()
         self._call("dd_rebuild")
-        # 2. the first / last column of the slab become the neighbours' ghost layer
+        # 2. the first / last column(s) of the slab become the neighbours' ghost layer
+        W = self.halo_width
         cx = self._cell_x()
-        b_l = np.nonzero(cx == lo)[0] if self.comm.left is not None else np.empty(0, np.int64)
-        b_r = np.nonzero(cx == hi)[0] if self.comm.right is not None else np.empty(0, np.int64)
+        b_l = np.nonzero(cx < lo + W)[0] if self.comm.left is not None else np.empty(0, np.int64)
+        b_r = np.nonzero(cx > hi - W)[0] if self.comm.right is not None else np.empty(0, np.int64)
         sl, sr = self._gather(b_l), self._gather(b_r)
         nl, nr = self.comm.exchange_counts(len(b_l), len(b_r))
         rl, rr = self.comm.exchange(sl, sr, self._record_bytes(nl) if nl else 0, self._record_bytes(nr) if nr else 0)
@@ -430,8 +462,8 @@ class DistributedEngine:
         cx = self._cell_x()
         ty = self._types()
         owned = (ty & GHOST_MASK) == 0
-        send_l = np.nonzero(owned & (cx == lo))[0] if self.comm.left is not None else np.empty(0, np.int64)
-        send_r = np.nonzero(owned & (cx == hi))[0] if self.comm.right is not None else np.empty(0, np.int64)
+        send_l = np.nonzero(owned & (cx < lo + W))[0] if self.comm.left is not None else np.empty(0, np.int64)
+        send_r = np.nonzero(owned & (cx > hi - W))[0] if self.comm.right is not None else np.empty(0, np.int64)
         slot_l = np.nonzero((ty & GHOST_LEFT) != 0)[0]
         slot_r = np.nonzero((ty & GHOST_RIGHT) != 0)[0]
         assert len(send_l) == len(b_l) and len(send_r) == len(b_r), "boundary columns changed between the two sorts"
@@ -472,9 +504,15 @@ class DistributedEngine:
         edge tiles start as soon as the halo has landed and share the chip with the interior launch instead of
         forming a second, poorly filled launch behind it."""
         torch = self.torch
+        if self.moving:
+            self._call("dd_progress_motion")         # :765 / :787 — owned and ghost copies move alike, then the pack
         token = self._halo_start(which - 1)
-        if not self.overlap:
+        if not self.overlap or (self.mdbc and which == 1):
+            # mDBC (:772) reads the fluid of state A in the ghost layers and rewrites the boundary densities that every
+            # tile of pass 1 may read: halo → mDBC → the whole pass, nothing to overlap
             self._halo_finish(which - 1, token)
+            if self.mdbc and which == 1:
+                self._call("dd_mdbc")
             self._call("dd_pass", C.c_int(which), C.c_double(dt))
             return
         main = torch.cuda.current_stream(self.device)

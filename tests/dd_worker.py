@@ -61,10 +61,12 @@ def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overla
         c = [x + cut_shift for x in b.cuts()]
         plan = SlabPlan([-INF] + c, [x - 1 for x in c] + [INF])
     eng = DistributedEngine(p, s, rank, world, local_device=0, plan=plan, device_float_bytes=fb, axis=axis, overlap=overlap, recut_imbalance=recut)
+    if hasattr(p, "geometries"):
+        eng.set_motions(p.geometries)
     pr = eng.advance(1e9, max_steps=steps)
     res = eng.gather_all()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dd.npz"), iteration=pr.iteration, total_time=pr.total_time,
-                 n_rebuilds=pr.n_rebuilds, axis=eng.axis, n_recuts=eng.n_recuts, **res)
+                 n_rebuilds=pr.n_rebuilds, axis=eng.axis, n_recuts=eng.n_recuts, halo_width=eng.halo_width, **res)
     dist.barrier()
     dist.destroy_process_group()
