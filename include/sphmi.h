@@ -208,7 +208,7 @@ int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local)
  * launches since the last reset (sampled: the launches of every 8th step), and the number of launches. */
 int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 
-/* ---- domain decomposition: one process per GPU, slabs along one axis with a one-cell halo ---------
+/* ---- domain decomposition: one process per GPU, slabs along one axis, one-cell halo (wider with mDBC) --
  * The reference has no multi-process path; these entry points let a host driver
  * (sphexample_amd/distributed.py: torch.distributed over RCCL) run the SAME kernels on a slab of the
  * domain.  The handle is created with n_particles = the rank's CAPACITY; the live count changes at every
