@@ -458,27 +458,36 @@ class DistributedEngine:
             self._call("dd_append", C.c_void_p(rr.data_ptr()), C.c_int64(nr), C.c_int(GHOST_RIGHT))
         torch.cuda.current_stream(self.device).synchronize()
         self._call("dd_rebuild")
-        # 3. halo index lists in the final order (stable sorts ⇒ k-th sender entry ↔ k-th ghost slot)
+        # 3. halo index lists in the final order (stable sorts ⇒ k-th sender entry ↔ k-th ghost slot; the same holds
+        #    for the sub-lists of ONE column, because both sides see the same positions).  State A travels with all
+        #    `halo_width` columns (mDBC reads them), the half-step state H with the one column the pair forces reach.
         cx = self._cell_x()
         ty = self._types()
         owned = (ty & GHOST_MASK) == 0
-        send_l = np.nonzero(owned & (cx < lo + W))[0] if self.comm.left is not None else np.empty(0, np.int64)
-        send_r = np.nonzero(owned & (cx > hi - W))[0] if self.comm.right is not None else np.empty(0, np.int64)
-        slot_l = np.nonzero((ty & GHOST_LEFT) != 0)[0]
-        slot_r = np.nonzero((ty & GHOST_RIGHT) != 0)[0]
-        assert len(send_l) == len(b_l) and len(send_r) == len(b_r), "boundary columns changed between the two sorts"
-        assert len(slot_l) == nl and len(slot_r) == nr
+        none = np.empty(0, np.int64)
         vb = 2 * self.vbytes
         mk = lambda n: torch.empty(max(n, 1) * vb, dtype=torch.uint8, device=self.device)  # noqa: E731
-        self._halo = dict(send_l=self._idx_dev(send_l), send_r=self._idx_dev(send_r),
-                          slot_l=self._idx_dev(slot_l), slot_r=self._idx_dev(slot_r),
-                          n_send_l=len(send_l), n_send_r=len(send_r), n_slot_l=nl, n_slot_r=nr,
-                          buf_l=mk(len(send_l)), buf_r=mk(len(send_r)))
+        self._halo = []
+        for w in (W, 1):
+            send_l = np.nonzero(owned & (cx < lo + w))[0] if self.comm.left is not None else none
+            send_r = np.nonzero(owned & (cx > hi - w))[0] if self.comm.right is not None else none
+            slot_l = np.nonzero(((ty & GHOST_LEFT) != 0) & (cx >= lo - w))[0]
+            slot_r = np.nonzero(((ty & GHOST_RIGHT) != 0) & (cx <= hi + w))[0]
+            if w == W:
+                assert len(send_l) == len(b_l) and len(send_r) == len(b_r), "boundary columns changed between the two sorts"
+                assert len(slot_l) == nl and len(slot_r) == nr
+            self._halo.append(dict(send_l=self._idx_dev(send_l), send_r=self._idx_dev(send_r),
+                                   slot_l=self._idx_dev(slot_l), slot_r=self._idx_dev(slot_r),
+                                   n_send_l=len(send_l), n_send_r=len(send_r), n_slot_l=len(slot_l), n_slot_r=len(slot_r),
+                                   buf_l=mk(len(send_l)), buf_r=mk(len(send_r))))
+            if W == 1:
+                self._halo.append(self._halo[0])
+                break
         self.n_rebuilds += 1
 
     def _halo_start(self, which: int):
         """Pack the slab-edge columns of state set `which` (0 = A, 1 = H) and post the exchange."""
-        hl, p = self._halo, C.c_void_p
+        hl, p = self._halo[which], C.c_void_p
         vb = 2 * self.vbytes
         if hl["n_send_l"]:
             self._call("dd_halo_pack", C.c_int(which), p(hl["send_l"].data_ptr()), C.c_int64(hl["n_send_l"]), p(hl["buf_l"].data_ptr()))
@@ -490,7 +499,7 @@ class DistributedEngine:
 
     def _halo_finish(self, which: int, token):
         """Wait for the exchange and refresh the ghost copies of state set `which`."""
-        hl, p = self._halo, C.c_void_p
+        hl, p = self._halo[which], C.c_void_p
         rl, rr = self.comm.finish_exchange(token)
         if hl["n_slot_l"]:
             self._call("dd_halo_unpack", C.c_int(which), p(hl["slot_l"].data_ptr()), C.c_int64(hl["n_slot_l"]), p(rl.data_ptr()))
