@@ -38,4 +38,6 @@ if __name__ == "__main__":
     i1, i2 = np.argsort(r["ID"]), np.argsort(dd["ID"])
     print(f"N={len(r['ID'])} world={world} axis={int(dd['axis'])} rebuilds {pr.n_rebuilds}/{int(dd['n_rebuilds'])} "
           f"t {pr.total_time:.9e}/{float(dd['total_time']):.9e} "
-          f"rho {np.abs(dd['Density'][i2] - r['Density'][i1]).max() / 1000:.2e} x {np.abs(dd['Position'][i2] - r['Position'][i1]).max():.2e}")
+          f"rho {np.abs(dd['Density'][i2] - r['Density'][i1]).max() / 1000:.2e} x {np.abs(dd['Position'][i2] - r['Position'][i1]).max():.2e} "
+          f"| ids ok {len(np.unique(dd['ID'])) == len(r['ID'])} mean rho {dd['Density'].mean():.4f}/{r['Density'].mean():.4f} "
+          f"front x {dd['Position'][:, 0][dd['Density'] > 0].max():.4f} median |dx| {np.median(np.abs(dd['Position'][i2] - r['Position'][i1]).max(axis=1)):.2e}")
