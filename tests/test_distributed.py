@@ -161,6 +161,13 @@ def test_two_slabs_with_moving_cuts(request):
     assert int(dd["n_recuts"]) >= 1
 
 
+@pytest.mark.gpu
+def test_two_slabs_with_moving_cuts_mdbc(request):
+    """The same with mDBC: five-column ghost layers, ghost nodes in the records, slabs never narrower than the halo."""
+    dd = _two_slabs("dam_break_2d_mdbc", 80, 8, 1e-9, 0, True, 1.02, request, cut_shift=3)
+    assert int(dd["n_recuts"]) >= 1 and int(dd["halo_width"]) == 5
+
+
 def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0, world=2):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
