@@ -142,6 +142,11 @@ int sphmi_download_begin(sphmi_handle* h,
                          void* position, void* velocity, void* acceleration, void* density, void* pressure,
                          int64_t* id, uint8_t* type, uint64_t* group_marker, void* ghost_points, int64_t* cells);
 int sphmi_download_end(sphmi_handle* h);
+/* Components per vector of the downloaded Position / Velocity / Acceleration / GhostPoints: `dims` (default, the
+ * SVector{D} layout of SimParticles) or 3 — the point layout of the VTKHDF writer, which pads 2-D vectors with a zero
+ * (to_3d!, src/ProduceHDFVTK.jl:251-325): the arrays handed to sphmi_download* then hold n×3 values and can be appended
+ * to the `Points` / PointData datasets as they are.  Cells stay n×dims. */
+int sphmi_set_output_components(sphmi_handle* h, int components);
 int sphmi_host_register(sphmi_handle* h, void* ptr, int64_t bytes);
 int sphmi_host_unregister(sphmi_handle* h, void* ptr);
 

@@ -104,6 +104,8 @@ function RunSimulationMI355X(; SimGeometry, SimMetaData::SimulationMetaData{D,T,
         output = SetupVTKOutput(SimMetaData, SimParticles, SimKernel, D)          # :846
         SimMetaData.OutputIterationCounter = 1                                     # :849
         output.save_particles(SimMetaData.OutputIterationCounter)
+        # (a writer that appends to the VTKHDF datasets itself can ask for the padded point layout instead of running
+        #  to_3d! on the host: ccall((:sphmi_set_output_components, LIB), Cint, (Ptr{Cvoid}, Cint), h, 3) → n×3 vectors)
         # the StructArray's columns receive every output: page-lock them once (released by sphmi_destroy)
         for col in (P.Position, P.Velocity, P.Acceleration, P.Density, P.Pressure, P.ID, P.GroupMarker)
             ccall((:sphmi_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), h, pointer(col), sizeof(col))

@@ -181,17 +181,35 @@ class Backend:
         return prog
 
     def download(self, fields=("Position", "Velocity", "Acceleration", "Density", "Pressure", "ID",
-                               "Type", "GroupMarker", "GhostPoints", "Cells")) -> dict:
+                               "Type", "GroupMarker", "GhostPoints", "Cells"), components: Optional[int] = None) -> dict:
+        """`components=3`: vector fields as n×3 (2-D vectors padded with a zero — the VTKHDF point layout the reference
+        produces with to_3d!, src/ProduceHDFVTK.jl:251-325), packed that way on the device."""
         N, D = self.N, self.D
+        Cv = D if components is None else int(components)
+        native = Cv != D and self._has("set_output_components")
+        Cd = Cv if native else D
         spec = {
-            "Position": ((N, D), self._ft), "Velocity": ((N, D), self._ft),
-            "Acceleration": ((N, D), self._ft), "Density": ((N,), self._ft),
+            "Position": ((N, Cd), self._ft), "Velocity": ((N, Cd), self._ft),
+            "Acceleration": ((N, Cd), self._ft), "Density": ((N,), self._ft),
             "Pressure": ((N,), self._ft), "ID": ((N,), np.int64), "Type": ((N,), np.uint8),
-            "GroupMarker": ((N,), np.uint64), "GhostPoints": ((N, D), self._ft),
+            "GroupMarker": ((N,), np.uint64), "GhostPoints": ((N, Cd), self._ft),
             "Cells": ((N, D), np.int64),
         }
         out = {k: (np.empty(*spec[k]) if k in fields else None) for k in spec}
-        self._check(self._fn("download")(self._h, *[_ptr(out[k]) for k in spec]))
+        if native:
+            self._fn("set_output_components").argtypes = [C.c_void_p, C.c_int]
+            self._check(self._fn("set_output_components")(self._h, Cv))
+        try:
+            self._check(self._fn("download")(self._h, *[_ptr(out[k]) for k in spec]))
+        finally:
+            if native:
+                self._check(self._fn("set_output_components")(self._h, D))
+        if Cv != D and not native:          # backends without the entry point (the oracle): pad on the host
+            if Cv != 3:
+                raise ValueError("components must be dims or 3")
+            for k in ("Position", "Velocity", "Acceleration", "GhostPoints"):
+                if out[k] is not None:
+                    out[k] = np.concatenate([out[k], np.zeros((N, 3 - D), dtype=out[k].dtype)], axis=1)
         return {k: v for k, v in out.items() if v is not None}
 
     def download_into(self, p, begin_only: bool = False) -> None:

@@ -52,6 +52,7 @@ struct EngineBase {
     virtual void download(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
     virtual void download_begin(void*, void*, void*, void*, void*, int64_t*, uint8_t*, uint64_t*, void*, int64_t*) = 0;
     virtual void download_end() = 0;
+    virtual void set_output_components(int c) = 0;
     virtual void host_register(void* p, size_t bytes) = 0;
     virtual void host_unregister(void* p) = 0;
     virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
@@ -143,7 +144,7 @@ struct Engine final : EngineBase {
     explicit Engine(const sphmi_config& c) {
         cfg = c;
         N = cap = (int)c.n_particles;
-        D = c.dims;
+        D = c.dims; out_comp = c.dims;
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0)
@@ -623,6 +624,11 @@ struct Engine final : EngineBase {
         }
     }
     hipStream_t copy_stream = nullptr; hipEvent_t ev_packed = nullptr; bool download_pending = false;
+    int out_comp = 0;          // components per output vector: D, or 3 (sphmi_set_output_components)
+    void set_output_components(int c) override {
+        if (c != D && c != 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_output_components: dims or 3");
+        out_comp = c;
+    }
     // begin: snapshot every requested field into the arena IN STREAM ORDER (so later steps cannot disturb it), then
     // hand the device→host copies to a second stream; end: wait for them.  Between the two the caller may advance.
     template <class H>
@@ -630,8 +636,8 @@ struct Engine final : EngineBase {
                            int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) {
         if (!copy_stream) { HC(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); HC(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)); }
         if (download_pending) { HC(hipStreamSynchronize(copy_stream)); download_pending = false; }
-        const size_t n = (size_t)N, nd = n * (size_t)D;
-        const size_t need = (4 * nd + 2 * n) * sizeof(H) + nd * 8 + n * 17 + 256 * 12;
+        const size_t n = (size_t)N, nd = n * (size_t)out_comp, ncell_d = n * (size_t)D;
+        const size_t need = (4 * nd + 2 * n) * sizeof(H) + ncell_d * 8 + n * 17 + 256 * 12;
         if (need > out_arena_bytes) {
             (void)hipFree(out_arena);
             out_arena = nullptr; out_arena_bytes = 0;
@@ -647,10 +653,10 @@ struct Engine final : EngineBase {
         o.pos = (H*)take(position, nd * sizeof(H)); o.vel = (H*)take(velocity, nd * sizeof(H));
         o.acc = (H*)take(acceleration, nd * sizeof(H)); o.rho = (H*)take(density, n * sizeof(H));
         o.press = (H*)take(pressure, n * sizeof(H)); o.ghost = (H*)take(ghost_points, nd * sizeof(H));
-        o.cells = (long long*)take(cells, nd * 8);
+        o.cells = (long long*)take(cells, ncell_d * 8);
         char* a_id = take(ids, n * 8); char* a_ty = take(ty, n); char* a_grp = take(groups, n * 8);
         hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
-                           stepped ? pk0[iH] : (const V4*)nullptr, acc[cur], ghost[cur], key[cur], N, D, grid, have_grid ? 1 : 0,
+                           stepped ? pk0[iH] : (const V4*)nullptr, acc[cur], ghost[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
                            (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
         HC(hipGetLastError());
         if (a_id) HC(hipMemcpyAsync(a_id, id[cur], n * 8, hipMemcpyDeviceToDevice, stream));
@@ -665,7 +671,7 @@ struct Engine final : EngineBase {
         copy(position, o.pos, nd * sizeof(H)); copy(velocity, o.vel, nd * sizeof(H));
         copy(acceleration, o.acc, nd * sizeof(H)); copy(density, o.rho, n * sizeof(H));
         copy(pressure, o.press, n * sizeof(H)); copy(ghost_points, o.ghost, nd * sizeof(H));
-        copy(cells, o.cells, nd * 8);
+        copy(cells, o.cells, ncell_d * 8);
         copy(ids, a_id, n * 8); copy(ty, a_ty, n); copy(groups, a_grp, n * 8);
         download_pending = true;
     }
@@ -1087,6 +1093,7 @@ int sphmi_download_begin(sphmi_handle* h, void* position, void* velocity, void* 
     SPHMI_GUARD(h, h->e->download_begin(position, velocity, acceleration, density, pressure, id, type, group_marker,
                                         ghost_points, cells));
 }
+int sphmi_set_output_components(sphmi_handle* h, int components) { SPHMI_GUARD(h, h->e->set_output_components(components)); }
 int sphmi_download_end(sphmi_handle* h) { SPHMI_GUARD(h, h->e->download_end()); }
 int sphmi_host_register(sphmi_handle* h, void* ptr, int64_t bytes) { SPHMI_GUARD(h, h->e->host_register(ptr, (size_t)bytes)); }
 int sphmi_host_unregister(sphmi_handle* h, void* ptr) { SPHMI_GUARD(h, h->e->host_unregister(ptr)); }

@@ -596,19 +596,20 @@ template <class H> struct OutFields {
 template <class T, class H>
 __global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
                                                      const typename Vec4<T>::type* half0, const typename Vec4<T>::type* accv,
-                                                     const typename Vec4<T>::type* ghostv, const int* key, int N, int D,
+                                                     const typename Vec4<T>::type* ghostv, const int* key, int N, int D, int C,
                                                      GridDesc g, int have_grid, T rho0, T inv_rho0, T Cbe, OutFields<H> o) {
+    // C: components per vector in the output (D, or 3 for the VTKHDF point layout: 2-D handles keep z = 0)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const size_t b = (size_t)i * D;
+    const size_t b = (size_t)i * C;
     if (o.pos || o.rho) {
         const auto q = pk0[i];
-        if (o.pos) { o.pos[b] = (H)q.x; o.pos[b + 1] = (H)q.y; if (D == 3) o.pos[b + 2] = (H)q.z; }
+        if (o.pos) { o.pos[b] = (H)q.x; o.pos[b + 1] = (H)q.y; if (C == 3) o.pos[b + 2] = (H)q.z; }
         if (o.rho) o.rho[i] = (H)(q.w < T(0) ? -q.w : q.w);
     }
     if (o.vel || (o.press && !half0)) {
         const auto q = pk1[i];
-        if (o.vel) { o.vel[b] = (H)q.x; o.vel[b + 1] = (H)q.y; if (D == 3) o.vel[b + 2] = (H)q.z; }
+        if (o.vel) { o.vel[b] = (H)q.x; o.vel[b + 1] = (H)q.y; if (C == 3) o.vel[b + 2] = (H)q.z; }
         if (o.press && !half0) o.press[i] = (H)q.w;                 // before any step: Pressure!(ρ) of :835
     }
     if (o.press && half0) {
@@ -618,17 +619,18 @@ __global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::typ
         const T r2 = rr * rr, r4 = r2 * r2;
         o.press[i] = (H)(Cbe * (r4 * r2 * rr - T(1)));
     }
-    if (o.acc) { const auto q = accv[i]; o.acc[b] = (H)q.x; o.acc[b + 1] = (H)q.y; if (D == 3) o.acc[b + 2] = (H)q.z; }
-    if (o.ghost) { const auto q = ghostv[i]; o.ghost[b] = (H)q.x; o.ghost[b + 1] = (H)q.y; if (D == 3) o.ghost[b + 2] = (H)q.z; }
+    if (o.acc) { const auto q = accv[i]; o.acc[b] = (H)q.x; o.acc[b + 1] = (H)q.y; if (C == 3) o.acc[b + 2] = (H)q.z; }
+    if (o.ghost) { const auto q = ghostv[i]; o.ghost[b] = (H)q.x; o.ghost[b + 1] = (H)q.y; if (C == 3) o.ghost[b + 2] = (H)q.z; }
     if (o.cells) {
-        if (!have_grid) { o.cells[b] = 0; o.cells[b + 1] = 0; if (D == 3) o.cells[b + 2] = 0; }
+        const size_t bc = (size_t)i * D;          // CartesianIndex{D}: never padded
+        if (!have_grid) { o.cells[bc] = 0; o.cells[bc + 1] = 0; if (D == 3) o.cells[bc + 2] = 0; }
         else {
             int kk = key[i];
             const int cx = kk % g.np[0]; kk /= g.np[0];
             const int cy = kk % g.np[1], cz = kk / g.np[1];
-            o.cells[b] = (long long)cx - 1 + g.gmin[0];
-            o.cells[b + 1] = (long long)cy - 1 + g.gmin[1];
-            if (D == 3) o.cells[b + 2] = (long long)cz - 1 + g.gmin[2];
+            o.cells[bc] = (long long)cx - 1 + g.gmin[0];
+            o.cells[bc + 1] = (long long)cy - 1 + g.gmin[1];
+            if (D == 3) o.cells[bc + 2] = (long long)cz - 1 + g.gmin[2];
         }
     }
 }

@@ -476,6 +476,28 @@ def test_download_into_is_in_place_and_repeatable(dam_break_2d_mdbc):
     assert (q.Density > 900).all() and np.abs(q.GhostPoints).sum() > 0 and (q.Pressure != 0).any()
 
 
+def test_download_in_vtkhdf_point_layout(dam_break_2d_mdbc, dam_break_3d_shipped):
+    """components=3: what to_3d! (src/ProduceHDFVTK.jl:251-325) makes of the 2-D vector fields, packed on the device —
+    n×3 with a zero third component; Cells stay n×dims; a 3-D handle is unchanged; the default layout is back afterwards."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d_mdbc
+    eng = make_engine(p, s, device_float_bytes=4)
+    eng.advance(1e9, max_steps=5)
+    d2, d3 = eng.download(), eng.download(components=3)
+    for k in ("Position", "Velocity", "Acceleration", "GhostPoints"):
+        assert d3[k].shape == (len(p), 3)
+        np.testing.assert_array_equal(d3[k][:, :2], d2[k], err_msg=k)
+        assert not d3[k][:, 2].any()
+    for k in ("Density", "Pressure", "ID", "Type", "GroupMarker", "Cells"):
+        np.testing.assert_array_equal(d3[k], d2[k], err_msg=k)
+    np.testing.assert_array_equal(eng.download()["Position"], d2["Position"])
+    p3, s3 = dam_break_3d_shipped
+    e3 = make_engine(p3, s3, device_float_bytes=4)
+    np.testing.assert_array_equal(e3.download(components=3)["Position"], e3.download()["Position"])
+    with pytest.raises(Exception):
+        eng.download(components=4)
+
+
 def test_run_simulation_config1_end_to_end(dam_break_2d):
     """BASELINE config 1/2 through the reference's own driver shape: RunSimulation (src/SPHCellList.jl:808-911 mirror)
     with the HIP engine against the same driver with the oracle as backend — 0.05 s of the 2-D dam break
