@@ -450,7 +450,7 @@ struct Engine final : EngineBase {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
         M.ctrl = ctrl;
-        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
+        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
         dim3 g((N + 3) / 4), b(256);               // one wave per particle, four per block

@@ -382,6 +382,7 @@ template <class T> struct MdbcParams {
     using V4 = typename Vec4<T>::type;
     V4* pk0;               // state A: ρ of boundary particles is rewritten in place
     const V4* ghost;       // { g, flag }  flag != 0 ⇔ !iszero(GhostPoint)
+    const uint8_t* type;   // ghost-copy bits (domain decomposition)
     const int* cstart;
     GridDesc g;
     unsigned long long* red;   // red[3]: non-positive density flag
@@ -579,8 +580,13 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
         write = true;
     }
     if (write) {
-        // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
-        if (!(newrho > R(0))) atomicOr(&M.red[3], 1ull);
+        // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive.  A ghost copy far out in a wide halo
+        // sums over a truncated neighbourhood: whatever that gives is never read, must not flip the flag and is
+        // no error (the owner of the particle judges the real value)
+        if (!(newrho > R(0))) {
+            if (M.type[i] & kGhostMask) return;
+            atomicOr(&M.red[3], 1ull);
+        }
         me.w = me.w > T(0) ? (T)newrho : (T)(-newrho);
         M.pk0[i] = me;
     }
