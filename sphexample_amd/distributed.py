@@ -267,10 +267,17 @@ class DistributedEngine:
         self.mdbc = setup.SimMetaData.BMode is SimpleMDBC
         widths = [1] * D
         if self.mdbc:
+            # `off` must not come out one short where a lattice sits exactly on cell edges and the device rounds the
+            # hash the other way (fp32 arithmetic, FMA contraction): take the widest column distance any rounding
+            # within ±1e-4 of a cell could give
             has = np.any(particles.GhostPoints != 0, axis=1)
+            col = lambda u: (np.sign(u) * np.trunc(np.abs(u) + 0.5)).astype(np.int64)          # noqa: E731
             for a in range(D):
-                gx = cell_x_of(particles.GhostPoints[has, a].astype(ft).astype(np.float64), H_inv)
-                widths[a] = 2 + (int(np.abs(gx - cols[a][has]).max()) if has.any() else 0)
+                ug = particles.GhostPoints[has, a].astype(ft).astype(np.float64) * H_inv
+                ux = particles.Position[has, a].astype(ft).astype(np.float64) * H_inv
+                d = 1e-4
+                off = max(int(np.abs(col(ug + d) - col(ux - d)).max()), int(np.abs(col(ug - d) - col(ux + d)).max())) if has.any() else 0
+                widths[a] = 2 + off
         self.axis = choose_axis(cols, world, [max(2, w) for w in widths]) if axis is None else int(axis)
         self.halo_width = W = widths[self.axis]
         cx = cols[self.axis]
