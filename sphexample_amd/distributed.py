@@ -105,7 +105,7 @@ class SlabPlan:
             cuts.append(c)
         cuts.append(hi + 1)
         for r in range(world):
-            if cuts[r + 1] - cuts[r] < min_width:
+            if world > 1 and cuts[r + 1] - cuts[r] < min_width:
                 raise ValueError(f"slab {r} would be narrower than {min_width} cell columns: too many ranks for this domain")
         INF = 1 << 30
         cx_lo = [(-INF if r == 0 else cuts[r]) for r in range(world)]
