@@ -237,6 +237,9 @@ int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi,
                       int has_upper_neighbour);
 int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out);   /* host: global cell index along the slab axis, n ints */
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out);              /* host: type bytes incl. ghost bits */
+/* the same two arrays into DEVICE buffers (n entries, stream order): index lists by device-side compaction */
+int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev);
+int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev);
 int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out);   /* migration buffer size    */
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev);
 int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n);

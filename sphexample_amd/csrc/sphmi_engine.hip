@@ -72,6 +72,8 @@ struct EngineBase {
     virtual int64_t dd_count() = 0;
     virtual void dd_cell_x(int32_t* out_host) = 0;
     virtual void dd_types(uint8_t* out_host) = 0;
+    virtual void dd_cell_x_dev(int32_t* out_dev) = 0;
+    virtual void dd_types_dev(uint8_t* out_dev) = 0;
     virtual size_t dd_record_bytes(int64_t n) = 0;
     virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
     virtual void dd_kill(const int32_t* idx_dev, int64_t n) = 0;
@@ -793,6 +795,17 @@ struct Engine final : EngineBase {
         HC(hipMemcpyAsync(out_host, cellx_d, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
     }
+    // the same two arrays into DEVICE buffers of the caller, in stream order (no host round trip: the driver builds its
+    // migration / ghost-layer / halo index lists with device-side compaction)
+    void dd_cell_x_dev(int32_t* out_dev) override {
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, dd_axis, (int*)out_dev);
+        HC(hipGetLastError());
+    }
+    void dd_types_dev(uint8_t* out_dev) override {
+        HC(hipSetDevice(cfg.device));
+        HC(hipMemcpyAsync(out_dev, type[cur], (size_t)N, hipMemcpyDeviceToDevice, stream));
+    }
     void dd_types(uint8_t* out_host) override {
         HC(hipSetDevice(cfg.device));
         HC(hipMemcpyAsync(out_host, type[cur], (size_t)N, hipMemcpyDeviceToHost, stream));
@@ -1059,6 +1072,8 @@ int sphmi_dd_mdbc(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_mdbc()); }
 int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
 int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }
+int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev) { SPHMI_GUARD(h, h->e->dd_cell_x_dev(cell_x_dev)); }
+int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev) { SPHMI_GUARD(h, h->e->dd_types_dev(type_dev)); }
 int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_gather(idx_dev, n, buf_dev)); }
 int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n) { SPHMI_GUARD(h, h->e->dd_kill(idx_dev, n)); }

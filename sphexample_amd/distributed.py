@@ -346,6 +346,8 @@ class DistributedEngine:
         L.sphmi_dd_count.argtypes = [vp, C.POINTER(i64)]
         L.sphmi_dd_cell_x.argtypes = [vp, vp]
         L.sphmi_dd_types.argtypes = [vp, vp]
+        L.sphmi_dd_cell_x_dev.argtypes = [vp, vp]
+        L.sphmi_dd_types_dev.argtypes = [vp, vp]
         L.sphmi_dd_record_bytes.argtypes = [vp, i64, C.POINTER(i64)]
         L.sphmi_dd_gather.argtypes = [vp, i32p, i64, vp]
         L.sphmi_dd_kill.argtypes = [vp, i32p, i64]
@@ -379,73 +381,77 @@ class DistributedEngine:
         self._call("dd_count", C.byref(n))
         return n.value
 
-    def _cell_x(self) -> np.ndarray:
-        out = np.empty(self._count(), dtype=np.int32)
-        self._call("dd_cell_x", out.ctypes.data_as(C.c_void_p))
-        return out
-
-    def _types(self) -> np.ndarray:
-        out = np.empty(self._count(), dtype=np.uint8)
-        self._call("dd_types", out.ctypes.data_as(C.c_void_p))
-        return out
-
-    def _idx_dev(self, idx: np.ndarray):
-        return self.torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
-
-    def _gather(self, idx: np.ndarray):
-        """Full records of the listed particles → uint8 device tensor (None when empty)."""
-        n = len(idx)
-        if n == 0:
-            return None
-        nb = C.c_int64()
-        self._call("dd_record_bytes", C.c_int64(n), C.byref(nb))
-        buf = self.torch.empty(nb.value, dtype=self.torch.uint8, device=self.device)
-        di = self._idx_dev(idx)
-        self._call("dd_gather", C.c_void_p(di.data_ptr()), C.c_int64(n), C.c_void_p(buf.data_ptr()))
-        self.torch.cuda.current_stream(self.device).synchronize()      # di / buf outlive the kernel
-        return buf
-
     def _record_bytes(self, n: int) -> int:
         nb = C.c_int64()
         self._call("dd_record_bytes", C.c_int64(n), C.byref(nb))
         return nb.value
 
     # -- collective rebuild ------------------------------------------------------------------------
+    def _cell_x_dev(self):
+        """Global cell column of every live particle (ghost copies included) as a device tensor."""
+        t = self.torch.empty(self._count(), dtype=self.torch.int32, device=self.device)
+        self._call("dd_cell_x_dev", C.c_void_p(t.data_ptr()))
+        return t
+
+    def _types_dev(self):
+        t = self.torch.empty(self._count(), dtype=self.torch.uint8, device=self.device)
+        self._call("dd_types_dev", C.c_void_p(t.data_ptr()))
+        return t
+
+    def _where(self, mask):
+        """Ascending int32 indices of the set entries — compaction on the device, nothing large crosses the bus."""
+        return self.torch.nonzero(mask).flatten().to(self.torch.int32)
+
+    def _gather_dev(self, idx):
+        """Full records of the particles listed in the device index tensor → uint8 device tensor (None when empty)."""
+        n = int(idx.numel())
+        if n == 0:
+            return None
+        buf = self.torch.empty(self._record_bytes(n), dtype=self.torch.uint8, device=self.device)
+        self._call("dd_gather", C.c_void_p(idx.data_ptr()), C.c_int64(n), C.c_void_p(buf.data_ptr()))
+        return buf
+
     def _rebuild(self):
+        """Everything that is per particle stays on the device (columns, type bits, index lists by compaction); the
+        host sees counts and the handful of scalars of the load-balance decision."""
         torch = self.torch
-        cx = self._cell_x()
-        ty = self._types()
-        owned = (ty & GHOST_MASK) == 0
+        INF = 1 << 30
+        cx = self._cell_x_dev()
+        owned = (self._types_dev() & GHOST_MASK) == 0
+        empty = torch.empty(0, dtype=torch.int32, device=self.device)
         # 0. load balance: the rebuild is the only time particles change cells, so it is also when the cuts may move
         if self.world > 1 and self.recut_imbalance is not None:
-            co = cx[owned].astype(np.int64)
-            ext = self.comm.allreduce_i64(np.array([-co.min(), co.max(), len(co), -len(co)]), "MAX")
+            co = cx[owned].to(torch.int64)
+            mine = torch.stack([-co.min(), co.max(), torch.tensor(co.numel(), device=self.device), torch.tensor(-co.numel(), device=self.device)])
+            ext = self.comm.allreduce_i64(mine.cpu().numpy(), "MAX")
             gmin, gmax, nmax, nmin = -int(ext[0]), int(ext[1]), int(ext[2]), -int(ext[3])
-            total = self.comm.allreduce_i64(np.array([len(co)]), "SUM")[0]
+            total = self.comm.allreduce_i64(np.array([co.numel()]), "SUM")[0]
             if nmax * self.world > self.recut_imbalance * total:
-                hist = self.comm.allreduce_i64(np.bincount(co - gmin, minlength=gmax - gmin + 1), "SUM")
+                hist = self.comm.allreduce_i64(torch.bincount(co - gmin, minlength=gmax - gmin + 1).cpu().numpy(), "SUM")
                 plan = self.plan.recut(gmin, hist)
                 if plan.cuts() != self.plan.cuts():
                     self.plan = plan
-                    INF = 1 << 30
                     self._call("dd_set_slab", C.c_int(self.axis), C.c_int64(max(plan.cx_lo[self.rank], -INF)),
                                C.c_int64(min(plan.cx_hi[self.rank], INF)), C.c_int(self.rank > 0), C.c_int(self.rank < self.world - 1))
                     self.n_recuts += 1
         lo, hi = self.plan.cx_lo[self.rank], self.plan.cx_hi[self.rank]
         # 1. ghosts die, leavers migrate to the adjacent rank
-        go_l = np.nonzero(owned & (cx < lo))[0]
-        go_r = np.nonzero(owned & (cx > hi))[0]
-        if len(go_l) and (cx[go_l] < self.plan.cx_lo[self.rank - 1]).any() or \
-           len(go_r) and (cx[go_r] > self.plan.cx_hi[self.rank + 1]).any():
+        go_l = self._where(owned & (cx < lo)) if self.comm.left is not None else empty
+        go_r = self._where(owned & (cx > hi)) if self.comm.right is not None else empty
+        skipped = False
+        if go_l.numel():
+            skipped |= bool((cx[go_l.long()] < self.plan.cx_lo[self.rank - 1]).any())
+        if go_r.numel():
+            skipped |= bool((cx[go_r.long()] > self.plan.cx_hi[self.rank + 1]).any())
+        if skipped:
             raise RuntimeError("domain decomposition: a particle skipped a whole slab between two rebuilds")
         self._call("dd_kill_ghosts")
-        sl, sr = self._gather(go_l), self._gather(go_r)
-        nl, nr = self.comm.exchange_counts(len(go_l), len(go_r))
+        sl, sr = self._gather_dev(go_l), self._gather_dev(go_r)
+        nl, nr = self.comm.exchange_counts(int(go_l.numel()), int(go_r.numel()))
         rl, rr = self.comm.exchange(sl, sr, self._record_bytes(nl) if nl else 0, self._record_bytes(nr) if nr else 0)
-        leavers = np.concatenate([go_l, go_r])
-        if len(leavers):
-            di = self._idx_dev(leavers)
-            self._call("dd_kill", C.c_void_p(di.data_ptr()), C.c_int64(len(leavers)))
+        leavers = torch.cat([go_l, go_r])
+        if leavers.numel():
+            self._call("dd_kill", C.c_void_p(leavers.data_ptr()), C.c_int64(int(leavers.numel())))
         for buf, n in ((rl, nl), (rr, nr)):
             if n:
                 self._call("dd_append", C.c_void_p(buf.data_ptr()), C.c_int64(n), C.c_int(0))
@@ -453,11 +459,12 @@ class DistributedEngine:
         self._call("dd_rebuild")
         # 2. the first / last column(s) of the slab become the neighbours' ghost layer
         W = self.halo_width
-        cx = self._cell_x()
-        b_l = np.nonzero(cx < lo + W)[0] if self.comm.left is not None else np.empty(0, np.int64)
-        b_r = np.nonzero(cx > hi - W)[0] if self.comm.right is not None else np.empty(0, np.int64)
-        sl, sr = self._gather(b_l), self._gather(b_r)
-        nl, nr = self.comm.exchange_counts(len(b_l), len(b_r))
+        cx = self._cell_x_dev()
+        b_l = self._where(cx < lo + W) if self.comm.left is not None else empty
+        b_r = self._where(cx > hi - W) if self.comm.right is not None else empty
+        sl, sr = self._gather_dev(b_l), self._gather_dev(b_r)
+        n_bl, n_br = int(b_l.numel()), int(b_r.numel())
+        nl, nr = self.comm.exchange_counts(n_bl, n_br)
         rl, rr = self.comm.exchange(sl, sr, self._record_bytes(nl) if nl else 0, self._record_bytes(nr) if nr else 0)
         if nl:
             self._call("dd_append", C.c_void_p(rl.data_ptr()), C.c_int64(nl), C.c_int(GHOST_LEFT))
@@ -468,25 +475,25 @@ class DistributedEngine:
         # 3. halo index lists in the final order (stable sorts ⇒ k-th sender entry ↔ k-th ghost slot; the same holds
         #    for the sub-lists of ONE column, because both sides see the same positions).  State A travels with all
         #    `halo_width` columns (mDBC reads them), the half-step state H with the one column the pair forces reach.
-        cx = self._cell_x()
-        ty = self._types()
+        cx = self._cell_x_dev()
+        ty = self._types_dev()
         owned = (ty & GHOST_MASK) == 0
-        none = np.empty(0, np.int64)
+        g_l, g_r = (ty & GHOST_LEFT) != 0, (ty & GHOST_RIGHT) != 0
         vb = 2 * self.vbytes
         mk = lambda n: torch.empty(max(n, 1) * vb, dtype=torch.uint8, device=self.device)  # noqa: E731
         self._halo = []
         for w in (W, 1):
-            send_l = np.nonzero(owned & (cx < lo + w))[0] if self.comm.left is not None else none
-            send_r = np.nonzero(owned & (cx > hi - w))[0] if self.comm.right is not None else none
-            slot_l = np.nonzero(((ty & GHOST_LEFT) != 0) & (cx >= lo - w))[0]
-            slot_r = np.nonzero(((ty & GHOST_RIGHT) != 0) & (cx <= hi + w))[0]
+            send_l = self._where(owned & (cx < lo + w)) if self.comm.left is not None else empty
+            send_r = self._where(owned & (cx > hi - w)) if self.comm.right is not None else empty
+            slot_l = self._where(g_l & (cx >= lo - w))
+            slot_r = self._where(g_r & (cx <= hi + w))
             if w == W:
-                assert len(send_l) == len(b_l) and len(send_r) == len(b_r), "boundary columns changed between the two sorts"
-                assert len(slot_l) == nl and len(slot_r) == nr
-            self._halo.append(dict(send_l=self._idx_dev(send_l), send_r=self._idx_dev(send_r),
-                                   slot_l=self._idx_dev(slot_l), slot_r=self._idx_dev(slot_r),
-                                   n_send_l=len(send_l), n_send_r=len(send_r), n_slot_l=len(slot_l), n_slot_r=len(slot_r),
-                                   buf_l=mk(len(send_l)), buf_r=mk(len(send_r))))
+                assert send_l.numel() == n_bl and send_r.numel() == n_br, "boundary columns changed between the two sorts"
+                assert slot_l.numel() == nl and slot_r.numel() == nr
+            self._halo.append(dict(send_l=send_l, send_r=send_r, slot_l=slot_l, slot_r=slot_r,
+                                   n_send_l=int(send_l.numel()), n_send_r=int(send_r.numel()),
+                                   n_slot_l=int(slot_l.numel()), n_slot_r=int(slot_r.numel()),
+                                   buf_l=mk(int(send_l.numel())), buf_r=mk(int(send_r.numel()))))
             if W == 1:
                 self._halo.append(self._halo[0])
                 break
