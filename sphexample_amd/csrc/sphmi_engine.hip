@@ -351,8 +351,9 @@ struct Engine final : EngineBase {
         const int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
         memcpy(bbox_h, init, sizeof(init));
         HC(hipMemcpyAsync(bbox_d, bbox_h, sizeof(init), hipMemcpyHostToDevice, stream));
-        if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
-        else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
+        const int nb_bbox = std::min(nb256, 512);
+        if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb_bbox), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
+        else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb_bbox), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
         HC(hipGetLastError());
         HC(hipMemcpyAsync(bbox_h, bbox_d, 6 * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));

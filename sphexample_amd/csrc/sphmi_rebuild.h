@@ -41,20 +41,29 @@ constexpr uint8_t kGhostLeft = 0x80, kGhostRight = 0x40, kGhostMask = 0xC0, kTyp
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
                                                    T inv_cutoff, int* bbox) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int ic = i < N ? i : N - 1;
-    auto p = pk0[ic];
-    const bool live = i < N && type[ic] != 0;
-    int c[3] = {map_floor<T>(p.x, inv_cutoff), map_floor<T>(p.y, inv_cutoff),
-                D == 3 ? map_floor<T>(p.z, inv_cutoff) : 0};
+    // grid-stride: a few hundred blocks, so that the six atomics per WAVE are a few thousand in total — one wave per
+    // 64 particles (16 k waves at 1 M) spent 228 µs queueing on the one cache line, for 16 MB of streaming reads
+    int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        if (type[i] == 0) continue;
+        const auto p = pk0[i];
+        const int c[3] = {map_floor<T>(p.x, inv_cutoff), map_floor<T>(p.y, inv_cutoff),
+                          D == 3 ? map_floor<T>(p.z, inv_cutoff) : 0};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = c[d] < mn[d] ? c[d] : mn[d]; mx[d] = c[d] > mx[d] ? c[d] : mx[d]; }
+    }
+    __shared__ int s_box[4][6];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        int mn = wave_min_i(live ? c[d] : INT32_MAX), mx = wave_max_i(live ? c[d] : INT32_MIN);
-        if ((threadIdx.x & 63) == 0) {
-            // almost every wave is inside the box already: test before paying for the atomic
-            if (mn < __hip_atomic_load(&bbox[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bbox[d], mn);
-            if (mx > __hip_atomic_load(&bbox[3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bbox[3 + d], mx);
-        }
+        const int lo = wave_min_i(mn[d]), hi = wave_max_i(mx[d]);
+        if ((threadIdx.x & 63) == 0) { s_box[threadIdx.x >> 6][d] = lo; s_box[threadIdx.x >> 6][3 + d] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        int v = s_box[0][d];
+        for (int w = 1; w < 4; ++w) v = d < 3 ? (s_box[w][d] < v ? s_box[w][d] : v) : (s_box[w][d] > v ? s_box[w][d] : v);
+        if (d < 3) atomicMin(&bbox[d], v); else atomicMax(&bbox[d], v);
     }
 }
 
@@ -67,16 +76,34 @@ struct GridDesc {
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
                                                     T inv_cutoff, GridDesc g, int* count, int* key, int* slot) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    auto p = pk0[i];
-    int cx = map_floor<T>(p.x, inv_cutoff) - g.gmin[0] + 1;
-    int cy = map_floor<T>(p.y, inv_cutoff) - g.gmin[1] + 1;
-    int cz = D == 3 ? map_floor<T>(p.z, inv_cutoff) - g.gmin[2] + 1 : 0;
-    int k = cx + g.np[0] * (cy + g.np[1] * cz);
-    if (type[i] == 0) k = g.ncell;          // dead particles sort behind every cell ("graveyard" key)
-    key[i] = k;
-    slot[i] = atomicAdd(&count[k], 1);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int k = -1;                               // lanes past the end: a key no particle has
+    if (i < N) {
+        auto p = pk0[i];
+        int cx = map_floor<T>(p.x, inv_cutoff) - g.gmin[0] + 1;
+        int cy = map_floor<T>(p.y, inv_cutoff) - g.gmin[1] + 1;
+        int cz = D == 3 ? map_floor<T>(p.z, inv_cutoff) - g.gmin[2] + 1 : 0;
+        k = cx + g.np[0] * (cy + g.np[1] * cz);
+        if (type[i] == 0) k = g.ncell;        // dead particles sort behind every cell ("graveyard" key)
+        key[i] = k;
+    }
+    // The particles arrive in the previous sorted order, so a wave holds a few RUNS of equal keys: one atomic per run
+    // (its first lane adds the run length and hands out base + offset) instead of 64 colliding returning atomics.
+    // Any numbering of a cell's particles will do here — k_rankfix restores the stable order.
+    const int kprev = __shfl_up(k, 1, 64);
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(lane == 0 || k != kprev);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));                 // heads at or below this lane
+    const int start = 63 - __builtin_clzll(upto);                                   // first lane of my run
+    const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+    const int next = above ? __builtin_ctzll(above) : 64;                           // first lane of the next run
+    int base = 0;
+    if (lane == start && i < N) {
+        // my run ends at the next head — seen from the run's first lane
+        base = atomicAdd(&count[k], next - start);
+    }
+    base = __shfl(base, start, 64);
+    if (i < N) slot[i] = base + (lane - start);
 }
 
 // ---- exclusive scan over the cell histogram (3 launches) ------------------------------------
