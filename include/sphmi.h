@@ -240,6 +240,10 @@ int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out);              /* host: ty
 /* the same two arrays into DEVICE buffers (n entries, stream order): index lists by device-side compaction */
 int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev);
 int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev);
+/* Work per cell column for the load balance: cost_dev[c] += Σ over the OWNED particles of column col0 + c of the
+ * candidates in their 3^D cells (cell list of the last rebuild) — what a particle costs in the neighbour kernel;
+ * cost_dev: ncols zero-initialised uint64 on the device. */
+int sphmi_dd_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_dev);
 int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out);   /* migration buffer size    */
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev);
 int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n);

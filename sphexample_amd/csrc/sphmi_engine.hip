@@ -73,6 +73,7 @@ struct EngineBase {
     virtual void dd_cell_x(int32_t* out_host) = 0;
     virtual void dd_types(uint8_t* out_host) = 0;
     virtual void dd_cell_x_dev(int32_t* out_dev) = 0;
+    virtual void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) = 0;
     virtual void dd_types_dev(uint8_t* out_dev) = 0;
     virtual size_t dd_record_bytes(int64_t n) = 0;
     virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
@@ -803,6 +804,13 @@ struct Engine final : EngineBase {
         hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, dd_axis, (int*)out_dev);
         HC(hipGetLastError());
     }
+    void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) override {
+        if (!have_grid) throw EngineError(SPHMI_ERR_STATE, "sphmi_dd_column_cost before the first rebuild");
+        HC(hipSetDevice(cfg.device));
+        hipLaunchKernelGGL(k_dd_column_cost, dim3((N + 255) / 256), dim3(256), 0, stream, key[cur], type[cur], cstart, N, grid, D, dd_axis,
+                           (long long)col0, (int)ncols, (unsigned long long*)out_dev);
+        HC(hipGetLastError());
+    }
     void dd_types_dev(uint8_t* out_dev) override {
         HC(hipSetDevice(cfg.device));
         HC(hipMemcpyAsync(out_dev, type[cur], (size_t)N, hipMemcpyDeviceToDevice, stream));
@@ -1074,6 +1082,7 @@ int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { SPHMI_GUARD(h, *n_out = h-
 int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }
 int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev) { SPHMI_GUARD(h, h->e->dd_cell_x_dev(cell_x_dev)); }
+int sphmi_dd_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_dev) { SPHMI_GUARD(h, h->e->dd_column_cost(col0, ncols, cost_dev)); }
 int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev) { SPHMI_GUARD(h, h->e->dd_types_dev(type_dev)); }
 int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_gather(idx_dev, n, buf_dev)); }

@@ -712,6 +712,29 @@ __global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* 
     }
 }
 
+// Load balance by WORK, not by particle count: the cost of a particle in the neighbour kernel goes with the candidates of
+// its 3^D cells (a dry wall particle has a tenth of an interior fluid particle's).  Per cell column along the slab axis:
+// Σ over OWNED particles of that candidate count, from the cell list of the last rebuild.
+__global__ void __launch_bounds__(256) k_dd_column_cost(const int* key, const uint8_t* type, const int* cstart, int N, GridDesc g,
+                                                        int D, int axis, long long col0, int ncols, unsigned long long* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint8_t t = type[i];
+    if (t == 0 || (t & kGhostMask)) return;
+    const int k = key[i];
+    if (k >= g.ncell) return;
+    const int nxp = g.np[0], nxyp = g.np[0] * g.np[1];
+    const int nseg = D == 3 ? 9 : 3;
+    int c = 0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
+        c += cstart[k + off + 2] - cstart[k + off - 1];
+    }
+    const int cc[3] = {k % nxp, (k / nxp) % g.np[1], k / nxyp};
+    const long long col = (long long)cc[axis] - 1 + g.gmin[axis] - col0;
+    if (col >= 0 && col < ncols) atomicAdd(&out[col], (unsigned long long)c);
+}
+
 // Migration record buffer for n particles:
 // [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][n×i64 id][n×u64 group][n×u64 order tag][n×u8 type]
 template <class T> struct DdRecord {

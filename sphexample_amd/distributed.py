@@ -60,22 +60,73 @@ def cell_x_of(x: np.ndarray, H_inv: float) -> np.ndarray:
     return (np.sign(x) * np.trunc(np.abs(x) * H_inv + 0.5)).astype(np.int64)
 
 
-def choose_axis(cols: List[np.ndarray], world: int, min_width=2) -> int:
-    """Slab axis: the one whose equal-count column cuts leave the lightest heaviest rank.  Ties go to the
-    slowest sort axis (its ghost layers are contiguous runs of the cell-sorted arrays).  `min_width`: columns a
-    slab must keep — a number, or one number per axis (the halo width, which depends on the axis with mDBC)."""
-    best, best_load = 0, None
+def best_cuts(hist: np.ndarray, world: int, width: int, lo_b=None, hi_b=None) -> Optional[List[int]]:
+    """Cut positions c_1 < … < c_{world-1} (slab r = columns c_r … c_{r+1}-1, c_0 = 0, c_world = len(hist)) that
+    MINIMISE THE HEAVIEST SLAB, every slab at least `width` columns, cut r within [lo_b[r], hi_b[r]] when given.
+    Exact (dynamic programme over the columns): with a dozen columns per slab one column is a tenth of a slab's work,
+    and cutting at the quantiles of the cumulative work can be that far from the best partition.  None: infeasible."""
+    n = len(hist)
+    cum = np.concatenate([[0.0], np.cumsum(hist, dtype=np.float64)])
+    INF = float("inf")
+    f = np.full(n + 1, INF); f[0] = 0.0                       # f[c]: best heaviest-slab value with the current cut at c
+    back = []
+    for r in range(1, world + 1):
+        g = np.full(n + 1, INF); arg = np.zeros(n + 1, dtype=np.int64)
+        cs = [n] if r == world else range(max(r * width, 0 if lo_b is None else lo_b[r]),
+                                          min(n - (world - r) * width, n if hi_b is None else hi_b[r]) + 1)
+        for c in cs:
+            prev = np.arange(0, c - width + 1)
+            if len(prev) == 0:
+                continue
+            v = np.maximum(f[prev], cum[c] - cum[prev])
+            k = int(np.argmin(v))
+            g[c], arg[c] = v[k], prev[k]
+        f = g; back.append(arg)
+    if not np.isfinite(f[n]):
+        return None
+    cuts, c = [], n
+    for r in range(world, 0, -1):
+        c = int(back[r - 1][c]); cuts.append(c)
+    return list(reversed(cuts))[1:]                           # drop c_0 = 0
+
+
+def particle_work(cols: List[np.ndarray]) -> np.ndarray:
+    """What a particle costs in the neighbour kernel: the number of candidates in the 3^D cells around its own (the
+    measure of the engine's tile schedule and of sphmi_dd_column_cost).  A dry wall particle has a tenth of an interior
+    fluid particle's, so cuts that equalise particle COUNTS leave the rank with the dry walls short of work."""
+    lo = [int(c.min()) for c in cols]
+    dims = [int(c.max()) - l + 3 for c, l in zip(cols, lo)]                    # one cell of padding per side
+    lin = np.zeros(len(cols[0]), dtype=np.int64)
+    for c, l, d in zip(reversed(cols), reversed(lo), reversed(dims)):           # last axis slowest, like the cell sort
+        lin = lin * d + (c - l + 1)
+    grid = np.bincount(lin, minlength=int(np.prod(dims))).reshape(list(reversed(dims)))
+    box = grid.astype(np.int64)
+    for ax in range(box.ndim):                                                  # separable 3-wide box sum
+        up, dn = np.roll(box, 1, axis=ax), np.roll(box, -1, axis=ax)            # padding cells are empty: no wrap-around
+        box = box + up + dn
+    return box.reshape(-1)[lin]
+
+
+def choose_axis(cols: List[np.ndarray], world: int, min_width=2, weights: Optional[np.ndarray] = None) -> int:
+    """Slab axis: the one whose best column cuts leave the lightest heaviest rank (by `weights` = particle_work, else by
+    count).  Axes within 1 % of the best are a tie, won by the thinnest ghost layers (fewest particles in the columns next
+    to the cuts: fewer slab-edge tiles waiting for the halo), then by the slowest sort axis (its ghost layers are
+    contiguous runs of the cell-sorted arrays).  `min_width`: columns a slab must keep — a number, or one per axis (the
+    halo width, which depends on the axis with mDBC)."""
+    cand = []
     for ax, cx in enumerate(cols):
         try:
-            plan = SlabPlan.from_columns(cx, world, min_width if np.isscalar(min_width) else min_width[ax])
+            plan = SlabPlan.from_columns(cx, world, min_width if np.isscalar(min_width) else min_width[ax], weights)
         except ValueError:
             continue
-        load = np.bincount(plan.owner_of(cx), minlength=world).max()
-        if best_load is None or load <= best_load:
-            best, best_load = ax, load
-    if best_load is None:
+        load = np.bincount(plan.owner_of(cx), weights=weights, minlength=world).max()
+        edge = np.zeros(0, dtype=np.int64) if world == 1 else np.concatenate([[c - 1, c] for c in plan.cuts()])
+        cand.append((float(load), int(np.isin(cx, edge).sum()), ax))
+    if not cand:
         raise ValueError("no axis has enough cell columns per rank: too many ranks for this domain")
-    return best
+    best = min(c[0] for c in cand)
+    tie = [c for c in cand if c[0] <= 1.01 * best]
+    return min(tie, key=lambda c: (c[1], -c[2]))[2]
 
 
 @dataclass
@@ -90,23 +141,15 @@ class SlabPlan:
         return len(self.cx_lo)
 
     @staticmethod
-    def from_columns(cx: np.ndarray, world: int, min_width: int = 2) -> "SlabPlan":
-        """Equal-particle-count cuts on column boundaries (a uniform spatial cut would put the whole
-        initial water column on a quarter of the ranks)."""
+    def from_columns(cx: np.ndarray, world: int, min_width: int = 2, weights: Optional[np.ndarray] = None) -> "SlabPlan":
+        """Equal-WORK cuts on column boundaries (`weights`: particle_work; equal particle counts without) — a uniform
+        spatial cut would put the whole initial water column on a quarter of the ranks."""
         lo, hi = int(cx.min()), int(cx.max())
-        hist = np.bincount(cx - lo, minlength=hi - lo + 1)
-        cum = np.cumsum(hist)
-        total = int(cum[-1])
-        cuts = [lo]
-        for r in range(1, world):
-            # first column whose cumulative count reaches r/world of the particles
-            c = lo + int(np.searchsorted(cum, total * r / world, side="left")) + 1
-            c = max(c, cuts[-1] + min_width)    # every slab at least two (or halo-width) columns wide
-            cuts.append(c)
-        cuts.append(hi + 1)
-        for r in range(world):
-            if world > 1 and cuts[r + 1] - cuts[r] < min_width:
-                raise ValueError(f"slab {r} would be narrower than {min_width} cell columns: too many ranks for this domain")
+        hist = np.bincount(cx - lo, weights=weights, minlength=hi - lo + 1)
+        inner = best_cuts(hist, world, min_width if world > 1 else 1)
+        if inner is None:
+            raise ValueError(f"a slab would be narrower than {min_width} cell columns: too many ranks for this domain")
+        cuts = [lo] + [lo + c for c in inner] + [hi + 1]
         INF = 1 << 30
         cx_lo = [(-INF if r == 0 else cuts[r]) for r in range(world)]
         cx_hi = [(INF if r == world - 1 else cuts[r + 1] - 1) for r in range(world)]
@@ -117,19 +160,17 @@ class SlabPlan:
         return [self.cx_lo[r] for r in range(1, self.world)]
 
     def recut(self, col0: int, hist: np.ndarray) -> "SlabPlan":
-        """Equal-count cuts for the CURRENT global column histogram (`hist[k]` = particles in column col0 + k), with
-        every cut kept between its two old neighbours (so a particle changes rank by at most one — migration stays a
-        neighbour exchange) and every slab at least `min_width` columns wide."""
+        """Best cuts (lightest heaviest slab) for the CURRENT global column histogram (`hist[k]` = work, or particles,
+        of column col0 + k), with every cut kept between its two old neighbours (so a particle changes rank by at most
+        one — migration stays a neighbour exchange) and every slab at least `min_width` columns wide."""
         world, w = self.world, self.min_width
-        cum = np.cumsum(hist)
-        total = int(cum[-1])
-        old = [col0] + self.cuts() + [col0 + len(hist)]
-        new = [old[0]]
-        for r in range(1, world):
-            c = col0 + int(np.searchsorted(cum, total * r / world, side="left")) + 1
-            lo = max(old[r - 1] + w, new[-1] + w)               # not past the old cut on the left, slab r−1 ≥ w columns
-            hi = old[r + 1] - w                                  # not past the old cut on the right
-            new.append(min(max(c, lo), hi) if lo <= hi else old[r])
+        n = len(hist)
+        old = [col0] + self.cuts() + [col0 + n]
+        # cut r may move between its old neighbours, a slab width away from both
+        lo_b = [0] + [old[r - 1] + w - col0 for r in range(1, world)] + [n]
+        hi_b = [0] + [old[r + 1] - w - col0 for r in range(1, world)] + [n]
+        inner = best_cuts(np.asarray(hist, dtype=np.float64), world, w, lo_b, hi_b)
+        new = old[:-1] if inner is None else [old[0]] + [col0 + c for c in inner]
         INF = 1 << 30
         return SlabPlan([(-INF if r == 0 else new[r]) for r in range(world)],
                         [(INF if r == world - 1 else new[r + 1] - 1) for r in range(world)], w)
@@ -278,10 +319,11 @@ class DistributedEngine:
                 d = 1e-4
                 off = max(int(np.abs(col(ug + d) - col(ux - d)).max()), int(np.abs(col(ug - d) - col(ux + d)).max())) if has.any() else 0
                 widths[a] = 2 + off
-        self.axis = choose_axis(cols, world, [max(2, w) for w in widths]) if axis is None else int(axis)
+        work = particle_work(cols) if world > 1 else None
+        self.axis = choose_axis(cols, world, [max(2, w) for w in widths], work) if axis is None else int(axis)
         self.halo_width = W = widths[self.axis]
         cx = cols[self.axis]
-        self.plan = plan if plan is not None else SlabPlan.from_columns(cx, world, max(2, W))   # `plan`: start from given cuts
+        self.plan = plan if plan is not None else SlabPlan.from_columns(cx, world, max(2, W), work)   # `plan`: start from given cuts
         self.plan.min_width = max(self.plan.min_width, W)
         mine = np.nonzero(self.plan.owner_of(cx) == rank)[0]
         self.n_total = len(particles)
@@ -347,6 +389,7 @@ class DistributedEngine:
         L.sphmi_dd_cell_x.argtypes = [vp, vp]
         L.sphmi_dd_types.argtypes = [vp, vp]
         L.sphmi_dd_cell_x_dev.argtypes = [vp, vp]
+        L.sphmi_dd_column_cost.argtypes = [vp, i64, C.c_int32, vp]
         L.sphmi_dd_types_dev.argtypes = [vp, vp]
         L.sphmi_dd_record_bytes.argtypes = [vp, i64, C.POINTER(i64)]
         L.sphmi_dd_gather.argtypes = [vp, i32p, i64, vp]
@@ -419,15 +462,19 @@ class DistributedEngine:
         cx = self._cell_x_dev()
         owned = (self._types_dev() & GHOST_MASK) == 0
         empty = torch.empty(0, dtype=torch.int32, device=self.device)
-        # 0. load balance: the rebuild is the only time particles change cells, so it is also when the cuts may move
-        if self.world > 1 and self.recut_imbalance is not None:
+        # 0. load balance by WORK (candidates per particle, sphmi_dd_column_cost on the cell list of the previous rebuild):
+        #    the rebuild is the only time particles change cells, so it is also when the cuts may move
+        if self.world > 1 and self.recut_imbalance is not None and self.n_rebuilds > 0:
             co = cx[owned].to(torch.int64)
-            mine = torch.stack([-co.min(), co.max(), torch.tensor(co.numel(), device=self.device), torch.tensor(-co.numel(), device=self.device)])
-            ext = self.comm.allreduce_i64(mine.cpu().numpy(), "MAX")
-            gmin, gmax, nmax, nmin = -int(ext[0]), int(ext[1]), int(ext[2]), -int(ext[3])
-            total = self.comm.allreduce_i64(np.array([co.numel()]), "SUM")[0]
-            if nmax * self.world > self.recut_imbalance * total:
-                hist = self.comm.allreduce_i64(torch.bincount(co - gmin, minlength=gmax - gmin + 1).cpu().numpy(), "SUM")
+            ext = self.comm.allreduce_i64(torch.stack([-co.min(), co.max()]).cpu().numpy(), "MAX")
+            gmin, gmax = -int(ext[0]), int(ext[1])
+            cost = torch.zeros(gmax - gmin + 1, dtype=torch.int64, device=self.device)
+            self._call("dd_column_cost", C.c_int64(gmin), C.c_int32(gmax - gmin + 1), C.c_void_p(cost.data_ptr()))
+            mine = int(cost.sum())
+            wmax = int(self.comm.allreduce_i64(np.array([mine]), "MAX")[0])
+            total = int(self.comm.allreduce_i64(np.array([mine]), "SUM")[0])
+            if wmax * self.world > self.recut_imbalance * total:
+                hist = self.comm.allreduce_i64(cost.cpu().numpy(), "SUM")
                 plan = self.plan.recut(gmin, hist)
                 if plan.cuts() != self.plan.cuts():
                     self.plan = plan

@@ -45,7 +45,7 @@ def comm_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overlap=True, recut=1.05, cut_shift=0):
+def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overlap=True, recut=1.05, cut_shift=0, calls=1):
     """2 ranks sharing GPU 0 (gloo staging): slab engines vs nothing — rank 0 stores the gathered result."""
     dist = _init(rank, world, port)
     import conftest
@@ -63,7 +63,8 @@ def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overla
     eng = DistributedEngine(p, s, rank, world, local_device=0, plan=plan, device_float_bytes=fb, axis=axis, overlap=overlap, recut_imbalance=recut)
     if hasattr(p, "geometries"):
         eng.set_motions(p.geometries)
-    pr = eng.advance(1e9, max_steps=steps)
+    for _ in range(calls):            # every call re-arms Δx = 1 + h: a rebuild (and a chance to re-cut) at its first step
+        pr = eng.advance(1e9, max_steps=steps // calls)
     res = eng.gather_all()
     if rank == 0:
         np.savez(os.path.join(out_dir, "dd.npz"), iteration=pr.iteration, total_time=pr.total_time,

@@ -50,9 +50,62 @@ def test_choose_axis_prefers_the_evenly_filled_direction(dam_break_3d_shipped):
         plan = SlabPlan.from_columns(cols[ax], 2)
         loads[ax] = np.bincount(plan.owner_of(cols[ax]), minlength=2).max()
     ax = choose_axis(cols, 2)
-    assert loads[ax] == min(loads.values())
+    assert loads[ax] <= 1.01 * min(loads.values())               # within 1 % the thinner ghost layer decides
     with pytest.raises(ValueError):
         choose_axis([np.zeros(10, dtype=np.int64)], 2)          # one column cannot be split
+
+
+def test_cuts_balance_work_not_counts():
+    """particle_work = candidates in the 3^D cells around a particle (what it costs in the neighbour kernel); best_cuts
+    = the exact lightest-heaviest-slab partition.  On the generated dam break, count-balanced cuts along x leave the
+    rank with the dry walls ≈10 % short of work; the work-balanced plan picks y and stays within a column's worth."""
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    from sphexample_amd.distributed import best_cuts, particle_work
+    dp = 0.0085
+    p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
+    cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(3)]
+    w = particle_work(cols)
+    # brute-force check of the measure on a few particles
+    lin = {}
+    key = list(zip(*cols))
+    from collections import Counter
+    cnt = Counter(key)
+    for i in (0, len(p) // 3, len(p) - 1):
+        c = key[i]
+        assert w[i] == sum(cnt.get((c[0] + a, c[1] + b, c[2] + d), 0) for a in (-1, 0, 1) for b in (-1, 0, 1) for d in (-1, 0, 1))
+    assert w[p.Type == 1].mean() > 3 * w[p.Type != 1].mean()
+    ax = choose_axis(cols, 2, 2, w)
+    plan = SlabPlan.from_columns(cols[ax], 2, 2, w)
+    load = np.bincount(plan.owner_of(cols[ax]), weights=w, minlength=2)
+    by_count = SlabPlan.from_columns(cols[0], 2)
+    load0 = np.bincount(by_count.owner_of(cols[0]), weights=w, minlength=2)
+    # 23 columns along y at this resolution: one column is 4 % of the work
+    assert ax == 1 and load.max() / load.mean() < 1.05 < load0.max() / load0.mean()
+    # best_cuts against exhaustive search on a small histogram, with and without bounds
+    rng = np.random.default_rng(3)
+    h = rng.integers(0, 50, size=12).astype(float)
+    import itertools
+    def brute(world, width, lo=None, hi=None):
+        best = None
+        for cs in itertools.combinations(range(1, 12), world - 1):
+            e = (0,) + cs + (12,)
+            if any(e[k + 1] - e[k] < width for k in range(world)):
+                continue
+            if lo and any(not (lo[r] <= cs[r - 1] <= hi[r]) for r in range(1, world)):
+                continue
+            m = max(h[e[k]:e[k + 1]].sum() for k in range(world))
+            best = m if best is None else min(best, m)
+        return best
+    for world, width in ((2, 2), (3, 2), (4, 3), (4, 2)):
+        cs = best_cuts(h, world, width)
+        e = [0] + cs + [12]
+        assert max(h[e[k]:e[k + 1]].sum() for k in range(world)) == brute(world, width)
+    lo, hi = [0, 3, 6, 12], [0, 5, 9, 12]
+    cs = best_cuts(h, 3, 2, lo, hi)
+    e = [0] + cs + [12]
+    assert lo[1] <= cs[0] <= hi[1] and lo[2] <= cs[1] <= hi[2]
+    assert max(h[e[k]:e[k + 1]].sum() for k in range(3)) == brute(3, 2, lo, hi)
+    assert best_cuts(h, 7, 2) is None
 
 
 def test_slab_plan_keeps_halo_wide_slabs():
@@ -157,18 +210,18 @@ def test_more_slabs_match_single_gpu(world, request):
 def test_two_slabs_with_moving_cuts(request):
     """Start from cuts that are four columns off balance: the first rebuilds move them back (particles migrate, the
     ghost layers and halo lists are rebuilt) and the result is still the single-GPU one."""
-    dd = _two_slabs("dam_break_3d_shipped", 80, 8, 1e-9, 0, True, 1.05, request, cut_shift=4)
+    dd = _two_slabs("dam_break_3d_shipped", 80, 8, 1e-9, 0, True, 1.05, request, cut_shift=4, calls=2)
     assert int(dd["n_recuts"]) >= 1
 
 
 @pytest.mark.gpu
 def test_two_slabs_with_moving_cuts_mdbc(request):
     """The same with mDBC: five-column ghost layers, ghost nodes in the records, slabs never narrower than the halo."""
-    dd = _two_slabs("dam_break_2d_mdbc", 80, 8, 1e-9, 0, True, 1.02, request, cut_shift=3)
+    dd = _two_slabs("dam_break_2d_mdbc", 80, 8, 1e-9, 0, True, 1.02, request, cut_shift=3, calls=2)
     assert int(dd["n_recuts"]) >= 1 and int(dd["halo_width"]) == 5
 
 
-def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0, world=2):
+def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0, world=2, calls=1):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
     import torch.multiprocessing as mp
@@ -178,10 +231,11 @@ def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0,
     ref = make_engine(p, s, device_float_bytes=fb)
     if hasattr(p, "geometries"):
         ref.set_motions(p.geometries)
-    pr = ref.advance(1e9, max_steps=steps)
+    for _ in range(calls):
+        pr = ref.advance(1e9, max_steps=steps // calls)
     r = ref.download(("Position", "Density", "ID", "Velocity"))
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(engine_worker, args=(world, _free_port(), d, case, steps, fb, axis, overlap, recut, cut_shift), nprocs=world, join=True)
+        mp.spawn(engine_worker, args=(world, _free_port(), d, case, steps, fb, axis, overlap, recut, cut_shift, calls), nprocs=world, join=True)
         dd = dict(np.load(os.path.join(d, "dd.npz")))
     assert axis is None or int(dd["axis"]) == axis
     from sphexample_amd.config import SimpleMDBC
