@@ -122,7 +122,8 @@ struct Engine final : EngineBase {
     V4* kout_d = nullptr;              // StoreKernelOutput: { Σ∇W, ΣW } per particle
     MotionTable motions{};
     StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control + its pinned mirror
-    static constexpr int kBatch = 8;   // steps queued between two looks at the control flags
+    static constexpr int kBatch = 16;  // most steps queued between two looks at the control flags
+    double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
     static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
@@ -510,7 +511,12 @@ struct Engine final : EngineBase {
             for (;;) {
                 const int a0 = iA, b0 = iB;
                 const int64_t before = steps;
+                const double dx0 = delta_x;
+                // queue up to the step that is expected to ask for the rebuild (Δx grows by 4·max|Δx| a step, slowly
+                // changing), not beyond: what follows it in a batch is cancelled.  The first control of a call always asks.
                 int batch = kBatch;
+                if (dx0 >= cfg.h) batch = 1;
+                else if (dx_rate > 0.0) batch = (int)std::max(1.0, std::min((double)kBatch, std::floor((cfg.h - dx0) / dx_rate) + 1.0));
                 if (max_steps >= 0) batch = (int)std::min<int64_t>(batch, std::max<int64_t>(max_steps - steps, 1));
                 for (int k = 0; k < batch; ++k) { batch_step = k; enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
                 batch_step = -1;
@@ -524,6 +530,10 @@ struct Engine final : EngineBase {
                 iA = (executed & 1) ? b0 : a0; iB = (executed & 1) ? a0 : b0;
                 if (executed > 0) stepped = true;
                 total_time = c.total_time; last_dt = c.last_dt; delta_x = c.delta_x;
+                {
+                    const int64_t grown = executed + (c.need_rebuild ? 1 : 0);    // controls that added their 4·max|Δx|
+                    if (grown > 0 && dx0 < cfg.h && c.delta_x > dx0) dx_rate = (c.delta_x - dx0) / (double)grown;
+                }
                 if (c.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
                 if (c.error) {
                     char buf[160];

@@ -19,7 +19,7 @@ bit-identical on all ranks.
 
 Per step (mirrors ``Engine::step_once`` in csrc/sphmi_engine.hip):
     reductions → allreduce(MAX) → k_step_control on the device (Δx, dt, rebuild / stop flags; the host looks at
-    them once per batch of 8 queued steps) → [rebuild: migrate, re-ghost, sort] →
+    them once per batch of up to 16 queued steps, sized to end at the step expected to ask for a rebuild) → [rebuild: migrate, re-ghost, sort] →
     halo(state A) ‖ predictor on interior tiles → predictor on slab-edge tiles →
     halo(half-step state H) ‖ corrector on interior tiles → corrector on slab-edge tiles
 Ghost copies are ordinary entries of the rank's sorted particle array (type bits 0x80 / 0x40); the
@@ -376,6 +376,7 @@ class DistributedEngine:
         self.n_rebuilds = 0
         self._halo = None
         self._keep = [None, None]
+        self._dx_rate = 0.0                     # Δx per step, from the last batch (sizes the next one)
 
     # -- ctypes plumbing -----------------------------------------------------------------------------
     def _declare(self):
@@ -599,7 +600,7 @@ class DistributedEngine:
         main.wait_stream(side)                       # the next pack / the reductions need the edge tiles
 
     # -- the SimulationLoop of src/SPHCellList.jl:727-805, distributed --------------------------------
-    BATCH = 8      # steps queued between two looks at the control flags
+    BATCH = 16     # most steps queued between two looks at the control flags
 
     def advance(self, t_target: float, max_steps: int = -1) -> SphmiProgress:
         with self.torch.cuda.stream(self._main):
@@ -618,10 +619,19 @@ class DistributedEngine:
         st = SphmiDdControl()
         first = True
         while True:
-            batch = self.BATCH if max_steps < 0 else max(1, min(self.BATCH, max_steps - steps))
+            # A step that asks for a rebuild cancels the rest of its batch, and a cancelled step still pays its allreduce
+            # and its four point-to-point messages: queue up to the step that is EXPECTED to ask — Δx grows by 4·max|Δx|
+            # a step, at a rate that changes slowly — and no further.  Every rank computes the same number from the same
+            # (allreduced) values.
+            batch = self.BATCH
+            if self._dx_rate > 0.0:
+                batch = max(1, min(batch, int((cfg.h - self.delta_x) / self._dx_rate) + 1))
+            if max_steps >= 0:
+                batch = max(1, min(batch, max_steps - steps))
             if first:
                 batch = 1          # the loop re-arms Δx = 1 + h: the first control of a call always asks for a rebuild
                 first = False
+            dx0, steps0 = self.delta_x, steps
             for _ in range(batch):
                 # local maxima → global maxima → decisions, without leaving the device
                 self._call("dd_reductions_dev", C.c_void_p(red_t.data_ptr()))
@@ -633,6 +643,9 @@ class DistributedEngine:
             self._call("dd_ctrl_sync", C.byref(st))                   # the one host synchronisation of the batch
             steps = st.steps_done
             self.total_time, self.last_dt, self.delta_x = st.total_time, st.last_dt, st.delta_x
+            grown = (steps - steps0) + (1 if st.need_rebuild else 0)          # controls that added their 4·max|Δx|
+            if grown > 0 and dx0 < cfg.h and st.delta_x > dx0:
+                self._dx_rate = (st.delta_x - dx0) / grown
             if st.error == 2:
                 raise RuntimeError("non-positive density produced on some rank")
             if st.error:

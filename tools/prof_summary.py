@@ -9,7 +9,7 @@ import sys
 
 def main(path):
     db = sqlite3.connect(path)
-    # Steps are queued in batches of 8 with the control on the device (k_step_control): the pass kernels of a step
+    # Steps are queued in batches of up to 16 with the control on the device (k_step_control): the pass kernels of a step
     # the control cancelled (rebuild pending, loop bound reached) return at once.  Those launches (< 5 % of the
     # kernel's longest one) are counted separately so that the averages describe the launches that did the work.
     rows = db.execute(
