@@ -71,3 +71,26 @@ def engine_worker(rank, world, port, out_dir, case, steps, fb, axis=None, overla
                  n_rebuilds=pr.n_rebuilds, axis=eng.axis, n_recuts=eng.n_recuts, halo_width=eng.halo_width, **res)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def cost_worker(rank, world, port, out_dir, case, axis):
+    """Per-column work of sphmi_dd_column_cost (device, cell list of the first rebuild) summed over the ranks."""
+    dist = _init(rank, world, port)
+    import ctypes as C
+    import torch
+    import conftest
+    from sphexample_amd.distributed import DistributedEngine
+    p, s = getattr(conftest, "load_" + case)()
+    eng = DistributedEngine(p, s, rank, world, local_device=0, device_float_bytes=8, axis=axis)
+    eng.advance(1e9, max_steps=1)                 # the first control asks for the rebuild: cell list of the INITIAL positions
+    col0, ncols = -8, 400
+    with torch.cuda.stream(eng._main):
+        cost = torch.zeros(ncols, dtype=torch.int64, device=eng.device)
+        eng._call("dd_column_cost", C.c_int64(col0), C.c_int32(ncols), C.c_void_p(cost.data_ptr()))
+        eng._main.synchronize()
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(cost.cpu().numpy(), parts, dst=0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "cost.npz"), cost=np.sum(parts, axis=0), col0=col0, axis=eng.axis)
+    dist.barrier()
+    dist.destroy_process_group()

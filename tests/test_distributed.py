@@ -221,6 +221,26 @@ def test_two_slabs_with_moving_cuts_mdbc(request):
     assert int(dd["n_recuts"]) >= 1 and int(dd["halo_width"]) == 5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,axis", [("dam_break_3d_shipped", 1), ("dam_break_2d", 0)])
+def test_column_work_on_device_matches_host(case, axis, request):
+    """The re-cut balances what the first cut balanced: sphmi_dd_column_cost (owned particles of every rank, cell list
+    of the rebuild) = particle_work summed per column, exactly."""
+    import torch.multiprocessing as mp
+    from dd_worker import cost_worker
+    from sphexample_amd.distributed import particle_work
+    p, s = request.getfixturevalue(case)
+    cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(p.Position.shape[1])]
+    w = particle_work(cols)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(cost_worker, args=(2, _free_port(), d, case, axis), nprocs=2, join=True)
+        got = dict(np.load(os.path.join(d, "cost.npz")))
+    col0 = int(got["col0"])
+    want = np.bincount(cols[axis] - col0, weights=w, minlength=len(got["cost"])).astype(np.int64)
+    np.testing.assert_array_equal(got["cost"], want)
+    assert want.sum() > 0
+
+
 def _two_slabs(case, steps, fb, tol, axis, overlap, recut, request, cut_shift=0, world=2, calls=1):
     """Two slab engines (sharing GPU 0, halo over gloo) reproduce the single-GPU engine: same dt sequence,
     same rebuild cadence, density/position to rounding (the tiles differ, so only summation order does)."""
