@@ -603,7 +603,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     if (lane == 0 && wv == 0 && P.trace) {
         P.trace[2 * b] = st_t0;
-        P.trace[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+        P.trace[2 * b + 1] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(blockIdx.x & 7) << 60);   // + XCD of the block
     }
 #endif
 #ifdef SPHMI_STATS

@@ -17,11 +17,19 @@ fn = "/tmp/tiles.bin"
 env = dict(os.environ, SPHMI_LIB=lib, SPHMI_TRACE_FILE=fn)
 subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], env=env,
                capture_output=True)
-t = np.fromfile(fn, dtype=np.uint64).reshape(-1, 2)
-t = t[t[:, 1] > 0].astype(np.int64)
+raw = np.fromfile(fn, dtype=np.uint64).reshape(-1, 2)
+raw = raw[raw[:, 1] > 0]
+xcd = (raw[:, 1] >> np.uint64(60)).astype(np.int64)                 # the block's XCD rides in the top bits of the end clock
+t = np.stack([raw[:, 0], raw[:, 1] & np.uint64((1 << 60) - 1)], axis=1).astype(np.int64)
 t0, t1 = t[:, 0].min(), t[:, 1].max()
 span = t1 - t0
 print(f"tiles {len(t)}  span {span} ticks (100 MHz: {span / 100:.1f} us)  mean tile life {np.mean(t[:, 1] - t[:, 0]) / 100:.1f} us")
+print("per XCD: tiles, first start / last end (% of span), busy wave-time share")
+tot = (t[:, 1] - t[:, 0]).sum()
+for x in range(8):
+    m = xcd == x
+    print(f"  XCD {x}: {m.sum():5d} tiles  start {100 * (t[m, 0].min() - t0) / span:5.1f} %  end {100 * (t[m, 1].max() - t0) / span:5.1f} %  "
+          f"wave-time {100 * (t[m, 1] - t[m, 0]).sum() / tot:5.1f} %  95 % of its tiles done at {100 * (np.percentile(t[m, 1], 95) - t0) / span:5.1f} %")
 edges = np.linspace(t0, t1, 21)
 for k in range(20):
     a, b = edges[k], edges[k + 1]
