@@ -243,8 +243,11 @@ constexpr int kTileClasses = SPHMI_TILE_CLASSES;
 // by cost tripled the HBM fetch of the neighbour kernel).
 // cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
-                                                     int* part) {
-    __shared__ int s_min, s_max, s_wsum[16], s_off;
+                                                     int* part, int nseg) {
+    // nseg contiguous segments per XCD, dealt round-robin (segment s of 8·nseg equal-cost segments goes to XCD s % 8):
+    // with nseg = 1 an XCD's run is one stretch of the domain, and a stretch of interior fluid has no cheap tiles to
+    // end its launch with.  The XCD's tiles are written to order[x·ntile …].
+    __shared__ int s_min, s_max, s_wsum[16], s_off, s_beg[64], s_end[64];
     const int x = blockIdx.x;
     const long long total = cscan[ntile];
     auto lower_bound = [&](long long v) {
@@ -252,12 +255,23 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cscan[mid] < v) lo = mid + 1; else hi = mid; }
         return lo;
     };
-    const int beg = x == 0 ? 0 : lower_bound(total * x / 8);
-    const int end = x == 7 ? ntile : lower_bound(total * (x + 1) / 8);
-    if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; s_off = beg; }
+    const int nall = 8 * nseg;
+    if ((int)threadIdx.x < nseg) {                    // one binary search per segment bound, not per thread and loop
+        const int sg = x + 8 * (int)threadIdx.x;
+        s_beg[threadIdx.x] = sg == 0 ? 0 : lower_bound(total * sg / nall);
+        s_end[threadIdx.x] = sg == nall - 1 ? ntile : lower_bound(total * (sg + 1) / nall);
+    }
+    __syncthreads();
+    auto seg_beg = [&](int k) { return s_beg[k]; };
+    auto seg_end = [&](int k) { return s_end[k]; };
+    const int out0 = nseg == 1 ? seg_beg(0) : x * ntile;
+    if (threadIdx.x == 0) { s_min = INT32_MAX; s_max = INT32_MIN; s_off = out0; }
     __syncthreads();
     int mn = INT32_MAX, mx = INT32_MIN;
-    for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; if (c > 0) { mn = min(mn, c); mx = max(mx, c); } }
+    for (int k = 0; k < nseg; ++k) {
+        const int beg = seg_beg(k), end = seg_end(k);
+        for (int t = beg + (int)threadIdx.x; t < end; t += 1024) { const int c = cost[t]; if (c > 0) { mn = min(mn, c); mx = max(mx, c); } }
+    }
     if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
     const int cmin = s_min;
@@ -266,24 +280,27 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     auto cls_of = [&](int c) { return kTileClasses - 1 - min(kTileClasses - 1, (int)((float)(c - cmin) * scale)); };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int cls = 0; cls < kTileClasses; ++cls) {
-        for (int t0 = beg; t0 < end; t0 += 1024) {
-            const int t = t0 + (int)threadIdx.x;
-            const int c = t < end ? cost[t] : 0;
-            const bool in = c > 0 && cls_of(c) == cls;                     // cost 0: the tile is not in this list
-            const unsigned long long bal = __ballot(in);
-            const int below = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wsum[w] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, tot = 0;
-            for (int k = 0; k < 16; ++k) { const int v = s_wsum[k]; if (k < w) woff += v; tot += v; }
-            const int base = s_off;
-            if (in) order[base + woff + below] = t;
-            __syncthreads();
-            if (threadIdx.x == 0) s_off = base + tot;
-            __syncthreads();
+        for (int k = 0; k < nseg; ++k) {
+            const int beg = seg_beg(k), end = seg_end(k);
+            for (int t0 = beg; t0 < end; t0 += 1024) {
+                const int t = t0 + (int)threadIdx.x;
+                const int c = t < end ? cost[t] : 0;
+                const bool in = c > 0 && cls_of(c) == cls;                     // cost 0: the tile is not in this list
+                const unsigned long long bal = __ballot(in);
+                const int below = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wsum[w] = __popcll(bal);
+                __syncthreads();
+                int woff = 0, tot = 0;
+                for (int q = 0; q < 16; ++q) { const int v = s_wsum[q]; if (q < w) woff += v; tot += v; }
+                const int base = s_off;
+                if (in) order[base + woff + below] = t;
+                __syncthreads();
+                if (threadIdx.x == 0) s_off = base + tot;
+                __syncthreads();
+            }
         }
     }
-    if (threadIdx.x == 0) { part[x] = beg; part[8 + x] = s_off - beg; }      // run start in order[], tiles in the run
+    if (threadIdx.x == 0) { part[x] = out0; part[8 + x] = s_off - out0; }    // run start in order[], tiles in the run
 }
 
 __global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const int* slot, const int* cstart,
