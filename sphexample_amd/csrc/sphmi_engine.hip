@@ -126,6 +126,11 @@ struct Engine final : EngineBase {
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
+    // XCD shares of the estimated tile cost, moved towards equal finishing times: one corrector launch per rebuild
+    // interval records when each XCD ran out of tiles ($SPHMI_XCD_FEEDBACK=0 switches it off)
+    int xcd_feedback = 1; bool xcd_sample_next = false, xcd_sampled = false;
+    unsigned long long *xcd_clock_d = nullptr, *xcd_clock_h = nullptr;
+    double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
     static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
     // domain decomposition: slab axis and the rank's cell-column range along it
@@ -158,6 +163,8 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(c.device));
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) force_wpt = v; }
+        if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
+        HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
         const size_t n = (size_t)N;
         for (int k = 0; k < 3; ++k) { HC(hipMalloc(&pk0[k], n * sizeof(V4))); HC(hipMalloc(&pk1[k], n * sizeof(V4))); }
@@ -197,7 +204,7 @@ struct Engine final : EngineBase {
         (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
-        (void)hipFree(kout_d);
+        (void)hipFree(kout_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -317,6 +324,15 @@ struct Engine final : EngineBase {
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
         const int ntile = std::min((N + kWave - 1) / kWave, 8 * part_max[list]);
         const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
+        if (PASS == PASS_CORRECTOR && list == 0 && xcd_sample_next && wpt == 1 && batch_step == 0) {
+            // (the first step of a batch always executes unless the batch starts with a rebuild request, and then
+            // nothing is written and the sample is void: all-zero ends)
+            for (int k = 0; k < 8; ++k) xcd_clock_h[16 + k] = 0ull;
+            for (int k = 8; k < 16; ++k) xcd_clock_h[16 + k] = ~0ull;
+            HC(hipMemcpyAsync(xcd_clock_d, xcd_clock_h + 16, 16 * 8, hipMemcpyHostToDevice, stream));
+            P.xcd_clock = xcd_clock_d;
+            xcd_sample_next = false; xcd_sampled = true;
+        }
         if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
         else launch_force_wpt<PASS, MODEL, 1>(P, list);
@@ -355,12 +371,26 @@ struct Engine final : EngineBase {
         const int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
         memcpy(bbox_h, init, sizeof(init));
         HC(hipMemcpyAsync(bbox_d, bbox_h, sizeof(init), hipMemcpyHostToDevice, stream));
+        if (xcd_sampled) HC(hipMemcpyAsync(xcd_clock_h, xcd_clock_d, 16 * 8, hipMemcpyDeviceToHost, stream));   // read after the sync below
         const int nb_bbox = std::min(nb256, 512);
         if (D == 3) hipLaunchKernelGGL((k_cell_bbox<T, 3>), dim3(nb_bbox), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
         else        hipLaunchKernelGGL((k_cell_bbox<T, 2>), dim3(nb_bbox), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, bbox_d);
         HC(hipGetLastError());
         HC(hipMemcpyAsync(bbox_h, bbox_d, 6 * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
+        if (xcd_sampled) {
+            xcd_sampled = false;
+            // finishing time of every XCD in the sampled launch → its share of the estimated cost moves towards the
+            // speed it showed (damped; shares stay within ±20 % of an eighth)
+            const unsigned long long t0 = xcd_clock_h[8];
+            double Tx[8], mean = 0; bool ok = t0 != ~0ull;
+            for (int x = 0; x < 8 && ok; ++x) { ok = xcd_clock_h[x] > t0; Tx[x] = ok ? (double)(xcd_clock_h[x] - t0) : 0.0; mean += Tx[x] / 8; }
+            if (ok && xcd_feedback) {
+                double sum = 0;
+                for (int x = 0; x < 8; ++x) { xcd_w[x] *= std::sqrt(mean / Tx[x]); xcd_w[x] = std::min(0.15, std::max(0.10, xcd_w[x])); sum += xcd_w[x]; }
+                for (int x = 0; x < 8; ++x) xcd_w[x] /= sum;
+            }
+        }
         int64_t ncell = 1;
         for (int d = 0; d < 3; ++d) {
             if (d < D) {
@@ -441,7 +471,10 @@ struct Engine final : EngineBase {
                 // segments per XCD run (k_tile_order): measured best 1 / 16 / 32 / 64 at 2.5 k / 16.5 k / 44.6 k / 120 k tiles
                 // (+3.0 / +2.2 / +2.4 % for the three large cases); the short slab-edge list keeps one run per XCD
                 const int nseg = l == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1));
-                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg);
+                XcdShares W{};
+                for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 ? xcd_w[x] : 0.125);
+                W.cum[8] = 1.0f;
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W);
             }
             HC(hipGetLastError());
             HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
@@ -453,6 +486,7 @@ struct Engine final : EngineBase {
         }
         have_grid = true;
         n_rebuilds += 1;
+        xcd_sample_next = xcd_feedback != 0;
         end_phase(ev);
     }
 

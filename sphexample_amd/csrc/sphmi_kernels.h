@@ -120,6 +120,7 @@ struct ForceParams {
     const StepCtrl* ctrl;      // device-side step control (null: dt / dt2 below are used, the kernel always runs)
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
+    unsigned long long* xcd_clock;   // sampled launch: [x] = latest tile end on XCD x (max), [8] = earliest tile start (min); else null
     unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
     int N, nxp, nxyp;
     int visc, ddt, shift;    // model tags for the run-time variant of the kernel
@@ -483,6 +484,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
+    const unsigned long long xcd_t0 = P.xcd_clock ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -600,6 +602,12 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     }
     run_pairs(0, true);
+    if (P.xcd_clock && lane == 0 && wv == 0) {
+        // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
+        // shares of the estimated cost towards equal finishing times at the next rebuild.
+        atomicMax(&P.xcd_clock[blockIdx.x & 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicMin(&P.xcd_clock[8], xcd_t0);
+    }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     if (lane == 0 && wv == 0 && P.trace) {
         P.trace[2 * b] = st_t0;

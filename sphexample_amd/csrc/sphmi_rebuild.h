@@ -242,8 +242,9 @@ constexpr int kTileClasses = SPHMI_TILE_CLASSES;
 // in flight at any time are still neighbours in space and share their source rows in its L2 (a full sort
 // by cost tripled the HBM fetch of the neighbour kernel).
 // cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
+struct XcdShares { float cum[9]; };      // cumulative share of the estimated cost per XCD: cum[0] = 0 … cum[8] = 1
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
-                                                     int* part, int nseg) {
+                                                     int* part, int nseg, XcdShares W) {
     // nseg contiguous segments per XCD, dealt round-robin (segment s of 8·nseg equal-cost segments goes to XCD s % 8):
     // with nseg = 1 an XCD's run is one stretch of the domain, and a stretch of interior fluid has no cheap tiles to
     // end its launch with.  The XCD's tiles are written to order[x·ntile …].
@@ -257,9 +258,11 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     };
     const int nall = 8 * nseg;
     if ((int)threadIdx.x < nseg) {                    // one binary search per segment bound, not per thread and loop
-        const int sg = x + 8 * (int)threadIdx.x;
-        s_beg[threadIdx.x] = sg == 0 ? 0 : lower_bound(total * sg / nall);
-        s_end[threadIdx.x] = sg == nall - 1 ? ntile : lower_bound(total * (sg + 1) / nall);
+        // round k of the deal covers the cost span [k, k + 1) / nseg; inside it the XCDs take their shares in order
+        const int k = (int)threadIdx.x, sg = x + 8 * k;
+        const double lo = ((double)k + (double)W.cum[x]) / nseg, hi = ((double)k + (double)W.cum[x + 1]) / nseg;
+        s_beg[threadIdx.x] = sg == 0 ? 0 : lower_bound((long long)((double)total * lo));
+        s_end[threadIdx.x] = sg == nall - 1 ? ntile : lower_bound((long long)((double)total * hi));
     }
     __syncthreads();
     auto seg_beg = [&](int k) { return s_beg[k]; };
