@@ -128,7 +128,10 @@ struct Engine final : EngineBase {
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
     // XCD shares of the estimated tile cost, moved towards equal finishing times: one corrector launch per rebuild
     // interval records when each XCD ran out of tiles ($SPHMI_XCD_FEEDBACK=0 switches it off)
-    int xcd_feedback = 1; bool xcd_sample_next = false, xcd_sampled = false;
+    int xcd_feedback = 1; bool xcd_sampled = false;
+    // after a rebuild: 1 = the next eligible corrector launch measures the work of every tile and the schedule of the rest
+    // of the interval is rebuilt from it; 2 = the one after that records the XCD finishing times; 0 = nothing pending
+    int sched_state = 0; int resched = 1; int* tile_work_d = nullptr; bool part_readback = false;
     unsigned long long *xcd_clock_d = nullptr, *xcd_clock_h = nullptr;
     double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
@@ -164,6 +167,7 @@ struct Engine final : EngineBase {
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) force_wpt = v; }
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
+        if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
         HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
         const size_t n = (size_t)N;
@@ -179,7 +183,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
         const size_t nt = n / kWave + 2;
         for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], 8 * nt * 4)); }
-        HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt));
+        HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4));
         if (cfg.kernel_output == SPHMI_KOUT_STORE) { HC(hipMalloc(&kout_d, n * sizeof(V4))); HC(hipMemset(kout_d, 0, n * sizeof(V4))); }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
@@ -204,7 +208,7 @@ struct Engine final : EngineBase {
         (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
-        (void)hipFree(kout_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
+        (void)hipFree(kout_d); (void)hipFree(tile_work_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -324,15 +328,24 @@ struct Engine final : EngineBase {
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
         const int ntile = std::min((N + kWave - 1) / kWave, 8 * part_max[list]);
         const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
-        if (PASS == PASS_CORRECTOR && list == 0 && xcd_sample_next && wpt == 1 && batch_step == 0) {
-            // (the first step of a batch always executes unless the batch starts with a rebuild request, and then
-            // nothing is written and the sample is void: all-zero ends)
-            for (int k = 0; k < 8; ++k) xcd_clock_h[16 + k] = 0ull;
-            for (int k = 8; k < 16; ++k) xcd_clock_h[16 + k] = ~0ull;
-            HC(hipMemcpyAsync(xcd_clock_d, xcd_clock_h + 16, 16 * 8, hipMemcpyHostToDevice, stream));
-            P.xcd_clock = xcd_clock_d;
-            xcd_sample_next = false; xcd_sampled = true;
+        bool resched_after = false;
+        if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt == 1 && batch_step == 0) {
+            // (the first step of a batch executes unless the batch starts with a rebuild request; then nothing is
+            // written and the sample is void: all-zero work keeps the schedule, all-zero ends are ignored)
+            if (sched_state == 1 && resched) {
+                HC(hipMemsetAsync(tile_work_d, 0, (size_t)((N + kWave - 1) / kWave) * 4, stream));
+                P.tile_work = tile_work_d;
+                resched_after = true;
+                sched_state = xcd_feedback ? 2 : 0;
+            } else if (xcd_feedback) {
+                for (int k = 0; k < 8; ++k) xcd_clock_h[16 + k] = 0ull;
+                for (int k = 8; k < 16; ++k) xcd_clock_h[16 + k] = ~0ull;
+                HC(hipMemcpyAsync(xcd_clock_d, xcd_clock_h + 16, 16 * 8, hipMemcpyHostToDevice, stream));
+                P.xcd_clock = xcd_clock_d;
+                sched_state = 0; xcd_sampled = true;
+            } else sched_state = 0;
         }
+        if (resched_after) { launch_force_wpt<PASS, MODEL, 1>(P, list); reschedule_from_work(); return; }
         if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
         else launch_force_wpt<PASS, MODEL, 1>(P, list);
@@ -472,9 +485,10 @@ struct Engine final : EngineBase {
                 // (+3.0 / +2.2 / +2.4 % for the three large cases); the short slab-edge list keeps one run per XCD
                 const int nseg = l == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1));
                 XcdShares W{};
-                for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 ? xcd_w[x] : 0.125);
+                // (with the measured re-schedule the shares belong to IT: the estimate-based order lives for one step)
+                for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 && !resched ? xcd_w[x] : 0.125);
                 W.cum[8] = 1.0f;
-                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W);
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W, 0);
             }
             HC(hipGetLastError());
             HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
@@ -486,8 +500,28 @@ struct Engine final : EngineBase {
         }
         have_grid = true;
         n_rebuilds += 1;
-        xcd_sample_next = xcd_feedback != 0;
+        sched_state = 1;
         end_phase(ev);
+    }
+
+    // The schedule of list 0 from the MEASURED work of every tile (the sampled corrector launch just queued): same
+    // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.  All in
+    // stream order, no host round trip: the grid keeps an upper bound until the run lengths come back with the batch.
+    void reschedule_from_work() {
+        const int ntile = (N + kWave - 1) / kWave;
+        const int sb = (ntile + kScanTile - 1) / kScanTile;
+        hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_work_d, tile_scan, ntile, tile_tsum, misc_d + 2);
+        hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
+        hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
+        const int nseg = xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1);
+        XcdShares W{};
+        for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)xcd_w[x];
+        W.cum[8] = 1.0f;
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_work_d, tile_scan, ntile, tile_order[0], part_d, nseg, W, 1);
+        HC(hipGetLastError());
+        part_max[0] = std::min(ntile, std::max(part_max[0], (ntile + 7) / 8 * 3 / 2));       // until the lengths are back
+        HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
+        part_readback = true;
     }
 
     void run_mdbc(const StepCtrl* ctrl = nullptr) {
@@ -508,6 +542,12 @@ struct Engine final : EngineBase {
         HC(hipStreamSynchronize(stream));
         collect_events(batch_ctrl ? batch_ctrl->steps_done - steps_before : INT64_MAX);
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
+        if (part_readback) {
+            part_readback = false;
+            int m = 0;
+            for (int x = 0; x < 8; ++x) m = std::max(m, part_h[8 + x]);
+            if (m > 0) part_max[0] = m;
+        }
     }
 
     void fill(sphmi_progress* out, int64_t steps) {

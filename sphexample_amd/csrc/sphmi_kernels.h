@@ -120,6 +120,7 @@ struct ForceParams {
     const StepCtrl* ctrl;      // device-side step control (null: dt / dt2 below are used, the kernel always runs)
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
+    int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (WPT = 1), or null
     unsigned long long* xcd_clock;   // sampled launch: [x] = latest tile end on XCD x (max), [8] = earliest tile start (min); else null
     unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
     int N, nxp, nxyp;
@@ -491,6 +492,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #ifdef SPHMI_STATS
     unsigned long long st_it = 0, st_lane = 0, st_ref = 0, st_emp = 0, st_chunks = 0;
 #endif
+    int work_it = 0, work_ch = 0;    // wave-uniform work counters (scalar unit): pair-loop iterations, chunks scanned
     int wpos = 0, rpos = 0;          // this lane's queue: entries written / fetched so far
     int cbase = 0;                   // candidate index of bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
@@ -510,6 +512,7 @@ k_neighbor_force(const ForceParams<T> P) {
             cm = need ? ne.x : cm;
             cbase = need ? (int)ne.y : cbase;
             rpos += need ? 1 : 0;
+            work_it += 1;
 #ifdef SPHMI_STATS
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cm != 0));
             st_ref += __builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
@@ -587,6 +590,7 @@ k_neighbor_force(const ForceParams<T> P) {
             // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
             if (__builtin_amdgcn_ballot_w64((wpos - rpos) > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
             unsigned long long m = scan_chunk(cb, HI);
+            work_ch += 1;
 #ifdef SPHMI_STATS
             st_chunks += 1;
 #endif
@@ -602,6 +606,9 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     }
     run_pairs(0, true);
+    // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
+    // of the rebuild interval is rebuilt from it (Engine::reschedule)
+    if (WPT == 1 && P.tile_work && lane == 0) P.tile_work[b] = 9 * work_it + 16 * work_ch + 16;
     if (P.xcd_clock && lane == 0 && wv == 0) {
         // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
         // shares of the estimated cost towards equal finishing times at the next rebuild.

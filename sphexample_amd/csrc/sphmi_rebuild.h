@@ -244,13 +244,18 @@ constexpr int kTileClasses = SPHMI_TILE_CLASSES;
 // cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
 struct XcdShares { float cum[9]; };      // cumulative share of the estimated cost per XCD: cum[0] = 0 … cum[8] = 1
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
-                                                     int* part, int nseg, XcdShares W) {
+                                                     int* part, int nseg, XcdShares W, int keep_if_empty) {
     // nseg contiguous segments per XCD, dealt round-robin (segment s of 8·nseg equal-cost segments goes to XCD s % 8):
     // with nseg = 1 an XCD's run is one stretch of the domain, and a stretch of interior fluid has no cheap tiles to
     // end its launch with.  The XCD's tiles are written to order[x·ntile …].
     __shared__ int s_min, s_max, s_wsum[16], s_off, s_beg[64], s_end[64];
     const int x = blockIdx.x;
     const long long total = cscan[ntile];
+    if (total <= 0) {
+        // keep_if_empty: a re-schedule from a sampled launch that never ran (its step was cancelled) keeps the old order
+        if (!keep_if_empty && threadIdx.x == 0) { part[x] = 0; part[8 + x] = 0; }
+        return;
+    }
     auto lower_bound = [&](long long v) {
         int lo = 0, hi = ntile;                       // first t with cscan[t] >= v
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cscan[mid] < v) lo = mid + 1; else hi = mid; }
