@@ -135,7 +135,9 @@ struct Engine final : EngineBase {
     unsigned long long *xcd_clock_d = nullptr, *xcd_clock_h = nullptr;
     double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
-    static constexpr int kWptSmall = 1024, kWptMedium = 12000;   // measured: 108 tiles 4 > 2 > 1; 2481 tiles 2 ≈ 4 > 1; 16528 tiles 1 ≥ 2 > 4
+    // measured: 108 tiles 4 > 2 > 1; 2481 and 3109 tiles 2 > 1 (+8 %, +5 %); with the order from measured work (one wave
+    // per tile only) 4161 / 6344 / 10512 tiles 1 > 2 (+1.5 / +3.3 / +4 %); 16528 tiles 1 > 2 > 4
+    static constexpr int kWptSmall = 1024, kWptMedium = 4000;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
