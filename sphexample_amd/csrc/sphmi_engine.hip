@@ -135,9 +135,9 @@ struct Engine final : EngineBase {
     unsigned long long *xcd_clock_d = nullptr, *xcd_clock_h = nullptr;
     double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
-    // measured: 108 tiles 4 > 2 > 1; 2481 and 3109 tiles 2 > 1 (+8 %, +5 %); with the order from measured work (one wave
-    // per tile only) 4161 / 6344 / 10512 tiles 1 > 2 (+1.5 / +3.3 / +4 %); 16528 tiles 1 > 2 > 4
-    static constexpr int kWptSmall = 1024, kWptMedium = 4000;
+    // measured (both with the order from measured work): 108 tiles 4 > 2 > 1; 2481 … 6344 tiles 2 > 1 (+6 … +2 %);
+    // 10512 tiles 2 = 1; 14032 / 16528 / 24676 tiles 1 > 2 (+3 / +5 / +7 %)
+    static constexpr int kWptSmall = 1024, kWptMedium = 10000;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -331,7 +331,7 @@ struct Engine final : EngineBase {
         const int ntile = std::min((N + kWave - 1) / kWave, 8 * part_max[list]);
         const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
         bool resched_after = false;
-        if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt == 1 && batch_step == 0) {
+        if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && batch_step == 0) {
             // (the first step of a batch executes unless the batch starts with a rebuild request; then nothing is
             // written and the sample is void: all-zero work keeps the schedule, all-zero ends are ignored)
             if (sched_state == 1 && resched) {
@@ -347,7 +347,11 @@ struct Engine final : EngineBase {
                 sched_state = 0; xcd_sampled = true;
             } else sched_state = 0;
         }
-        if (resched_after) { launch_force_wpt<PASS, MODEL, 1>(P, list); reschedule_from_work(); return; }
+        if (resched_after) {
+            if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list); else launch_force_wpt<PASS, MODEL, 1>(P, list);
+            reschedule_from_work();
+            return;
+        }
         if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
         else launch_force_wpt<PASS, MODEL, 1>(P, list);

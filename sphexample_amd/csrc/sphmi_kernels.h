@@ -120,7 +120,7 @@ struct ForceParams {
     const StepCtrl* ctrl;      // device-side step control (null: dt / dt2 below are used, the kernel always runs)
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
-    int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (WPT = 1), or null
+    int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (of its slowest wave × WPT), or null
     unsigned long long* xcd_clock;   // sampled launch: [x] = latest tile end on XCD x (max), [8] = earliest tile start (min); else null
     unsigned long long* trace;   // experiment builds (SPHMI_STATS / SPHMI_TRACE): per tile { start, end } of s_memrealtime, or null
     int N, nxp, nxyp;
@@ -608,7 +608,7 @@ k_neighbor_force(const ForceParams<T> P) {
     run_pairs(0, true);
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
-    if (WPT == 1 && P.tile_work && lane == 0) P.tile_work[b] = 9 * work_it + 16 * work_ch + 16;
+    int tile_work = 9 * work_it + 16 * work_ch + 16;
     if (P.xcd_clock && lane == 0 && wv == 0) {
         // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
         // shares of the estimated cost towards equal finishing times at the next rebuild.
@@ -629,7 +629,9 @@ k_neighbor_force(const ForceParams<T> P) {
 #endif
     if constexpr (WPT > 1) {
         __shared__ V4 s_part[3 * (WPT - 1) * kWave];        // partial sums of waves 1 … WPT−1
+        __shared__ int s_work[WPT];
         // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
+        if (lane == 0) s_work[wv] = tile_work;
         if (wv > 0) {
             V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_part[(wv - 1) * kWave + lane] = o;
             if (shift) { V4 g; g.x = gcx; g.y = gcy; g.z = gcz; g.w = divr; s_part[(WPT - 1 + wv - 1) * kWave + lane] = g; }
@@ -637,6 +639,10 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
         if (wv > 0) return;
+        // the workgroup holds its WPT wave slots until the slowest wave is done
+#pragma unroll
+        for (int k = 1; k < WPT; ++k) tile_work = max(tile_work, s_work[k]);
+        tile_work *= WPT;
 #pragma unroll
         for (int k = 0; k < WPT - 1; ++k) {
             const V4 o = s_part[k * kWave + lane];
@@ -645,6 +651,7 @@ k_neighbor_force(const ForceParams<T> P) {
             if (MODEL < 0 && P.kout) { const V4 g = s_part[(2 * (WPT - 1) + k) * kWave + lane]; kgx += g.x; kgy += g.y; kgz += g.z; kw += g.w; }
         }
     }
+    if (P.tile_work && lane == 0) P.tile_work[b] = tile_work;
     // ---- epilogue ---------------------------------------------------------------------------
     const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
