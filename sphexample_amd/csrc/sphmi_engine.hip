@@ -131,7 +131,8 @@ struct Engine final : EngineBase {
     int xcd_feedback = 1; bool xcd_sampled = false;
     // after a rebuild: 1 = the next eligible corrector launch measures the work of every tile and the schedule of the rest
     // of the interval is rebuilt from it; 2 = the one after that records the XCD finishing times; 0 = nothing pending
-    int sched_state = 0; int resched = 1; int* tile_work_d = nullptr; bool part_readback = false;
+    int sched_state = 0; int resched = 1; int* tile_work_d = nullptr;
+    int sched1_state = 0; int* tile_work1_d = nullptr; bool resched0_pending = false, resched1_pending = false;    // the same for the slab-edge list (its launch sits on the side stream)
     unsigned long long *xcd_clock_d = nullptr, *xcd_clock_h = nullptr;
     double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
@@ -185,7 +186,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
         const size_t nt = n / kWave + 2;
         for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], 8 * nt * 4)); }
-        HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4));
+        HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4)); HC(hipMalloc(&tile_work1_d, nt * 4));
         if (cfg.kernel_output == SPHMI_KOUT_STORE) { HC(hipMalloc(&kout_d, n * sizeof(V4))); HC(hipMemset(kout_d, 0, n * sizeof(V4))); }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
@@ -210,7 +211,7 @@ struct Engine final : EngineBase {
         (void)hipFree(out_arena);
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
-        (void)hipFree(kout_d); (void)hipFree(tile_work_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
+        (void)hipFree(kout_d); (void)hipFree(tile_work_d); (void)hipFree(tile_work1_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
         (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -349,8 +350,14 @@ struct Engine final : EngineBase {
         }
         if (resched_after) {
             if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list); else launch_force_wpt<PASS, MODEL, 1>(P, list);
-            reschedule_from_work();
+            resched0_pending = true;              // served before the next step is queued (outside the timed phase)
             return;
+        }
+        if (PASS == PASS_CORRECTOR && list == 1 && sched1_state == 1 && resched && wpt <= 2 && batch_step == 0) {
+            // slab-edge list: measured here (side stream), re-ordered on the main stream once the streams have joined
+            HC(hipMemsetAsync(tile_work1_d, 0, (size_t)((N + kWave - 1) / kWave) * 4, stream));
+            P.tile_work = tile_work1_d;
+            sched1_state = 0; resched1_pending = true;
         }
         if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
@@ -506,28 +513,32 @@ struct Engine final : EngineBase {
         }
         have_grid = true;
         n_rebuilds += 1;
-        sched_state = 1;
+        sched_state = 1; sched1_state = dd_slab ? 1 : 0; resched0_pending = false; resched1_pending = false;
         end_phase(ev);
     }
 
     // The schedule of list 0 from the MEASURED work of every tile (the sampled corrector launch just queued): same
-    // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.  All in
-    // stream order, no host round trip: the grid keeps an upper bound until the run lengths come back with the batch.
-    void reschedule_from_work() {
+    // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.
+    void reschedule_from_work(int list) {
         const int ntile = (N + kWave - 1) / kWave;
         const int sb = (ntile + kScanTile - 1) / kScanTile;
-        hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_work_d, tile_scan, ntile, tile_tsum, misc_d + 2);
+        int* work = list == 0 ? tile_work_d : tile_work1_d;
+        hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, work, tile_scan, ntile, tile_tsum, misc_d + 2);
         hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
         hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
-        const int nseg = xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1);
+        const int nseg = list == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1));
         XcdShares W{};
-        for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)xcd_w[x];
+        for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(list == 0 ? xcd_w[x] : 0.125);
         W.cum[8] = 1.0f;
-        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_work_d, tile_scan, ntile, tile_order[0], part_d, nseg, W, 1);
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, work, tile_scan, ntile, tile_order[list], part_d + 16 * list, nseg, W, 1);
         HC(hipGetLastError());
-        part_max[0] = std::min(ntile, std::max(part_max[0], (ntile + 7) / 8 * 3 / 2));       // until the lengths are back
-        HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
-        part_readback = true;
+        // the grid of the following launches needs the longest run: one short host round trip per rebuild interval
+        // (≈30 µs every ≈40 steps); a sample whose step was cancelled left the table as it was
+        HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+        int m = 0;
+        for (int x = 0; x < 8; ++x) m = std::max(m, part_h[16 * list + 8 + x]);
+        if (m > 0) part_max[list] = m;
     }
 
     void run_mdbc(const StepCtrl* ctrl = nullptr) {
@@ -548,12 +559,7 @@ struct Engine final : EngineBase {
         HC(hipStreamSynchronize(stream));
         collect_events(batch_ctrl ? batch_ctrl->steps_done - steps_before : INT64_MAX);
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
-        if (part_readback) {
-            part_readback = false;
-            int m = 0;
-            for (int x = 0; x < 8; ++x) m = std::max(m, part_h[8 + x]);
-            if (m > 0) part_max[0] = m;
-        }
+
     }
 
     void fill(sphmi_progress* out, int64_t steps) {
@@ -564,7 +570,12 @@ struct Engine final : EngineBase {
 
     // Queue one step of the while loop at src/SPHCellList.jl:742-802 with every per-step decision on the device
     // (k_step_control): Δx, Δt, the loop bound and the rebuild criterion.  Kernels of a cancelled step return at once.
+    void serve_reschedules() {
+        if (resched0_pending) { resched0_pending = false; reschedule_from_work(0); }
+        if (resched1_pending) { resched1_pending = false; reschedule_from_work(1); }
+    }
     void enqueue_step() {
+        serve_reschedules();
         Ev ev = begin_phase(PH_TIMESTEP);
         hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, red_d, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
         end_phase(ev);
@@ -977,6 +988,7 @@ struct Engine final : EngineBase {
     // into a caller-owned device buffer of 4 × int64, then reset — no host round trip before the allreduce
     void dd_reductions_dev(void* out4_dev) override {
         HC(hipSetDevice(cfg.device));
+        serve_reschedules();                                                               // main stream, after the join
         hipLaunchKernelGGL(k_take_reductions, dim3(1), dim3(64), 0, stream, red_d, (unsigned long long*)out4_dev);
         HC(hipGetLastError());
     }
