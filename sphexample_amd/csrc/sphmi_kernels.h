@@ -143,19 +143,25 @@ __device__ __forceinline__ float  fast_rcp(float x)  { return __builtin_amdgcn_r
 #ifndef SPHMI_F64_DIV
 #define SPHMI_F64_DIV 0
 #endif
+#ifndef SPHMI_F64_NEWTON
+#define SPHMI_F64_NEWTON 1
+#endif
 __device__ __forceinline__ double fast_rcp(double x) {
 #if SPHMI_F64_DIV
     return 1.0 / x;
 #else
-    // v_rcp_f64 (≈2⁻²⁶ relative) + two Newton steps: ≤ 1 ulp for the normal, positive arguments of the pair loop
+    // v_rcp_f64 (≈2⁻²⁶ relative) + ONE Newton step: ≈2⁻⁵² for the normal, positive arguments of the pair loop (a second
+    // step, -DSPHMI_F64_NEWTON=2, makes it ≤ 1 ulp and costs 4 % of the fp64 kernel; parity to the oracle is the same)
     double y = __builtin_amdgcn_rcp(x);
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+#if SPHMI_F64_NEWTON > 1
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+#endif
     return y;
 #endif
 }
 __device__ __forceinline__ float  fast_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }   // (v_rsq_f64 + Newton: no faster)
 
 __device__ __forceinline__ float  absT(float x)  { return __builtin_fabsf(x); }
 __device__ __forceinline__ double absT(double x) { return __builtin_fabs(x); }
