@@ -116,6 +116,7 @@ struct Engine final : EngineBase {
     int *count = nullptr, *cstart = nullptr, *tsum = nullptr;
     // tile schedules of the neighbour kernel: list 0 = interior (everything without a slab), list 1 = slab-edge tiles
     int *tile_cost[2] = {nullptr, nullptr}, *tile_order[2] = {nullptr, nullptr}, *tile_scan = nullptr, *tile_tsum = nullptr;
+    int list_tiles[2] = {0, 0};        // tiles of each list (decides the waves per tile)
     int *part_d = nullptr, *part_h = nullptr;       // 2 × 16 ints: run starts and run lengths per XCD
     uint8_t* tile_cls = nullptr;
     unsigned long long* trace_d = nullptr;
@@ -329,7 +330,7 @@ struct Engine final : EngineBase {
         P.order = tile_order[list]; P.part = part_d + 16 * list; P.trace = trace_d;
         // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip (per list: the
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
-        const int ntile = std::min((N + kWave - 1) / kWave, 8 * part_max[list]);
+        const int ntile = list_tiles[list];        // fixed at the rebuild: the choice must not follow the measured run lengths
         const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
         bool resched_after = false;
         if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && batch_step == 0) {
@@ -508,7 +509,8 @@ struct Engine final : EngineBase {
             HC(hipStreamSynchronize(stream));
             for (int l = 0; l < 2; ++l) {
                 part_max[l] = 0;
-                if (l < nlist) for (int x = 0; x < 8; ++x) part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]);
+                list_tiles[l] = 0;
+                if (l < nlist) for (int x = 0; x < 8; ++x) { part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]); list_tiles[l] += part_h[16 * l + 8 + x]; }
             }
         }
         have_grid = true;

@@ -476,6 +476,33 @@ def test_download_into_is_in_place_and_repeatable(dam_break_2d_mdbc):
     assert (q.Density > 900).all() and np.abs(q.GhostPoints).sum() > 0 and (q.Pressure != 0).any()
 
 
+def test_schedule_never_changes_results(monkeypatch):
+    """The tile schedule is re-built from MEASURED work after every rebuild and the XCD shares follow measured finishing
+    times — both depend on timing.  Tiles are independent and the reductions are maxima, so the particles must come out
+    bit-identical with the static, estimate-based schedule and with any number of segments per XCD (the number of waves
+    per tile is not a schedule: it changes the summation order)."""
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    from sphexample_amd.engine import make_engine
+    dp = 0.0105
+    p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
+    assert len(p) > 70000                                   # > 1024 tiles: the launches that are sampled
+    out = []
+    for env in ({}, {"SPHMI_RESCHED": "0", "SPHMI_XCD_FEEDBACK": "0"}, {"SPHMI_XCD_SEGS": "4"}):
+        for k in ("SPHMI_RESCHED", "SPHMI_XCD_FEEDBACK", "SPHMI_WPT", "SPHMI_XCD_SEGS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = make_engine(p, s, device_float_bytes=4)
+        for _ in range(3):                                   # every call starts with a rebuild → a fresh measurement
+            pr = e.advance(1e9, max_steps=40)
+        assert pr.n_rebuilds >= 3
+        out.append((pr.total_time, e.download(("Position", "Velocity", "Density", "Acceleration", "ID"))))
+    for t, d in out[1:]:
+        assert t == out[0][0]
+        for k, v in d.items():
+            np.testing.assert_array_equal(v, out[0][1][k], err_msg=k)
+
+
 def test_download_in_vtkhdf_point_layout(dam_break_2d_mdbc, dam_break_3d_shipped):
     """components=3: what to_3d! (src/ProduceHDFVTK.jl:251-325) makes of the 2-D vector fields, packed on the device —
     n×3 with a zero third component; Cells stay n×dims; a 3-D handle is unchanged; the default layout is back afterwards."""
