@@ -7,7 +7,7 @@
   lattice sites, the fluid block in the same order with the same IDs and densities (to the CSV's
   6 significant digits); the boundary block holds the same sites but the pillar is listed in plain
   x-major order rather than in the drawing order of the DualSPHysics export
-  (tests/test_cases.py checks this against the fixture copy).
+  (tests/test_host_logic.py::test_generator_reproduces_shipped_layout checks this against the fixture copy).
 * parameter presets that restate the reference's driver scripts:
   ``example/Dambreak3d.jl:8-59`` (C3/C4), ``example/StillWedgeMDBC.jl:7,30-38,60,69-71`` (C5) and the
   2-D dam-break derived from ``example/Dambreak2dMDBC.jl:7`` with the spacing the shipped files have (C1/C2).

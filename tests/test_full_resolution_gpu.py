@@ -1,0 +1,119 @@
+"""fp32 kernels against the fp64 oracle AT THE RESOLUTIONS THE HEADLINE IS QUOTED ON (BASELINE configs 3 and 4).
+
+The K-step parity tests of test_engine_gpu.py run on the shipped Dp0.02 layouts; the positions the fp32 kernels
+store are absolute, so their rounding grows relative to the particle spacing as the lattice is refined: one ulp of
+x ≈ 1.6 m is 2.8e-5·dp at dp = 0.00425 (C3, N = 1 057 738) and 5.6e-5·dp at dp = 0.002125 (C4, N = 7 700 240).
+These tests measure what that does to a force evaluation and to K full steps, on the real lattices, with the
+parameters of example/Dambreak3d.jl:8-59, from the state at t = 0 (column at rest) and from a perturbed state
+(random fluid velocities ±0.3 m/s, density offsets 0 … 2 kg/m³).
+
+Tolerance (north_star): density and position < 1e-5 relative to the field maximum; single force evaluation
+2e-4 of the field maximum (the figure of test_engine_gpu.py).  dρ/dt of the column AT REST is the residue of the
+hydrostatic cancellation (ρⱼ − ρᵢ − ρᴴᵢⱼ ≈ 0, velocities 0: orders of magnitude below the moving flow's, `drho_field_max` in the
+record), so its error is measured against the dρ/dt scale of the perturbed state of the same lattice, and additionally
+as the density error one step of it causes (|Δ dρ/dt|·Δt/ρ₀ < 1e-8).  The measured figures are written to
+gpurun_out/parity_full_resolution.json and quoted in BASELINE.md.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, perturbed
+from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+
+pytestmark = pytest.mark.gpu
+
+TOL_STATE = 1e-5
+TOL_FORCE = 2e-4
+
+
+def _by_id(st):
+    order = np.argsort(st["ID"], kind="stable")
+    return {k: v[order] for k, v in st.items()}
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _record(name, figures):
+    path = os.path.join(ROOT, "gpurun_out", "parity_full_resolution.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[name] = figures
+        json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[full-resolution parity] {name}: {json.dumps(figures)}")
+
+
+def _threads():
+    from oracle.oracle import Oracle
+    # the oracle keeps nthreads full-length accumulator copies (reference-shaped): 16 is near its best and bounds memory
+    return max(1, min(16, os.cpu_count() or 1, Oracle.max_threads()))
+
+
+def _run(dp, steps, lo, hi, tag):
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    p0 = dam_break_3d(dp)
+    s = setup_dam_break_3d(dp)
+    assert lo < len(p0) < hi
+    fig = {"dp": dp, "N": len(p0), "steps": steps, "oracle_threads": _threads(),
+           "ulp_x_over_dp": float(np.spacing(np.float32(np.abs(p0.Position).max())) / dp)}
+    drho_scale = 0.0
+    for state, p in (("perturbed", perturbed(p0, seed=5)), ("rest", p0)):
+        t0 = time.perf_counter()
+        eng = make_engine(p, s, device_float_bytes=4)
+        orc = make_oracle(p, s, threads=_threads())
+        # single force evaluation (also sorts both sides, as UpdateNeighbors! does)
+        d1, a1 = eng.forces_once()
+        d2, a2 = orc.forces_once()
+        ie = np.argsort(eng.download(("ID",))["ID"], kind="stable")
+        io = np.argsort(orc.download(("ID",))["ID"], kind="stable")
+        drho_scale = max(drho_scale, float(np.abs(d2).max()))          # perturbed first: the scale of a moving flow
+        f_drho = float(np.abs(d1[ie] - d2[io]).max() / drho_scale)
+        f_acc = _relmax(a1[ie], a2[io])
+        f_drho_abs, drho_max = float(np.abs(d1[ie] - d2[io]).max()), float(np.abs(d2).max())
+        # K steps
+        pe = eng.advance(1e9, max_steps=steps)
+        po = orc.advance(1e9, max_steps=steps)
+        assert pe.iteration == po.iteration == steps
+        assert pe.n_rebuilds == po.n_rebuilds
+        e = _by_id(eng.download(("ID", "Density", "Position", "Velocity")))
+        o = _by_id(orc.download(("ID", "Density", "Position", "Velocity")))
+        np.testing.assert_array_equal(e["ID"], o["ID"])
+        r = {"force_drho": f_drho, "force_acc": f_acc, "force_drho_abs": f_drho_abs, "drho_field_max": drho_max,
+             "drho_step_effect": f_drho_abs * float(po.last_dt) / s.SimConstants.rho0,
+             "rho": _relmax(e["Density"], o["Density"]),
+             "x": float(np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max()),
+             "x_over_dp": float(np.abs(e["Position"] - o["Position"]).max() / dp),
+             "v": float(np.abs(e["Velocity"] - o["Velocity"]).max() / max(np.abs(o["Velocity"]).max(), 1e-12)),
+             "dt": float(abs(pe.last_dt - po.last_dt) / po.last_dt),
+             "t": float(abs(pe.total_time - po.total_time) / po.total_time),
+             "seconds": time.perf_counter() - t0}
+        fig[state] = r
+        eng.close(); orc.close()
+        del eng, orc
+    _record(tag, fig)
+    for state in ("rest", "perturbed"):
+        r = fig[state]
+        assert r["rho"] < TOL_STATE, (state, r)
+        assert r["x"] < TOL_STATE, (state, r)
+        assert r["dt"] < TOL_STATE and r["t"] < TOL_STATE, (state, r)
+        assert r["force_drho"] < TOL_FORCE and r["force_acc"] < TOL_FORCE, (state, r)
+        assert r["drho_step_effect"] < 1e-8, (state, r)
+
+
+def test_c3_resolution_fp32_vs_oracle():
+    """BASELINE config 3: dp = 0.00425, N = 1 057 738, 8 steps."""
+    _run(0.00425, 8, 1.0e6, 1.1e6, "C3_dp0.00425")
+
+
+def test_c4_resolution_fp32_vs_oracle():
+    """BASELINE config 4's lattice on one GPU: dp = 0.002125, N = 7 700 240, 5 steps."""
+    _run(0.002125, 5, 7.6e6, 7.8e6, "C4_dp0.002125")

@@ -13,7 +13,7 @@ while read -r line; do
   timeout 300 rocprofv3 --pmc $line -d $R/gpurun_out/$out/p$i -o p -- ${PMC_CMD:-python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@"} > $R/gpurun_out/$out/p$i.log 2>&1
   db=$(find $R/gpurun_out/$out/p$i -name '*.db' | head -1)
   echo "### pass $i: $line"
-  python $R/tools/pmc_summary.py "$db" "k_neighbor_force<float, 3, 1>" | tail -n +2
+  python $R/tools/pmc_summary.py "$db" "k_neighbor_force" | tail -n +2
 done <<'LIST'
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
