@@ -23,7 +23,10 @@
  *     `device_float_bytes` wide (4 = fp32 kernels, 8 = fp64 kernels); conversion happens in
  *     upload/download.
  *   - the library installs no signal handlers and never calls back into the host runtime.
- *   - one handle = one simulation = one GPU; a handle must not be used from two threads at once.
+ *   - one handle = one simulation; a handle must not be used from two threads at once.  A handle created with a
+ *     device list (sphmi_config.n_devices > 1) spreads the simulation over the GPUs of the node — slabs of the domain,
+ *     one-cell halo over RCCL/xGMI each neighbour pass — behind the SAME sphmi_upload / sphmi_advance / sphmi_download
+ *     calls: the caller (one Julia process, src/SPHCellList.jl:883) does not change.
  */
 #ifndef SPHMI_H
 #define SPHMI_H
@@ -34,7 +37,8 @@
 extern "C" {
 #endif
 
-#define SPHMI_ABI_VERSION 2
+#define SPHMI_ABI_VERSION 3
+#define SPHMI_MAX_DEVICES 16
 
 /* status codes */
 enum {
@@ -87,6 +91,14 @@ typedef struct sphmi_config {
     double blin_constant, smagorinsky_constant;
     /* CubicSpline.eps (tensile correction, src/SPHKernels.jl:15-19,114-126) */
     double cubic_eps;
+    /* Device list: n_devices <= 1 → one GPU, `device` above.  n_devices > 1 → the particle set is
+     * split into n_devices slabs along one axis, slab r on HIP device devices[r]; halos and the per-step MAX-allreduce
+     * travel over RCCL.  The same ordinal may appear more than once (several slabs share that GPU; transfers are then
+     * stream-ordered device copies — the single-GPU test configuration).  slab_axis: 0 = chosen for balance, 1 / 2 / 3 =
+     * x / y / z. */
+    int32_t n_devices;
+    int32_t slab_axis;
+    int32_t devices[SPHMI_MAX_DEVICES];
 } sphmi_config;
 
 /* What the reference's SimulationLoop leaves in SimMetaData (src/SPHCellList.jl:679-685,:759). */
@@ -213,7 +225,36 @@ int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local)
  * launches since the last reset (sampled: the launches of every 8th step), and the number of launches. */
 int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int64_t* launches_out);
 
-/* ---- domain decomposition: one process per GPU, slabs along one axis, one-cell halo (wider with mDBC) --
+/* ---- multi-GPU handles ------------------------------------------------------------------------------------
+ * sphmi_create with cfg->n_devices > 1: all slabs in THIS process (what the reference's single Julia process needs).
+ * sphmi_create_rank: the same slab driver with ONE slab per process and the other slabs behind RCCL — rank r of `world`
+ * processes (torchrun: one process per GPU).  Every process passes the SAME full particle set to sphmi_upload and keeps
+ * its slab; sphmi_download then returns the particles this process owns (sphmi_owned_count of them, at most
+ * cfg->n_particles).  `unique_id`: the 128 bytes sphmi_rccl_unique_id produced on rank 0, distributed by the launcher
+ * (a file, MPI, torch.distributed's store …).  cfg->device is this rank's GPU. */
+int sphmi_rccl_unique_id(void* id_out /* 128 bytes */);
+int sphmi_create_rank(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out);
+int sphmi_owned_count(sphmi_handle* h, int64_t* n_out);   /* particles sphmi_download returns (any handle)        */
+typedef struct sphmi_multi_info {
+    int32_t world, n_local;        /* slabs in total / held by this handle                                         */
+    int32_t axis, halo_width;      /* slab axis (0 = x …); ghost-layer width in cell columns (1; 2 + off with mDBC) */
+    int32_t transport;             /* 0 = stream-ordered device copies, 1 = RCCL                                    */
+    int32_t reserved;
+    int64_t n_recuts;              /* rebuilds at which the cuts moved (load balance by work)                        */
+    int64_t cuts[SPHMI_MAX_DEVICES];    /* cuts[r-1] = first cell column of slab r                                  */
+    int64_t n_live[SPHMI_MAX_DEVICES];  /* particles incl. ghost copies currently held per local slab               */
+} sphmi_multi_info;
+int sphmi_multi_info_get(sphmi_handle* h, sphmi_multi_info* out);
+/* Test hook: start from these cuts (world-1 first columns) instead of the balanced ones; call before sphmi_upload. */
+int sphmi_multi_set_cuts(sphmi_handle* h, const int64_t* cuts, int32_t n);
+/* Host-only planning (no device needed; CPU tests): slab axis, cuts, halo width, owned particles and capacity per
+ * slab for `world` slabs of the given particle set.  cuts_out: world-1, owned_out / capacity_out: world entries. */
+int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* ghost_points, int64_t n, int32_t world,
+                     int32_t* axis_out, int32_t* halo_width_out, int64_t* cuts_out, int64_t* owned_out,
+                     int64_t* capacity_out);
+
+/* ---- domain decomposition, verb by verb (test harness: sphexample_amd/distributed.py drives these from Python; the
+ * product path is the slab driver inside the library, above): slabs along one axis, one-cell halo (wider with mDBC) --
  * The reference has no multi-process path; these entry points let a host driver
  * (sphexample_amd/distributed.py: torch.distributed over RCCL) run the SAME kernels on a slab of the
  * domain.  The handle is created with n_particles = the rank's CAPACITY; the live count changes at every

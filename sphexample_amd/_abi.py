@@ -13,7 +13,8 @@ import numpy as np
 from .config import (NoMDBC, SimpleMDBC, SimulationConstants, SimulationMetaData, SPHDensityDiffusion,
                      SPHKernelInstance, SPHViscosity)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_DEVICES = 16
 
 OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NUMERIC, ERR_DOMAIN, ERR_STATE = range(6)
 
@@ -31,6 +32,7 @@ class SphmiConfig(C.Structure):
         ("k", C.c_double), ("h", C.c_double), ("h_inv", C.c_double), ("H", C.c_double),
         ("H_inv", C.c_double), ("H2", C.c_double), ("alphaD", C.c_double), ("eta2", C.c_double),
         ("blin_constant", C.c_double), ("smagorinsky_constant", C.c_double), ("cubic_eps", C.c_double),
+        ("n_devices", C.c_int32), ("slab_axis", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES),
     ]
 
 
@@ -96,7 +98,7 @@ class Backend:
     A backend is `lib` + symbol `prefix`; every entry point has the signature declared in
     include/sphmi.h."""
 
-    def __init__(self, lib: C.CDLL, prefix: str, cfg: SphmiConfig):
+    def __init__(self, lib: C.CDLL, prefix: str, cfg: SphmiConfig, create=None):
         self._lib, self._p = lib, prefix
         self.cfg = cfg
         self.N, self.D = int(cfg.n_particles), int(cfg.dims)
@@ -106,7 +108,7 @@ class Backend:
         f("last_error").argtypes = [C.c_void_p]
         self._h = C.c_void_p()
         f("create").argtypes = [C.POINTER(SphmiConfig), C.POINTER(C.c_void_p)]
-        rc = f("create")(C.byref(cfg), C.byref(self._h))
+        rc = (create or f("create"))(C.byref(cfg), C.byref(self._h))
         if rc != OK:
             raise SphmiError(rc, (f("last_error")(None) or b"").decode())
         f("destroy").argtypes = [C.c_void_p]

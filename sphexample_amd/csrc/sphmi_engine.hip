@@ -62,36 +62,38 @@ struct EngineBase {
     virtual void force_stats(int reset, double* avg_ms, int64_t* launches) = 0;
     virtual void device_ptrs(void** pk0, void** pk1, int64_t* n) = 0;
     virtual void reset_count() = 0;
-    // domain decomposition
+    virtual int64_t owned_count() { return cfg.n_particles; }
+    // domain decomposition, verb by verb (slab handles only)
+    [[noreturn]] static void not_a_slab() { throw EngineError(SPHMI_ERR_STATE, "not a slab handle: sphmi_dd_* verbs need a single-device handle"); }
     virtual void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) = 0;
-    virtual void dd_set_stream(void* s) = 0;
-    virtual void dd_upload(int64_t n, const void*, const void*, const void*, const void*, const uint8_t*,
-                           const int64_t*, const uint64_t*, const void*, const int64_t*) = 0;
-    virtual void dd_progress_motion() = 0;
-    virtual void dd_mdbc() = 0;
-    virtual int64_t dd_count() = 0;
-    virtual void dd_cell_x(int32_t* out_host) = 0;
-    virtual void dd_types(uint8_t* out_host) = 0;
-    virtual void dd_cell_x_dev(int32_t* out_dev) = 0;
-    virtual void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) = 0;
-    virtual void dd_types_dev(uint8_t* out_dev) = 0;
-    virtual size_t dd_record_bytes(int64_t n) = 0;
-    virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
-    virtual void dd_kill(const int32_t* idx_dev, int64_t n) = 0;
-    virtual void dd_kill_ghosts() = 0;
-    virtual void dd_append(const void* buf_dev, int64_t n, int flag) = 0;
-    virtual void dd_rebuild() = 0;
-    virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) = 0;
-    virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) = 0;
-    virtual void dd_reductions(double* out8) = 0;
-    virtual void dd_reductions_dev(void* out4_dev) = 0;
-    virtual void dd_pass(int which, double dt, int part) = 0;
-    virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) = 0;
-    virtual void dd_ctrl_init(double delta_x, double t_target, int64_t max_steps) = 0;
-    virtual void dd_step_control(void* red4_dev) = 0;
-    virtual void dd_ctrl_sync(sphmi_dd_control* out) = 0;
-    virtual void dd_ctrl_resume() = 0;
-    virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) = 0;
+    virtual void dd_set_stream(void* s) { not_a_slab(); }
+    virtual void dd_upload(int64_t, const void*, const void*, const void*, const void*, const uint8_t*,
+                           const int64_t*, const uint64_t*, const void*, const int64_t*) { not_a_slab(); }
+    virtual void dd_progress_motion() { not_a_slab(); }
+    virtual void dd_mdbc() { not_a_slab(); }
+    virtual int64_t dd_count() { not_a_slab(); return 0; }
+    virtual void dd_cell_x(int32_t* out_host) { not_a_slab(); }
+    virtual void dd_types(uint8_t* out_host) { not_a_slab(); }
+    virtual void dd_cell_x_dev(int32_t* out_dev) { not_a_slab(); }
+    virtual void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) { not_a_slab(); }
+    virtual void dd_types_dev(uint8_t* out_dev) { not_a_slab(); }
+    virtual size_t dd_record_bytes(int64_t n) { not_a_slab(); return 0; }
+    virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) { not_a_slab(); }
+    virtual void dd_kill(const int32_t* idx_dev, int64_t n) { not_a_slab(); }
+    virtual void dd_kill_ghosts() { not_a_slab(); }
+    virtual void dd_append(const void* buf_dev, int64_t n, int flag) { not_a_slab(); }
+    virtual void dd_rebuild() { not_a_slab(); }
+    virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { not_a_slab(); }
+    virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { not_a_slab(); }
+    virtual void dd_reductions(double* out8) { not_a_slab(); }
+    virtual void dd_reductions_dev(void* out4_dev) { not_a_slab(); }
+    virtual void dd_pass(int which, double dt, int part) { not_a_slab(); }
+    virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) { not_a_slab(); }
+    virtual void dd_ctrl_init(double delta_x, double t_target, int64_t max_steps) { not_a_slab(); }
+    virtual void dd_step_control(void* red4_dev) { not_a_slab(); }
+    virtual void dd_ctrl_sync(sphmi_dd_control* out) { not_a_slab(); }
+    virtual void dd_ctrl_resume() { not_a_slab(); }
+    virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) { not_a_slab(); }
 };
 
 template <class T>
@@ -489,7 +491,7 @@ struct Engine final : EngineBase {
                                    grid.np[0], grid.np[1], dd_axis, lo_pad, hi_pad, tile_cls);
             }
             hipLaunchKernelGGL(k_tile_cost, dim3((ntile + 255) / 256), dim3(256), 0, stream, key[cur], cstart,
-                               dd_slab ? tile_cls : (const uint8_t*)nullptr, N, ntile, grid.np[0], grid.np[0] * grid.np[1], D,
+                               dd_slab ? tile_cls : (const uint8_t*)nullptr, N, ntile, grid.np[0], grid.np[0] * grid.np[1], D, grid.ncell,
                                tile_cost[0], tile_cost[1]);
             for (int l = 0; l < nlist; ++l) {
                 hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_cost[l], tile_scan, ntile, tile_tsum, misc_d + 2);
@@ -1105,6 +1107,8 @@ struct Engine final : EngineBase {
 
 }  // namespace sphmi
 
+#include "sphmi_multi.h"
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -1118,10 +1122,10 @@ struct sphmi_handle { sphmi::EngineBase* e; };
 
 extern "C" {
 
-static_assert(SPHMI_ABI_VERSION == 2, "update the text of sphmi_backend_info");
+static_assert(SPHMI_ABI_VERSION == 3, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
-    return "sphmi abi 2 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
-           "counting-sort cell list, mDBC, moving bodies, shifting | no CPU fallback";
+    return "sphmi abi 3 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+           "counting-sort cell list, mDBC, moving bodies, shifting | multi-GPU slabs over RCCL | no CPU fallback";
 }
 
 const char* sphmi_last_error(const sphmi_handle* h) {
@@ -1129,10 +1133,92 @@ const char* sphmi_last_error(const sphmi_handle* h) {
     return h->e->err.c_str();
 }
 
-int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
+static int check_config(const sphmi_config* cfg, std::string& why);
+
+static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out) {
     using namespace sphmi;
     auto fail = [&](int st, const std::string& m) { g_create_error = m; return st; };
     if (!cfg || !out) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: null argument");
+    std::string why;
+    if (int st = check_config(cfg, why)) return fail(st, why);
+    try {
+        sphmi_handle* h = new sphmi_handle{nullptr};
+        try {
+            const bool f32 = cfg->device_float_bytes == 4;
+            if (rank >= 0) {
+                if (world < 1 || rank >= world) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_create_rank: rank / world out of range");
+                if (f32) h->e = new MultiEngine<float>(*cfg, world, rank, unique_id); else h->e = new MultiEngine<double>(*cfg, world, rank, unique_id);
+            } else if (cfg->n_devices > 1) {
+                if (f32) h->e = new MultiEngine<float>(*cfg, cfg->n_devices, -1, nullptr); else h->e = new MultiEngine<double>(*cfg, cfg->n_devices, -1, nullptr);
+            } else {
+                sphmi_config c = *cfg;
+                if (c.n_devices == 1) c.device = c.devices[0];
+                if (f32) h->e = new Engine<float>(c); else h->e = new Engine<double>(c);
+            }
+        } catch (...) { delete h; throw; }
+        *out = h;
+        return SPHMI_OK;
+    } catch (const EngineError& x) { return fail(x.status, x.what()); }
+    catch (const std::exception& x) { return fail(SPHMI_ERR_DEVICE, x.what()); }
+}
+
+int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) { return create_any(cfg, -1, 0, nullptr, out); }
+int sphmi_create_rank(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out) {
+    if (rank < 0) { sphmi::g_create_error = "sphmi_create_rank: negative rank"; return SPHMI_ERR_ARGUMENT; }
+    return create_any(cfg, rank, world, unique_id, out);
+}
+int sphmi_rccl_unique_id(void* id_out) {
+    using namespace sphmi;
+    if (!id_out) return SPHMI_ERR_ARGUMENT;
+    try {
+        ncclUniqueId id;
+        NC(Rccl::get().GetUniqueId(&id));
+        memcpy(id_out, &id, sizeof id);
+        return SPHMI_OK;
+    } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
+}
+int sphmi_owned_count(sphmi_handle* h, int64_t* n_out) {
+    if (!n_out) return SPHMI_ERR_ARGUMENT;
+    SPHMI_GUARD(h, *n_out = h->e->owned_count());
+}
+int sphmi_multi_info_get(sphmi_handle* h, sphmi_multi_info* out) {
+    if (!out) return SPHMI_ERR_ARGUMENT;
+    SPHMI_GUARD(h, ([&] {
+        if (auto* m = dynamic_cast<sphmi::MultiEngine<float>*>(h->e)) m->multi_info(out);
+        else if (auto* d = dynamic_cast<sphmi::MultiEngine<double>*>(h->e)) d->multi_info(out);
+        else { memset(out, 0, sizeof *out); out->world = 1; out->n_local = 1; }
+    }()));
+}
+int sphmi_multi_set_cuts(sphmi_handle* h, const int64_t* cuts, int32_t n) {
+    if (!cuts || n < 0 || n >= SPHMI_MAX_DEVICES) return SPHMI_ERR_ARGUMENT;
+    SPHMI_GUARD(h, ([&] {
+        sphmi::SlabPlan p;
+        p.lo.assign(n + 1, 0); p.hi.assign(n + 1, 0);
+        for (int r = 0; r <= n; ++r) { p.lo[r] = r == 0 ? -sphmi::SlabPlan::INF : cuts[r - 1]; p.hi[r] = r == n ? sphmi::SlabPlan::INF : cuts[r] - 1; }
+        if (auto* m = dynamic_cast<sphmi::MultiEngine<float>*>(h->e)) m->given_plan = p;
+        else if (auto* d = dynamic_cast<sphmi::MultiEngine<double>*>(h->e)) d->given_plan = p;
+        else throw sphmi::EngineError(SPHMI_ERR_STATE, "sphmi_multi_set_cuts: not a multi-device handle");
+    }()));
+}
+int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* ghost_points, int64_t n, int32_t world,
+                     int32_t* axis_out, int32_t* halo_width_out, int64_t* cuts_out, int64_t* owned_out, int64_t* capacity_out) {
+    using namespace sphmi;
+    if (!cfg || !position || n < 1 || world < 1 || world > SPHMI_MAX_DEVICES) return SPHMI_ERR_ARGUMENT;
+    try {
+        SlabSetup S;
+        plan_slabs(*cfg, position, ghost_points, n, world, cfg->slab_axis - 1, nullptr, 1.6, S);
+        if (axis_out) *axis_out = S.axis;
+        if (halo_width_out) *halo_width_out = S.halo_width;
+        if (cuts_out) for (int r = 1; r < world; ++r) cuts_out[r - 1] = S.plan.lo[r];
+        if (owned_out) { for (int r = 0; r < world; ++r) owned_out[r] = 0; for (int o : S.owner) owned_out[o] += 1; }
+        if (capacity_out) for (int r = 0; r < world; ++r) capacity_out[r] = S.capacity[r];
+        return SPHMI_OK;
+    } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
+    catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_ARGUMENT; }
+}
+
+static int check_config(const sphmi_config* cfg, std::string& why) {
+    auto fail = [&](int st, const std::string& m) { why = m; return st; };
     if (cfg->struct_size != (int32_t)sizeof(sphmi_config) || cfg->abi_version != SPHMI_ABI_VERSION)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: struct_size / abi_version mismatch");
     if (cfg->dims != 2 && cfg->dims != 3) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: dims must be 2 or 3");
@@ -1140,8 +1226,13 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
         (cfg->device_float_bytes != 4 && cfg->device_float_bytes != 8))
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: float_bytes must be 4 or 8");
     // the neighbour gathers use 32-bit buffer offsets: n × sizeof(packet) must stay below 4 GB
-    if (cfg->n_particles < 1 || cfg->n_particles > (1ll << 27))
-        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27]");
+    // (n × sizeof(packet) < 4 GB: 2^27 packets of 16 bytes, 2^26 of 32; a multi-device handle holds n / devices per slab)
+    {
+        const int64_t per = (cfg->n_devices > 1) ? (cfg->n_particles + cfg->n_devices - 1) / cfg->n_devices : cfg->n_particles;
+        const int64_t lim = cfg->device_float_bytes == 8 ? (1ll << 26) : (1ll << 27);
+        if (cfg->n_particles < 1 || per > lim)
+            return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27] (fp32 kernels) / [1, 2^26] (fp64 kernels) per device");
+    }
     if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2 && cfg->kernel != SPHMI_KERNEL_CUBIC_SPLINE)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: kernel not implemented");
     if (cfg->kernel_output != SPHMI_KOUT_NONE && cfg->kernel_output != SPHMI_KOUT_STORE)
@@ -1156,14 +1247,9 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) {
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: mdbc mode not implemented");
     if (!(cfg->h > 0) || !(cfg->H > 0) || !(cfg->rho0 > 0) || !(cfg->m0 > 0) || !(cfg->c0 > 0) || !(cfg->CFL > 0))
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: h, H, rho0, m0, c0, CFL must be positive");
-    try {
-        sphmi_handle* h = new sphmi_handle{nullptr};
-        if (cfg->device_float_bytes == 4) h->e = new Engine<float>(*cfg);
-        else h->e = new Engine<double>(*cfg);
-        *out = h;
-        return SPHMI_OK;
-    } catch (const EngineError& x) { return fail(x.status, x.what()); }
-    catch (const std::exception& x) { return fail(SPHMI_ERR_DEVICE, x.what()); }
+    if (cfg->n_devices < 0 || cfg->n_devices > SPHMI_MAX_DEVICES) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_devices out of range [0, 16]");
+    if (cfg->slab_axis < 0 || cfg->slab_axis > cfg->dims) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: slab_axis must be 0 (auto) or 1 … dims");
+    return SPHMI_OK;
 }
 
 int sphmi_destroy(sphmi_handle* h) {
@@ -1187,13 +1273,13 @@ int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void
 }
 int sphmi_dd_progress_motion(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_progress_motion()); }
 int sphmi_dd_mdbc(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_mdbc()); }
-int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
+int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { if (!n_out) return SPHMI_ERR_ARGUMENT; SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
 int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
 int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }
 int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev) { SPHMI_GUARD(h, h->e->dd_cell_x_dev(cell_x_dev)); }
 int sphmi_dd_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_dev) { SPHMI_GUARD(h, h->e->dd_column_cost(col0, ncols, cost_dev)); }
 int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev) { SPHMI_GUARD(h, h->e->dd_types_dev(type_dev)); }
-int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
+int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { if (!bytes_out) return SPHMI_ERR_ARGUMENT; SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
 int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_gather(idx_dev, n, buf_dev)); }
 int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n) { SPHMI_GUARD(h, h->e->dd_kill(idx_dev, n)); }
 int sphmi_dd_kill_ghosts(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_kill_ghosts()); }
@@ -1216,6 +1302,7 @@ int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, voi
     SPHMI_GUARD(h, h->e->dd_download_owned(position, velocity, density, id, n_out));
 }
 int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
+    if (!out) return SPHMI_ERR_ARGUMENT;
     SPHMI_GUARD(h, (out->iteration = h->e->iteration, out->steps_done = 0, out->n_rebuilds = h->e->n_rebuilds,
                     out->index_counter = h->e->index_counter, out->total_time = h->e->total_time,
                     out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));

@@ -1,0 +1,1108 @@
+// sphmi_multi.h — the slab driver INSIDE libsphmi.so: one sphmi_create / sphmi_advance drives the GPUs of a node.
+//
+// The reference has no multi-device path; its caller runs ONE host process and calls
+// SimulationLoop(...) once per output interval (src/SPHCellList.jl:727-805, called at :883).  This file keeps that
+// contract: a handle created with a device list (sphmi_config.n_devices > 1) owns one slab engine per device and
+// sphmi_advance runs the whole interval — reductions → MAX-allreduce → device-side step control → halo ‖ interior
+// tiles → edge tiles, twice per step — from ONE host thread, with no host round trip inside a batch of queued steps.
+// A second way in, sphmi_create_rank, is the same driver with ONE local slab per process and the peers behind RCCL
+// (what `torchrun bench.py --gpus N` uses: the contract there is one process per GPU).
+//
+// Decomposition (unchanged from round 1, now host C++): 1-D slabs cut on cell-column boundaries by WORK (candidates
+// in the 3^D cells around a particle, the measure of the tile schedule), exact lightest-heaviest-slab cuts (dynamic
+// programme), slab axis chosen for balance, ghost layer = one cell column per side (2 + off with mDBC) kept as
+// ordinary entries of the sorted arrays, migration + re-cut at the collective rebuild, 64-bit order tags that keep
+// the reference's in-cell order independent of the slab a particle lives in.
+//
+// Transport: RCCL (ncclSend / ncclRecv between slab neighbours — each a direct xGMI link — and one ncclAllReduce of
+// four uint64 bit patterns per step), bound at run time from librccl.so.1; or, when the ranks of ONE process share a
+// device (the single-GPU test configuration) or SPHMI_TRANSPORT=local, stream-ordered device copies.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <memory>
+#include <numeric>
+
+namespace sphmi {
+
+// ------------------------------------------------------------------------------------------------------------------
+// device helpers of the collective rebuild: predicates → ascending index lists (stable compaction)
+// ------------------------------------------------------------------------------------------------------------------
+// flag[i] = ((type[i] & tmask) == tval) && lo <= cx[i] <= hi      (type 0 = dead never matches: tval != 0 or tmask == 0 handled by `live`)
+__global__ void __launch_bounds__(256) k_dd_flag(const int* cx, const uint8_t* type, int N, int tmask, int tval, int any_live,
+                                                 long long lo, long long hi, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int t = type[i];
+    const bool tm = any_live ? (t != 0) : ((t & tmask) == tval && t != 0);
+    const long long c = cx[i];
+    flag[i] = (tm && c >= lo && c <= hi) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_dd_compact(const int* flag, const int* pos, int N, int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && flag[i]) out[pos[i]] = i;
+}
+// min / max of cx over the listed particles (slab-skip check) and over owned particles (re-cut extent)
+__global__ void __launch_bounds__(256) k_dd_minmax(const int* cx, const uint8_t* type, const int* idx, int n, int* mm) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int lo = INT32_MAX, hi = INT32_MIN;
+    if (k < n) {
+        const int i = idx ? idx[k] : k;
+        if (idx || (type[i] != 0 && !(type[i] & kGhostMask))) lo = hi = cx[i];
+    }
+    lo = wave_min_i(lo); hi = wave_max_i(hi);
+    if ((threadIdx.x & 63) == 0) { if (lo != INT32_MAX) atomicMin(&mm[0], lo); if (hi != INT32_MIN) atomicMax(&mm[1], hi); }
+}
+// cells that hold owned particles (a cell is wholly owned or wholly ghost: the cuts run along cell columns)
+__global__ void __launch_bounds__(256) k_dd_count_owned_cells(const int* key, const uint8_t* type, int N, int ncell, int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool head = false;
+    if (i < N) { const int k = key[i]; head = k < ncell && type[i] != 0 && !(type[i] & kGhostMask) && (i == 0 || key[i - 1] != k); }
+    const unsigned long long b = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
+}
+// M = max(M, T_0, …, T_{n-1}) over four uint64 bit patterns (non-negative floats order like integers)
+struct RedPtrs { const unsigned long long* p[16]; int n; };
+__global__ void k_dd_merge_max(unsigned long long* M, RedPtrs T) {
+    const int i = threadIdx.x;
+    if (i >= 4) return;
+    unsigned long long v = M[i];
+    for (int k = 0; k < T.n; ++k) { const unsigned long long u = T.p[k][i]; v = u > v ? u : v; }
+    M[i] = v;
+}
+// the reduction slots of the last corrector → T (slots reset); T is what travels
+__global__ void k_dd_take(unsigned long long* red, unsigned long long* T) {
+    const int i = threadIdx.x;
+    if (i < 4) { T[i] = red[i]; red[i] = 0; }
+}
+// both halo lists of a side in one launch: [0, nl) → buf_l, [nl, nl + nr) → buf_r
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_pack2(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+                                                    const int* idx_l, int nl, typename Vec4<T>::type* buf_l,
+                                                    const int* idx_r, int nr, typename Vec4<T>::type* buf_r) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nl) { const int i = idx_l[k]; buf_l[k] = pk0[i]; buf_l[nl + k] = pk1[i]; return; }
+    k -= nl;
+    if (k < nr) { const int i = idx_r[k]; buf_r[k] = pk0[i]; buf_r[nr + k] = pk1[i]; }
+}
+template <class T>
+__global__ void __launch_bounds__(256) k_halo_unpack2(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+                                                      const int* idx_l, int nl, const typename Vec4<T>::type* buf_l,
+                                                      const int* idx_r, int nr, const typename Vec4<T>::type* buf_r) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nl) { const int i = idx_l[k]; pk0[i] = buf_l[k]; pk1[i] = buf_l[nl + k]; return; }
+    k -= nl;
+    if (k < nr) { const int i = idx_r[k]; pk0[i] = buf_r[k]; pk1[i] = buf_r[nr + k]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host-side planning (pure C++: also reachable without a device through sphmi_plan_slabs, for the CPU tests)
+// ------------------------------------------------------------------------------------------------------------------
+struct SlabPlan {
+    static constexpr long long INF = 1ll << 30;
+    std::vector<long long> lo, hi;     // rank r owns the cell columns lo[r] … hi[r] (inclusive)
+    int min_width = 2;                 // columns a slab keeps: at least the halo width (a ghost layer comes from ONE neighbour)
+    int world() const { return (int)lo.size(); }
+    std::vector<long long> cuts() const { std::vector<long long> c; for (int r = 1; r < world(); ++r) c.push_back(lo[r]); return c; }
+    int owner_of(long long cx) const { int r = 0; while (r + 1 < world() && cx >= lo[r + 1]) ++r; return r; }
+};
+
+// map_floor (src/SPHCellList.jl:56-61) in the arithmetic of the DEVICE type: the ownership the host assigns must be
+// the cell the kernels will compute
+inline long long host_cell(double x, double H_inv, int device_float_bytes) {
+    if (device_float_bytes == 4) { const float xf = (float)x; const float t = truncf(fmaf(fabsf(xf), (float)H_inv, 0.5f)); return xf < 0 ? -(long long)t : (long long)t; }
+    const double t = std::trunc(std::fma(std::fabs(x), H_inv, 0.5));
+    return x < 0 ? -(long long)t : (long long)t;
+}
+
+// cut positions c_1 < … < c_{world-1} over columns 0 … n-1 that MINIMISE THE HEAVIEST SLAB, every slab at least `width`
+// columns, cut r within [lo_b[r], hi_b[r]] when given.  Exact (dynamic programme).  false: infeasible.
+inline bool best_cuts(const std::vector<double>& hist, int world, int width, const std::vector<long long>* lo_b,
+                      const std::vector<long long>* hi_b, std::vector<long long>& cuts) {
+    const int n = (int)hist.size();
+    std::vector<double> cum(n + 1, 0.0);
+    for (int i = 0; i < n; ++i) cum[i + 1] = cum[i] + hist[i];
+    const double BIG = std::numeric_limits<double>::infinity();
+    std::vector<double> f(n + 1, BIG), g;
+    f[0] = 0.0;
+    std::vector<std::vector<int>> back(world, std::vector<int>(n + 1, 0));
+    for (int r = 1; r <= world; ++r) {
+        g.assign(n + 1, BIG);
+        long long c0 = r == world ? n : std::max<long long>((long long)r * width, lo_b ? (*lo_b)[r] : 0);
+        long long c1 = r == world ? n : std::min<long long>(n - (long long)(world - r) * width, hi_b ? (*hi_b)[r] : n);
+        for (long long c = c0; c <= c1; ++c) {
+            double best = BIG; int arg = 0;
+            for (long long p = 0; p <= c - width; ++p) {
+                const double v = std::max(f[p], cum[c] - cum[p]);
+                if (v < best) { best = v; arg = (int)p; }
+            }
+            g[c] = best; back[r - 1][c] = arg;
+        }
+        f = g;
+    }
+    if (!(f[n] < BIG)) return false;
+    cuts.assign(world - 1, 0);
+    int c = n;
+    for (int r = world; r >= 1; --r) { c = back[r - 1][c]; if (r >= 2) cuts[r - 2] = c; }
+    return true;
+}
+
+inline bool plan_from_hist(long long col0, const std::vector<double>& hist, int world, int min_width, SlabPlan& plan) {
+    std::vector<long long> inner;
+    if (!best_cuts(hist, world, world > 1 ? min_width : 1, nullptr, nullptr, inner)) return false;
+    plan.lo.assign(world, 0); plan.hi.assign(world, 0); plan.min_width = min_width;
+    for (int r = 0; r < world; ++r) {
+        plan.lo[r] = r == 0 ? -SlabPlan::INF : col0 + inner[r - 1];
+        plan.hi[r] = r == world - 1 ? SlabPlan::INF : col0 + inner[r] - 1;
+    }
+    return true;
+}
+// best cuts for the CURRENT global column histogram, every cut between its two old neighbours (a particle changes rank
+// by at most one: migration stays a neighbour exchange), every slab at least min_width columns
+inline SlabPlan plan_recut(const SlabPlan& old, long long col0, const std::vector<double>& hist) {
+    const int world = old.world(), w = old.min_width;
+    const long long n = (long long)hist.size();
+    std::vector<long long> oc(world + 1);
+    oc[0] = col0; oc[world] = col0 + n;
+    for (int r = 1; r < world; ++r) oc[r] = old.lo[r];
+    std::vector<long long> lo_b(world + 1, 0), hi_b(world + 1, 0), inner;
+    for (int r = 1; r < world; ++r) { lo_b[r] = oc[r - 1] + w - col0; hi_b[r] = oc[r + 1] - w - col0; }
+    lo_b[world] = hi_b[world] = n;
+    SlabPlan p = old;
+    if (!best_cuts(hist, world, w, &lo_b, &hi_b, inner)) return p;
+    for (int r = 0; r < world; ++r) {
+        p.lo[r] = r == 0 ? -SlabPlan::INF : col0 + inner[r - 1];
+        p.hi[r] = r == world - 1 ? SlabPlan::INF : col0 + inner[r] - 1;
+    }
+    return p;
+}
+
+struct SlabSetup {
+    int axis = 0, halo_width = 1;
+    SlabPlan plan;
+    std::vector<int> owner;              // rank of every particle
+    std::vector<long long> capacity;     // particles a rank's handle must hold
+};
+
+// cols[a][i]: cell column of particle i along axis a.  work[i] = candidates in the 3^D cells around particle i.
+inline std::vector<double> particle_work(const std::vector<std::vector<long long>>& cols) {
+    const int D = (int)cols.size();
+    const size_t N = cols[0].size();
+    long long lo[3] = {0, 0, 0}, dim[3] = {1, 1, 1};
+    for (int a = 0; a < D; ++a) {
+        long long mn = cols[a][0], mx = cols[a][0];
+        for (size_t i = 1; i < N; ++i) { mn = std::min(mn, cols[a][i]); mx = std::max(mx, cols[a][i]); }
+        lo[a] = mn; dim[a] = mx - mn + 3;                                  // one cell of padding per side
+    }
+    const size_t nc = (size_t)(dim[0] * dim[1] * dim[2]);
+    std::vector<long long> grid(nc, 0), box(nc, 0);
+    std::vector<size_t> lin(N);
+    for (size_t i = 0; i < N; ++i) {
+        size_t l = 0;
+        for (int a = D - 1; a >= 0; --a) l = l * (size_t)dim[a] + (size_t)(cols[a][i] - lo[a] + 1);
+        lin[i] = l; grid[l] += 1;
+    }
+    long long stride = 1;
+    for (int a = 0; a < D; ++a) {                                          // separable 3-wide box sum (padding cells are empty)
+        for (size_t l = 0; l < nc; ++l) {
+            long long v = grid[l];
+            const long long ca = (long long)(l / (size_t)stride) % dim[a];
+            if (ca > 0) v += grid[l - (size_t)stride];
+            if (ca + 1 < dim[a]) v += grid[l + (size_t)stride];
+            box[l] = v;
+        }
+        grid.swap(box);
+        stride *= dim[a];
+    }
+    std::vector<double> w(N);
+    for (size_t i = 0; i < N; ++i) w[i] = (double)grid[lin[i]];
+    return w;
+}
+
+// Slab axis, cuts, ownership and per-rank capacity for `world` ranks.  axis_req < 0: choose the axis whose best cuts
+// leave the lightest heaviest rank; axes within 1 % tie → the thinnest ghost layers, then the slowest sort axis.
+inline void plan_slabs(const sphmi_config& cfg, const void* position, const void* ghost_points, int64_t N, int world,
+                       int axis_req, const SlabPlan* given, double capacity_factor, SlabSetup& out) {
+    const int D = cfg.dims;
+    auto coord = [&](const void* base, int64_t i, int a) -> double {
+        return cfg.host_float_bytes == 8 ? ((const double*)base)[i * D + a] : (double)((const float*)base)[i * D + a];
+    };
+    std::vector<std::vector<long long>> cols(D, std::vector<long long>((size_t)N));
+    for (int a = 0; a < D; ++a)
+        for (int64_t i = 0; i < N; ++i) cols[a][(size_t)i] = host_cell(coord(position, i, a), cfg.H_inv, cfg.device_float_bytes);
+    // halo width per axis: one column for the pair forces; with mDBC 2 + off, off = the widest column distance between a
+    // boundary particle and its ghost node under any rounding within ±1e-4 of a cell (lattices sit exactly on cell edges)
+    int widths[3] = {1, 1, 1};
+    if (cfg.mdbc == SPHMI_MDBC_SIMPLE && ghost_points) {
+        auto col = [](double u) { const double t = std::trunc(std::fabs(u) + 0.5); return (long long)(u < 0 ? -t : t); };
+        auto dev = [&](double x) { return cfg.device_float_bytes == 4 ? (double)(float)x : x; };
+        for (int a = 0; a < D; ++a) {
+            long long off = 0;
+            for (int64_t i = 0; i < N; ++i) {
+                bool nz = false;
+                for (int d = 0; d < D; ++d) nz |= coord(ghost_points, i, d) != 0.0;
+                if (!nz) continue;
+                const double ug = dev(coord(ghost_points, i, a)) * cfg.H_inv, ux = dev(coord(position, i, a)) * cfg.H_inv;
+                const double e = 1e-4;
+                off = std::max(off, std::max(std::llabs(col(ug + e) - col(ux - e)), std::llabs(col(ug - e) - col(ux + e))));
+            }
+            widths[a] = 2 + (int)off;
+        }
+    }
+    std::vector<double> work;
+    if (world > 1) work = particle_work(cols);
+    auto hist_of = [&](int a, long long& c0) {
+        long long mn = cols[a][0], mx = cols[a][0];
+        for (auto c : cols[a]) { mn = std::min(mn, c); mx = std::max(mx, c); }
+        std::vector<double> h((size_t)(mx - mn + 1), 0.0);
+        for (size_t i = 0; i < (size_t)N; ++i) h[(size_t)(cols[a][i] - mn)] += work.empty() ? 1.0 : work[i];
+        c0 = mn;
+        return h;
+    };
+    int axis = axis_req;
+    if (axis < 0) {
+        struct Cand { double load; long long edge; int ax; };
+        std::vector<Cand> cand;
+        for (int a = 0; a < D; ++a) {
+            long long c0; auto h = hist_of(a, c0);
+            SlabPlan p;
+            if (!plan_from_hist(c0, h, world, std::max(2, widths[a]), p)) continue;
+            std::vector<double> load(world, 0.0);
+            long long edge = 0;
+            for (size_t i = 0; i < (size_t)N; ++i) {
+                const int r = p.owner_of(cols[a][i]);
+                load[r] += work.empty() ? 1.0 : work[i];
+                for (int q = 1; q < world; ++q) edge += (cols[a][i] == p.lo[q] - 1 || cols[a][i] == p.lo[q]) ? 1 : 0;
+            }
+            cand.push_back({*std::max_element(load.begin(), load.end()), edge, a});
+        }
+        if (cand.empty()) throw EngineError(SPHMI_ERR_ARGUMENT, "no axis has enough cell columns per device: too many devices for this domain");
+        double best = cand[0].load;
+        for (auto& c : cand) best = std::min(best, c.load);
+        const Cand* pick = nullptr;
+        for (auto& c : cand) {
+            if (c.load > 1.01 * best) continue;
+            if (!pick || c.edge < pick->edge || (c.edge == pick->edge && c.ax > pick->ax)) pick = &c;
+        }
+        axis = pick->ax;
+    }
+    if (axis >= D) throw EngineError(SPHMI_ERR_ARGUMENT, "slab axis out of range");
+    out.axis = axis; out.halo_width = widths[axis];
+    long long c0; auto h = hist_of(axis, c0);
+    if (given) out.plan = *given;
+    else if (!plan_from_hist(c0, h, world, std::max(2, widths[axis]), out.plan))
+        throw EngineError(SPHMI_ERR_ARGUMENT, "a slab would be narrower than the halo: too many devices for this domain");
+    out.plan.min_width = std::max(out.plan.min_width, widths[axis]);
+    out.owner.resize((size_t)N);
+    std::vector<long long> n_own(world, 0);
+    for (size_t i = 0; i < (size_t)N; ++i) { out.owner[i] = out.plan.owner_of(cols[axis][i]); n_own[out.owner[i]] += 1; }
+    // capacity: owned + the ghost columns, with room for the fluid to pile up and for the cuts to move
+    std::vector<long long> cnt(h.size(), 0);
+    for (size_t i = 0; i < (size_t)N; ++i) cnt[(size_t)(cols[axis][i] - c0)] += 1;
+    const long long lo_c = c0, hi_c = c0 + (long long)h.size() - 1;
+    auto colc = [&](long long c) -> long long { return (c >= lo_c && c <= hi_c) ? cnt[(size_t)(c - lo_c)] : 0; };
+    const long long hmax = *std::max_element(cnt.begin(), cnt.end());
+    out.capacity.assign(world, 0);
+    const int W = out.halo_width;
+    for (int r = 0; r < world; ++r) {
+        const long long s_lo = std::max(out.plan.lo[r], lo_c), s_hi = std::min(out.plan.hi[r], hi_c);
+        long long ghosts = 0;
+        for (int k = 1; k <= W; ++k) ghosts += colc(s_lo - k) + colc(s_hi + k);
+        const long long slack = colc(s_lo - W - 1) + colc(s_hi + W + 1) + 2 * hmax;
+        long long cap = (long long)(capacity_factor * (double)(n_own[r] + ghosts)) + slack + 1024;
+        cap = std::max(cap, (long long)(capacity_factor * ((double)N / world)));
+        out.capacity[r] = cap;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time (librccl.so.1: the copy already in the process — torch ships one — or /opt/rocm/lib's)
+// ------------------------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    static Rccl& get() {
+        static Rccl r;
+        if (r.so) return r;
+        const char* names[] = {getenv("SPHMI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { if (n && *n && (r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
+        if (!r.so) throw EngineError(SPHMI_ERR_DEVICE, std::string("RCCL not found (librccl.so.1): ") + (dlerror() ? dlerror() : ""));
+        auto sym = [&](const char* s) { void* p = dlsym(r.so, s); if (!p) throw EngineError(SPHMI_ERR_DEVICE, std::string("RCCL symbol missing: ") + s); return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        return r;
+    }
+};
+#define NC(expr)                                                                                                      \
+    do {                                                                                                              \
+        ncclResult_t r_ = (expr);                                                                                     \
+        if (r_ != ncclSuccess) throw EngineError(SPHMI_ERR_DEVICE, std::string(#expr) + ": " + Rccl::get().GetErrorString(r_)); \
+    } while (0)
+
+// a device buffer that only grows (rebuild-time lists and message buffers)
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    void* need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            if (hipMalloc(&p, want) != hipSuccess) throw EngineError(SPHMI_ERR_DEVICE, "hipMalloc failed (slab driver buffer)");
+            cap = want;
+        }
+        return p;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// one point-to-point message of a phase (global ranks; buffers are device memory of the local end(s))
+struct Msg { int src, dst; const void* sbuf; void* rbuf; size_t bytes; int slot; };   // slot: which persistent buffer pair (WAR tracking of the local transport)
+
+template <class T> struct MultiEngine;
+
+// ------------------------------------------------------------------------------------------------------------------
+template <class T>
+struct MultiEngine final : EngineBase {
+    using V4 = typename Vec4<T>::type;
+    struct Halo {                          // one per state set: [0] = A (halo_width columns), [1] = H (one column)
+        DevBuf send_l, send_r, slot_l, slot_r, sb_l, sb_r, rb_l, rb_r;
+        int n_send_l = 0, n_send_r = 0, n_slot_l = 0, n_slot_r = 0;
+    };
+    struct Rank {
+        int rank = 0, device = 0;
+        std::unique_ptr<Engine<T>> e;
+        hipStream_t main = nullptr, side = nullptr;
+        hipEvent_t ev_pack = nullptr, ev_edge = nullptr, ev_red = nullptr, ev_consumed[8] = {};
+        bool consumed_valid[8] = {};
+        Halo halo[2];
+        unsigned long long *T2 = nullptr, *M = nullptr, *stage = nullptr;   // T2: 2 × 4 travelling slots (step parity), M: merged, stage: peers' T (other devices)
+        DevBuf cx, flag, pos, idx[4], rec_s[2], rec_r[2], cost;
+        int* mm_d = nullptr; int* mm_h = nullptr;
+        int64_t* cnt_h = nullptr;
+        ncclComm_t comm = nullptr;
+        bool has_left = false, has_right = false;
+    };
+    int world = 1;                     // slabs in total
+    std::vector<Rank> R;               // the LOCAL ones (all of them in one-process mode, one in rank mode)
+    bool rank_mode = false;            // one local slab, peers in other processes
+    bool use_rccl = false;
+    int D = 0, axis = 0, halo_width = 1;
+    SlabPlan plan;
+    bool overlap = true, moving = false, have_halo = false;
+    double recut_imbalance = 1.05; int64_t n_recuts = 0;
+    int64_t n_total = 0;
+    double dx_rate = 0.0;
+    int parity = 0;
+    static constexpr int kBatch = 16;
+    std::vector<int> dev_of;           // device of every global rank (one-process mode)
+
+    Rank* local(int g) { for (auto& r : R) if (r.rank == g) return &r; return nullptr; }
+
+    MultiEngine(const sphmi_config& c, int world_, int my_rank /* −1: all ranks local */, const void* unique_id) {
+        cfg = c; D = c.dims; world = world_; out_comp = c.dims;
+        rank_mode = my_rank >= 0;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw EngineError(SPHMI_ERR_DEVICE, "no HIP device available (libsphmi has no CPU fallback)");
+        if (world < 1 || world > 16) throw EngineError(SPHMI_ERR_ARGUMENT, "1 to 16 slabs per handle");
+        if (const char* w = getenv("SPHMI_DD_OVERLAP")) overlap = atoi(w) != 0;
+        if (const char* w = getenv("SPHMI_DD_RECUT")) recut_imbalance = atof(w);
+        bool shared_device = false;
+        if (rank_mode) {
+            R.resize(1); R[0].rank = my_rank; R[0].device = c.device;
+        } else {
+            R.resize(world);
+            for (int r = 0; r < world; ++r) {
+                R[r].rank = r; R[r].device = c.devices[r];
+                for (int q = 0; q < r; ++q) shared_device |= c.devices[q] == c.devices[r];
+            }
+        }
+        for (auto& r : R) if (r.device < 0 || r.device >= ndev) throw EngineError(SPHMI_ERR_ARGUMENT, "device ordinal out of range");
+        const char* tr = getenv("SPHMI_TRANSPORT");
+        // (a one-rank world under sphmi_create_rank still runs its allreduce through RCCL: the binding is exercised)
+        use_rccl = rank_mode || (world > 1 && !shared_device && !(tr && !strcmp(tr, "local")));
+        if (tr && !strcmp(tr, "rccl") && shared_device) throw EngineError(SPHMI_ERR_ARGUMENT, "RCCL cannot run two ranks on one device");
+        if (use_rccl) {
+            Rccl& N = Rccl::get();
+            if (rank_mode) {
+                if (!unique_id) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_create_rank: null unique id");
+                ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+                HC(hipSetDevice(R[0].device));
+                NC(N.CommInitRank(&R[0].comm, world, id, my_rank));
+            } else {
+                std::vector<ncclComm_t> comms(world);
+                std::vector<int> devs(world);
+                for (int r = 0; r < world; ++r) devs[r] = R[r].device;
+                NC(N.CommInitAll(comms.data(), world, devs.data()));
+                for (int r = 0; r < world; ++r) R[r].comm = comms[r];
+            }
+        }
+        if (!use_rccl && !rank_mode) {
+            // stream-ordered copies between the slabs of this process: peers on other devices need peer access
+            for (auto& a : R) for (auto& b : R) if (a.device != b.device) {
+                HC(hipSetDevice(a.device));
+                int can = 0; (void)hipDeviceCanAccessPeer(&can, a.device, b.device);
+                if (can) { hipError_t e = hipDeviceEnablePeerAccess(b.device, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+            }
+        }
+        for (auto& r : R) {
+            r.has_left = r.rank > 0; r.has_right = r.rank < world - 1;
+            HC(hipSetDevice(r.device));
+            HC(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+            HC(hipEventCreateWithFlags(&r.ev_pack, hipEventDisableTiming));
+            HC(hipEventCreateWithFlags(&r.ev_edge, hipEventDisableTiming));
+            HC(hipEventCreateWithFlags(&r.ev_red, hipEventDisableTiming));
+            for (auto& e : r.ev_consumed) HC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HC(hipMalloc(&r.T2, 8 * 8)); HC(hipMalloc(&r.M, 4 * 8)); HC(hipMalloc(&r.stage, 16 * 4 * 8));
+            HC(hipMemset(r.T2, 0, 8 * 8)); HC(hipMemset(r.M, 0, 4 * 8));
+            HC(hipMalloc(&r.mm_d, 2 * 4)); HC(hipHostMalloc(&r.mm_h, 2 * 4)); HC(hipHostMalloc(&r.cnt_h, 8 * 8));
+        }
+    }
+    ~MultiEngine() override {
+        for (auto& r : R) {
+            (void)hipSetDevice(r.device);
+            if (r.e) (void)hipStreamSynchronize(r.e->stream);
+            if (r.side) { (void)hipStreamSynchronize(r.side); }
+            if (r.comm) { try { Rccl::get().CommDestroy(r.comm); } catch (...) {} }
+            for (auto& h : r.halo) for (DevBuf* b : {&h.send_l, &h.send_r, &h.slot_l, &h.slot_r, &h.sb_l, &h.sb_r, &h.rb_l, &h.rb_r}) b->release();
+            for (DevBuf* b : {&r.cx, &r.flag, &r.pos, &r.idx[0], &r.idx[1], &r.idx[2], &r.idx[3], &r.rec_s[0], &r.rec_s[1], &r.rec_r[0], &r.rec_r[1], &r.cost}) b->release();
+            (void)hipFree(r.T2); (void)hipFree(r.M); (void)hipFree(r.stage); (void)hipFree(r.mm_d); (void)hipHostFree(r.mm_h); (void)hipHostFree(r.cnt_h);
+            if (r.ev_pack) { (void)hipEventDestroy(r.ev_pack); (void)hipEventDestroy(r.ev_edge); (void)hipEventDestroy(r.ev_red); }
+            for (auto& e : r.ev_consumed) if (e) (void)hipEventDestroy(e);
+            r.e.reset();
+            if (r.side) (void)hipStreamDestroy(r.side);
+        }
+    }
+
+    // ---- host-side collectives (rebuild-time bookkeeping: counts and the handful of scalars of the re-cut) --------
+    // vals[k][r]: value k of local rank r → every local rank sees the reduction over ALL ranks
+    enum Op { OP_SUM, OP_MAX };
+    void host_allreduce(std::vector<long long>& v /* per local rank: n values each, concatenated [r][k] */, int n, Op op) {
+        const int L = (int)R.size();
+        if (!rank_mode) {
+            for (int k = 0; k < n; ++k) {
+                long long acc = v[k];
+                for (int r = 1; r < L; ++r) acc = op == OP_SUM ? acc + v[(size_t)r * n + k] : std::max(acc, v[(size_t)r * n + k]);
+                for (int r = 0; r < L; ++r) v[(size_t)r * n + k] = acc;
+            }
+            return;
+        }
+        if (world == 1) return;
+        Rank& r = R[0];
+        HC(hipSetDevice(r.device));
+        void* d = r.cost.need((size_t)n * 8);
+        HC(hipMemcpyAsync(d, v.data(), (size_t)n * 8, hipMemcpyHostToDevice, r.main));
+        NC(Rccl::get().AllReduce(d, d, (size_t)n, ncclInt64, op == OP_SUM ? ncclSum : ncclMax, r.comm, r.main));
+        HC(hipMemcpyAsync(v.data(), d, (size_t)n * 8, hipMemcpyDeviceToHost, r.main));
+        HC(hipStreamSynchronize(r.main));
+    }
+    // every local rank tells its neighbours one number per side; returns what the neighbours told it
+    void host_neighbour_counts(const std::vector<long long>& to_l, const std::vector<long long>& to_r,
+                               std::vector<long long>& from_l, std::vector<long long>& from_r) {
+        const int L = (int)R.size();
+        from_l.assign(L, 0); from_r.assign(L, 0);
+        if (!rank_mode) {
+            for (int r = 0; r < L; ++r) { if (r > 0) from_l[r] = to_r[r - 1]; if (r + 1 < L) from_r[r] = to_l[r + 1]; }
+            return;
+        }
+        if (world == 1) return;
+        Rank& r = R[0];
+        HC(hipSetDevice(r.device));
+        long long* d = (long long*)r.cost.need(4 * 8);
+        r.cnt_h[0] = to_l[0]; r.cnt_h[1] = to_r[0]; r.cnt_h[2] = 0; r.cnt_h[3] = 0;
+        HC(hipMemcpyAsync(d, r.cnt_h, 4 * 8, hipMemcpyHostToDevice, r.main));
+        Rccl& N = Rccl::get();
+        NC(N.GroupStart());
+        if (r.has_left) { NC(N.Send(d + 0, 1, ncclInt64, r.rank - 1, r.comm, r.main)); NC(N.Recv(d + 2, 1, ncclInt64, r.rank - 1, r.comm, r.main)); }
+        if (r.has_right) { NC(N.Send(d + 1, 1, ncclInt64, r.rank + 1, r.comm, r.main)); NC(N.Recv(d + 3, 1, ncclInt64, r.rank + 1, r.comm, r.main)); }
+        NC(N.GroupEnd());
+        HC(hipMemcpyAsync(r.cnt_h, d, 4 * 8, hipMemcpyDeviceToHost, r.main));
+        HC(hipStreamSynchronize(r.main));
+        from_l[0] = r.cnt_h[2]; from_r[0] = r.cnt_h[3];
+    }
+
+    // ---- device point-to-point phase ----------------------------------------------------------------------------
+    // Every local sender has recorded ev_pack on its main stream after filling its send buffers.  side: the messages
+    // (and whatever the caller queues behind them) go to the side streams, so that the interior launch on main overlaps.
+    void exchange(const std::vector<Msg>& msgs, bool side) {
+        if (msgs.empty()) return;
+        if (use_rccl) {
+            Rccl& N = Rccl::get();
+            NC(N.GroupStart());
+            for (const Msg& m : msgs) {
+                if (Rank* s = local(m.src)) { HC(hipSetDevice(s->device)); NC(N.Send(m.sbuf, m.bytes, ncclUint8, m.dst, s->comm, side ? s->side : s->main)); }
+                if (Rank* d = local(m.dst)) { HC(hipSetDevice(d->device)); NC(N.Recv(m.rbuf, m.bytes, ncclUint8, m.src, d->comm, side ? d->side : d->main)); }
+            }
+            NC(N.GroupEnd());
+            return;
+        }
+        for (const Msg& m : msgs) {
+            Rank *s = local(m.src), *d = local(m.dst);
+            hipStream_t q = side ? d->side : d->main;
+            HC(hipSetDevice(d->device));
+            HC(hipStreamWaitEvent(q, s->ev_pack, 0));
+            if (m.bytes) HC(hipMemcpyAsync(m.rbuf, m.sbuf, m.bytes, hipMemcpyDeviceToDevice, q));
+            if (m.slot >= 0) {       // the sender must not refill this buffer before the copy has read it
+                HC(hipEventRecord(s->ev_consumed[m.slot], q));
+                s->consumed_valid[m.slot] = true;
+            }
+        }
+    }
+    void wait_consumed(Rank& r, int slot) {
+        if (!use_rccl && r.consumed_valid[slot]) { HC(hipStreamWaitEvent(r.main, r.ev_consumed[slot], 0)); r.consumed_valid[slot] = false; }
+    }
+
+    // ---- upload: split the particle set, one slab engine per local rank ------------------------------------------
+    void upload(const void* position, const void* velocity, const void* acceleration, const void* density,
+                const uint8_t* ty, const int64_t* ids, const uint64_t* groups, const void* ghost_points) override {
+        if (!position || !velocity || !density || !ty || !ids) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: null array");
+        if (cfg.mdbc != SPHMI_MDBC_NONE && !ghost_points) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: mDBC handle without ghost points");
+        const int64_t N = cfg.n_particles;
+        n_total = N;
+        SlabSetup S;
+        plan_slabs(cfg, position, ghost_points, N, world, cfg.slab_axis - 1, given_plan.world() == world ? &given_plan : nullptr, 1.6, S);
+        axis = S.axis; halo_width = S.halo_width; plan = S.plan;
+        const size_t hb = (size_t)cfg.host_float_bytes;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            sphmi_config c = cfg;
+            c.n_particles = S.capacity[r.rank]; c.device = r.device; c.n_devices = 0;
+            if (c.n_particles > (1ll << 27)) throw EngineError(SPHMI_ERR_ARGUMENT, "slab capacity beyond 2^27 particles: use more devices");
+            r.e.reset(new Engine<T>(c));
+            r.main = r.e->stream;
+            r.e->dd_set_slab(axis, std::max(plan.lo[r.rank], -SlabPlan::INF), std::min(plan.hi[r.rank], SlabPlan::INF), r.has_left, r.has_right);
+            for (int m = 0; m < motions_n; ++m) r.e->set_motion(mot_group[m], mot_vel[m], mot_start[m], mot_dur[m], mot_dir[m]);
+            r.e->iteration = iteration; r.e->total_time = total_time;
+            std::vector<int64_t> mine;
+            for (int64_t i = 0; i < N; ++i) if (S.owner[(size_t)i] == r.rank) mine.push_back(i);
+            const size_t n = mine.size();
+            if (n == 0) throw EngineError(SPHMI_ERR_ARGUMENT, "a slab owns no particle: too many devices for this case");
+            auto take = [&](const void* src, size_t elem) {
+                std::vector<char> o(src ? n * elem : 0);
+                if (src) for (size_t k = 0; k < n; ++k) memcpy(&o[k * elem], (const char*)src + (size_t)mine[k] * elem, elem);
+                return o;
+            };
+            auto px = take(position, hb * D), pv = take(velocity, hb * D), pa = take(acceleration, hb * D), pr = take(density, hb);
+            auto pt = take(ty, 1), pi = take(ids, 8), pg = take(groups, 8), ph = take(ghost_points, hb * D);
+            r.e->dd_upload((int64_t)n, px.data(), pv.data(), acceleration ? pa.data() : nullptr, pr.data(), (const uint8_t*)pt.data(),
+                           (const int64_t*)pi.data(), groups ? (const uint64_t*)pg.data() : nullptr,
+                           ghost_points ? ph.data() : nullptr, mine.data());
+        }
+        uploaded = true; have_halo = false; dx_rate = 0.0;
+    }
+
+    SlabPlan given_plan;               // test hook (sphmi_multi_set_cuts): start from these cuts instead of the balanced ones
+    int motions_n = 0; uint64_t mot_group[16]; double mot_vel[16], mot_start[16], mot_dur[16], mot_dir[16][3];
+    void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) override {
+        if (!dir) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_motion: null direction");
+        int m = 0;
+        while (m < motions_n && mot_group[m] != group) ++m;
+        if (m == 16) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_motion: more than 16 moving groups");
+        if (m == motions_n) motions_n += 1;
+        mot_group[m] = group; mot_vel[m] = vel; mot_start[m] = start; mot_dur[m] = dur;
+        for (int d = 0; d < 3; ++d) mot_dir[m][d] = d < D ? dir[d] : 0.0;
+        moving = true;
+        for (auto& r : R) if (r.e) r.e->set_motion(group, vel, start, dur, dir);
+    }
+
+    // ---- collective rebuild ------------------------------------------------------------------------------------
+    int* where(Rank& r, int tmask, int tval, bool any_live, long long lo, long long hi, DevBuf& out, int& n_out, bool sync_count = true) {
+        Engine<T>& e = *r.e;
+        const int N = e.N;
+        n_out = 0;
+        if (N == 0) return nullptr;
+        int* flag = (int*)r.flag.need((size_t)N * 4);
+        int* pos = (int*)r.pos.need((size_t)(N + 1) * 4);
+        const int nb = (N + 255) / 256;
+        hipLaunchKernelGGL(k_dd_flag, dim3(nb), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)e.type[e.cur], N, tmask, tval, any_live ? 1 : 0, lo, hi, flag);
+        const int ntiles = (N + kScanTile - 1) / kScanTile;
+        int* tsum = (int*)r.cost.need((size_t)(ntiles + 8) * 4 + 64);
+        hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, r.main, (const int*)flag, pos, N, tsum, tsum + ntiles + 2);
+        hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, r.main, tsum, ntiles, tsum + ntiles + 1);
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, r.main, pos, N, (const int*)tsum, (const int*)(tsum + ntiles + 1));
+        HC(hipGetLastError());
+        HC(hipMemcpyAsync(r.mm_h, pos + N, 4, hipMemcpyDeviceToHost, r.main));
+        HC(hipStreamSynchronize(r.main));
+        n_out = r.mm_h[0];
+        int* idx = (int*)out.need((size_t)std::max(n_out, 1) * 4);
+        if (n_out) { hipLaunchKernelGGL(k_dd_compact, dim3(nb), dim3(256), 0, r.main, (const int*)flag, (const int*)pos, N, idx); HC(hipGetLastError()); }
+        return idx;
+    }
+    void cellx(Rank& r) {
+        Engine<T>& e = *r.e;
+        int* cx = (int*)r.cx.need((size_t)std::max(e.N, 1) * 4);
+        e.dd_cell_x_dev(cx);
+    }
+    void set_slab(Rank& r) {
+        r.e->dd_set_slab(axis, std::max(plan.lo[r.rank], -SlabPlan::INF), std::min(plan.hi[r.rank], SlabPlan::INF), r.has_left, r.has_right);
+    }
+
+    void rebuild_collective() {
+        const int L = (int)R.size();
+        for (auto& r : R) { HC(hipSetDevice(r.device)); cellx(r); }
+        // 0. load balance by WORK (candidates per particle on the cell list of the previous rebuild): the rebuild is the
+        //    only time particles change cells, so it is also when the cuts may move
+        if (world > 1 && recut_imbalance > 0 && n_rebuilds > 0) {
+            std::vector<long long> ext((size_t)L * 2);
+            for (int q = 0; q < L; ++q) {
+                Rank& r = R[q]; HC(hipSetDevice(r.device));
+                r.mm_h[0] = INT32_MAX; r.mm_h[1] = INT32_MIN;
+                HC(hipMemcpyAsync(r.mm_d, r.mm_h, 8, hipMemcpyHostToDevice, r.main));
+                hipLaunchKernelGGL(k_dd_minmax, dim3((r.e->N + 255) / 256), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)nullptr, r.e->N, r.mm_d);
+                HC(hipMemcpyAsync(r.mm_h, r.mm_d, 8, hipMemcpyDeviceToHost, r.main));
+                HC(hipStreamSynchronize(r.main));
+                ext[(size_t)q * 2] = -(long long)r.mm_h[0]; ext[(size_t)q * 2 + 1] = r.mm_h[1];
+            }
+            host_allreduce(ext, 2, OP_MAX);
+            const long long gmin = -ext[0], gmax = ext[1];
+            const int ncols = (int)(gmax - gmin + 1);
+            std::vector<std::vector<long long>> cost(L, std::vector<long long>(ncols, 0));
+            std::vector<long long> tot((size_t)L * 2);
+            for (int q = 0; q < L; ++q) {
+                Rank& r = R[q]; HC(hipSetDevice(r.device));
+                unsigned long long* cd = (unsigned long long*)r.cost.need((size_t)ncols * 8);
+                HC(hipMemsetAsync(cd, 0, (size_t)ncols * 8, r.main));
+                r.e->dd_column_cost(gmin, ncols, (uint64_t*)cd);
+                HC(hipMemcpyAsync(cost[q].data(), cd, (size_t)ncols * 8, hipMemcpyDeviceToHost, r.main));
+                HC(hipStreamSynchronize(r.main));
+                long long mine = 0; for (auto v : cost[q]) mine += v;
+                tot[(size_t)q * 2] = mine;
+            }
+            // heaviest rank and total
+            std::vector<long long> mx(L), sm(L);
+            for (int q = 0; q < L; ++q) { mx[q] = tot[(size_t)q * 2]; sm[q] = tot[(size_t)q * 2]; }
+            host_allreduce(mx, 1, OP_MAX); host_allreduce(sm, 1, OP_SUM);
+            if ((double)mx[0] * world > recut_imbalance * (double)sm[0]) {
+                std::vector<long long> hist((size_t)L * ncols);
+                for (int q = 0; q < L; ++q) memcpy(&hist[(size_t)q * ncols], cost[q].data(), (size_t)ncols * 8);
+                host_allreduce(hist, ncols, OP_SUM);
+                std::vector<double> h(ncols);
+                for (int k = 0; k < ncols; ++k) h[k] = (double)hist[k];
+                SlabPlan np = plan_recut(plan, gmin, h);
+                if (np.cuts() != plan.cuts()) { plan = np; for (auto& r : R) set_slab(r); n_recuts += 1; }
+            }
+        }
+        // 1. ghosts die, leavers migrate to the adjacent rank
+        std::vector<long long> to_l(L, 0), to_r(L, 0), from_l, from_r;
+        std::vector<int*> go_l(L, nullptr), go_r(L, nullptr);
+        for (int q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            const long long lo = plan.lo[r.rank], hi = plan.hi[r.rank];
+            int nl = 0, nr = 0;
+            if (r.has_left) go_l[q] = where(r, kGhostMask, 0, false, -(1ll << 40), lo - 1, r.idx[0], nl);
+            if (r.has_right) go_r[q] = where(r, kGhostMask, 0, false, hi + 1, 1ll << 40, r.idx[1], nr);
+            to_l[q] = nl; to_r[q] = nr;
+            // a particle must not skip a whole slab between two rebuilds
+            for (int s = 0; s < 2; ++s) {
+                const int n = s == 0 ? nl : nr;
+                if (!n) continue;
+                r.mm_h[0] = INT32_MAX; r.mm_h[1] = INT32_MIN;
+                HC(hipMemcpyAsync(r.mm_d, r.mm_h, 8, hipMemcpyHostToDevice, r.main));
+                hipLaunchKernelGGL(k_dd_minmax, dim3((n + 255) / 256), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)(s == 0 ? go_l[q] : go_r[q]), n, r.mm_d);
+                HC(hipMemcpyAsync(r.mm_h, r.mm_d, 8, hipMemcpyDeviceToHost, r.main));
+                HC(hipStreamSynchronize(r.main));
+                if ((s == 0 && r.mm_h[0] < plan.lo[r.rank - 1]) || (s == 1 && r.mm_h[1] > plan.hi[r.rank + 1]))
+                    throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: a particle skipped a whole slab between two rebuilds");
+            }
+            r.e->dd_kill_ghosts();
+        }
+        migrate(to_l, to_r, go_l, go_r, /*kill=*/true, 0, 0);
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); r.e->dd_rebuild(); }
+        // 2. the first / last column(s) of the slab become the neighbours' ghost layer
+        const int W = halo_width;
+        std::vector<long long> n_bl(L, 0), n_br(L, 0);
+        for (int q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            cellx(r);
+            const long long lo = plan.lo[r.rank], hi = plan.hi[r.rank];
+            int nl = 0, nr = 0;
+            if (r.has_left) go_l[q] = where(r, 0, 0, true, -(1ll << 40), lo + W - 1, r.idx[0], nl);
+            if (r.has_right) go_r[q] = where(r, 0, 0, true, hi - W + 1, 1ll << 40, r.idx[1], nr);
+            n_bl[q] = nl; n_br[q] = nr;
+        }
+        std::vector<long long> got_l, got_r;
+        migrate(n_bl, n_br, go_l, go_r, /*kill=*/false, kGhostLeft, kGhostRight, &got_l, &got_r);
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); r.e->dd_rebuild(); }
+        // 3. halo index lists in the final order (stable sorts ⇒ k-th sender entry ↔ k-th ghost slot; the same holds for
+        //    the sub-lists of ONE column).  State A travels with all halo_width columns (mDBC reads them), the
+        //    half-step state H with the one column the pair forces reach.
+        for (int q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            cellx(r);
+            const long long lo = plan.lo[r.rank], hi = plan.hi[r.rank];
+            for (int k = 0; k < 2; ++k) {
+                const int w = k == 0 ? W : 1;
+                Halo& h = r.halo[k];
+                h.n_send_l = h.n_send_r = h.n_slot_l = h.n_slot_r = 0;
+                if (r.has_left) where(r, kGhostMask, 0, false, -(1ll << 40), lo + w - 1, h.send_l, h.n_send_l);
+                if (r.has_right) where(r, kGhostMask, 0, false, hi - w + 1, 1ll << 40, h.send_r, h.n_send_r);
+                where(r, kGhostLeft, kGhostLeft, false, lo - w, 1ll << 40, h.slot_l, h.n_slot_l);
+                where(r, kGhostRight, kGhostRight, false, -(1ll << 40), hi + w, h.slot_r, h.n_slot_r);
+                if (k == 0 && (h.n_send_l != n_bl[q] || h.n_send_r != n_br[q] || h.n_slot_l != got_l[q] || h.n_slot_r != got_r[q]))
+                    throw EngineError(SPHMI_ERR_STATE, "domain decomposition: boundary columns changed between the two sorts");
+                const size_t vb = 2 * sizeof(V4);
+                h.sb_l.need((size_t)std::max(h.n_send_l, 1) * vb); h.sb_r.need((size_t)std::max(h.n_send_r, 1) * vb);
+                h.rb_l.need((size_t)std::max(h.n_slot_l, 1) * vb); h.rb_r.need((size_t)std::max(h.n_slot_r, 1) * vb);
+            }
+            for (bool& v : r.consumed_valid) v = false;
+        }
+        // the one-column lists of state H must pair up across the cut exactly like the wide ones
+        {
+            std::vector<long long> sl(L), sr(L), fl, fr;
+            for (int q = 0; q < L; ++q) { sl[q] = R[q].halo[1].n_send_l; sr[q] = R[q].halo[1].n_send_r; }
+            host_neighbour_counts(sl, sr, fl, fr);
+            for (int q = 0; q < L; ++q)
+                if (R[q].halo[1].n_slot_l != fl[q] || R[q].halo[1].n_slot_r != fr[q])
+                    throw EngineError(SPHMI_ERR_STATE, "domain decomposition: edge-column lists do not pair up across a cut");
+        }
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
+        have_halo = true;
+        n_rebuilds += 1;
+    }
+
+    // full records of the listed particles to the adjacent ranks; arrivals are appended with `flag`
+    void migrate(const std::vector<long long>& n_l, const std::vector<long long>& n_r, const std::vector<int*>& idx_l,
+                 const std::vector<int*>& idx_r, bool kill, int flag_from_left, int flag_from_right,
+                 std::vector<long long>* got_l = nullptr, std::vector<long long>* got_r = nullptr) {
+        const int L = (int)R.size();
+        std::vector<long long> from_l, from_r;
+        host_neighbour_counts(n_l, n_r, from_l, from_r);
+        std::vector<Msg> msgs;
+        for (int q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            void* sl = n_l[q] ? r.rec_s[0].need(DdRecord<T>::bytes((size_t)n_l[q])) : nullptr;
+            void* sr = n_r[q] ? r.rec_s[1].need(DdRecord<T>::bytes((size_t)n_r[q])) : nullptr;
+            if (n_l[q]) e.dd_gather(idx_l[q], n_l[q], sl);
+            if (n_r[q]) e.dd_gather(idx_r[q], n_r[q], sr);
+            void* rl = from_l[q] ? r.rec_r[0].need(DdRecord<T>::bytes((size_t)from_l[q])) : nullptr;
+            void* rr = from_r[q] ? r.rec_r[1].need(DdRecord<T>::bytes((size_t)from_r[q])) : nullptr;
+            HC(hipEventRecord(r.ev_pack, r.main));
+            if (n_l[q]) msgs.push_back({r.rank, r.rank - 1, sl, nullptr, DdRecord<T>::bytes((size_t)n_l[q]), -1});
+            if (n_r[q]) msgs.push_back({r.rank, r.rank + 1, sr, nullptr, DdRecord<T>::bytes((size_t)n_r[q]), -1});
+            if (from_l[q]) msgs.push_back({r.rank - 1, r.rank, nullptr, rl, DdRecord<T>::bytes((size_t)from_l[q]), -1});
+            if (from_r[q]) msgs.push_back({r.rank + 1, r.rank, nullptr, rr, DdRecord<T>::bytes((size_t)from_r[q]), -1});
+        }
+        exchange(pair_up(msgs), false);
+        for (int q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            if (kill) { if (n_l[q]) e.dd_kill(idx_l[q], n_l[q]); if (n_r[q]) e.dd_kill(idx_r[q], n_r[q]); }
+            if (from_l[q]) e.dd_append(r.rec_r[0].p, from_l[q], flag_from_left);
+            if (from_r[q]) e.dd_append(r.rec_r[1].p, from_r[q], flag_from_right);
+            // the send buffers are reused by the next migrate: everything queued so far must have read them
+            HC(hipStreamSynchronize(r.main));
+        }
+        if (!use_rccl) for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
+        if (got_l) *got_l = from_l;
+        if (got_r) *got_r = from_r;
+    }
+    // Posted halves {src → dst: sbuf} and {src → dst: rbuf} become one message per (src, dst) when both ends are local;
+    // with RCCL the two halves stay separate calls anyway (Send on the source's communicator, Recv on the target's).
+    std::vector<Msg> pair_up(const std::vector<Msg>& posted) {
+        std::vector<Msg> out;
+        for (const Msg& m : posted) {
+            bool merged = false;
+            for (Msg& o : out) if (o.src == m.src && o.dst == m.dst && o.slot == m.slot) {
+                if (m.sbuf) o.sbuf = m.sbuf;
+                if (m.rbuf) o.rbuf = m.rbuf;
+                merged = true; break;
+            }
+            if (!merged) out.push_back(m);
+        }
+        if (use_rccl) {
+            // one entry per local END: a message whose both ends are local is sent by one and received by the other —
+            // exchange() issues Send when the source is local and Recv when the target is local, which is what `out` holds
+            return out;
+        }
+        return out;
+    }
+
+    // ---- one neighbour pass with its halo, all local ranks, phase by phase ----------------------------------------
+    void halo_msgs(int which, std::vector<Msg>& msgs) {
+        msgs.clear();
+        const size_t vb = 2 * sizeof(V4);
+        for (auto& r : R) {
+            Halo& h = r.halo[which];
+            if (r.has_left && h.n_send_l) msgs.push_back({r.rank, r.rank - 1, h.sb_l.p, nullptr, (size_t)h.n_send_l * vb, which * 4 + 0});
+            if (r.has_right && h.n_send_r) msgs.push_back({r.rank, r.rank + 1, h.sb_r.p, nullptr, (size_t)h.n_send_r * vb, which * 4 + 1});
+            if (r.has_left && h.n_slot_l) msgs.push_back({r.rank - 1, r.rank, nullptr, h.rb_l.p, (size_t)h.n_slot_l * vb, which * 4 + 1});
+            if (r.has_right && h.n_slot_r) msgs.push_back({r.rank + 1, r.rank, nullptr, h.rb_r.p, (size_t)h.n_slot_r * vb, which * 4 + 0});
+        }
+    }
+    void pass(int which) {
+        const int set = which - 1;
+        const bool serial = !overlap || (cfg.mdbc == SPHMI_MDBC_SIMPLE && which == 1);
+        std::vector<Msg> msgs;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            if (moving) e.dd_progress_motion();                          // :765 / :787 — owned and ghost copies move alike, then the pack
+            Halo& h = r.halo[set];
+            const int n = h.n_send_l + h.n_send_r;
+            wait_consumed(r, set * 4 + 0); wait_consumed(r, set * 4 + 1);
+            if (n) {
+                const int s_ = set == 0 ? e.iA : e.iH;
+                hipLaunchKernelGGL(k_halo_pack2<T>, dim3((n + 255) / 256), dim3(256), 0, r.main, e.pk0[s_], e.pk1[s_],
+                                   (const int*)h.send_l.p, h.n_send_l, (V4*)h.sb_l.p, (const int*)h.send_r.p, h.n_send_r, (V4*)h.sb_r.p);
+                HC(hipGetLastError());
+            }
+            HC(hipEventRecord(r.ev_pack, r.main));
+            if (!serial) {
+                HC(hipStreamWaitEvent(r.side, r.ev_pack, 0));            // everything queued so far: the previous pass, the pack
+                e.dd_pass(which, 0.0, 1);                                // interior tiles: need owned data only
+            }
+        }
+        halo_msgs(set, msgs);
+        exchange(pair_up(msgs), !serial);
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            Halo& h = r.halo[set];
+            const int n = h.n_slot_l + h.n_slot_r;
+            hipStream_t q = serial ? r.main : r.side;
+            e.stream = q;
+            try {
+                if (n) {
+                    const int s_ = set == 0 ? e.iA : e.iH;
+                    hipLaunchKernelGGL(k_halo_unpack2<T>, dim3((n + 255) / 256), dim3(256), 0, q, e.pk0[s_], e.pk1[s_],
+                                       (const int*)h.slot_l.p, h.n_slot_l, (const V4*)h.rb_l.p, (const int*)h.slot_r.p, h.n_slot_r, (const V4*)h.rb_r.p);
+                    HC(hipGetLastError());
+                }
+                if (serial) {
+                    // mDBC (:772) reads the fluid of state A in the ghost layers and rewrites the boundary densities that
+                    // every tile of pass 1 may read: halo → mDBC → the whole pass, nothing to overlap
+                    if (cfg.mdbc == SPHMI_MDBC_SIMPLE && which == 1) e.dd_mdbc();
+                    e.dd_pass(which, 0.0, 0);
+                } else {
+                    e.dd_pass(which, 0.0, 2);                            // slab-edge tiles, as soon as the halo has landed
+                    HC(hipEventRecord(r.ev_edge, r.side));
+                    HC(hipStreamWaitEvent(r.main, r.ev_edge, 0));         // the next pack / the reductions need the edge tiles
+                }
+            } catch (...) { e.stream = r.main; throw; }
+            e.stream = r.main;
+        }
+    }
+
+    // local maxima → global maxima → decisions, without leaving the device
+    void reductions_and_control() {
+        const int p = parity; parity ^= 1;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            r.e->serve_reschedules();
+            hipLaunchKernelGGL(k_dd_take, dim3(1), dim3(64), 0, r.main, r.e->red_d, r.T2 + 4 * p);
+            HC(hipGetLastError());
+            if (!use_rccl) HC(hipEventRecord(r.ev_red, r.main));
+        }
+        if (use_rccl) {
+            Rccl& N = Rccl::get();
+            NC(N.GroupStart());
+            for (auto& r : R) { HC(hipSetDevice(r.device)); NC(N.AllReduce(r.T2 + 4 * p, r.T2 + 4 * p, 4, ncclUint64, ncclMax, r.comm, r.main)); }
+            NC(N.GroupEnd());
+        }
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            RedPtrs P{}; P.n = 0;
+            P.p[P.n++] = r.T2 + 4 * p;
+            if (!use_rccl) {
+                // Double-buffered by step parity: rank q overwrites T2[p] again two steps from now, after its own merge of
+                // the NEXT step — which waited for every rank's take of that step, queued behind that rank's merge of this one.
+                for (auto& o : R) {
+                    if (&o == &r) continue;
+                    HC(hipStreamWaitEvent(r.main, o.ev_red, 0));
+                    if (o.device == r.device) P.p[P.n++] = o.T2 + 4 * p;
+                    else {
+                        HC(hipMemcpyAsync(r.stage + 4 * o.rank, o.T2 + 4 * p, 32, hipMemcpyDeviceToDevice, r.main));
+                        P.p[P.n++] = r.stage + 4 * o.rank;
+                    }
+                }
+            }
+            hipLaunchKernelGGL(k_dd_merge_max, dim3(1), dim3(64), 0, r.main, r.M, P);
+            HC(hipGetLastError());
+            r.e->dd_step_control(r.M);
+        }
+    }
+
+    // ---- the SimulationLoop of src/SPHCellList.jl:727-805, over all slabs --------------------------------------------
+    void advance(double t_target, int64_t max_steps, sphmi_progress* out) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_advance before sphmi_upload");
+        double dxl = 1.0 + cfg.h;                                        // :739
+        int64_t steps = 0;
+        for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->total_time = total_time; r.e->last_dt = last_dt; r.e->dd_ctrl_init(dxl, t_target, max_steps); }
+        bool first = true;
+        sphmi_dd_control st{};
+        try {
+            for (;;) {
+                // A step that asks for a rebuild cancels the rest of its batch, and a cancelled step still pays its allreduce
+                // and its messages: queue up to the step EXPECTED to ask (Δx grows by 4·max|Δx| a step, slowly changing).
+                int batch = kBatch;
+                if (dx_rate > 0.0) batch = std::max(1, std::min(batch, (int)((cfg.h - dxl) / dx_rate) + 1));
+                if (max_steps >= 0) batch = (int)std::max<int64_t>(1, std::min<int64_t>(batch, max_steps - steps));
+                if (first) { batch = 1; first = false; }                 // Δx re-armed: the first control of a call always asks
+                const double dx0 = dxl; const int64_t steps0 = steps;
+                for (int k = 0; k < batch; ++k) {
+                    reductions_and_control();
+                    if (have_halo) { pass(1); pass(2); }                 // before the first rebuild there is no ghost layer to exchange
+                }
+                for (auto& r : R) { HC(hipSetDevice(r.device)); sphmi_dd_control s{}; r.e->dd_ctrl_sync(&s); if (&r == &R[0]) st = s; }
+                steps = st.steps_done;
+                total_time = st.total_time; last_dt = st.last_dt; dxl = st.delta_x;
+                const int64_t grown = (steps - steps0) + (st.need_rebuild ? 1 : 0);
+                if (grown > 0 && dx0 < cfg.h && st.delta_x > dx0) dx_rate = (st.delta_x - dx0) / (double)grown;
+                if (st.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced on some slab");
+                if (st.error) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive or NaN dt");
+                if (st.need_rebuild) {
+                    rebuild_collective();
+                    dxl = 0.0;
+                    for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->dd_ctrl_resume(); }
+                    continue;
+                }
+                if (st.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) break;
+            }
+        } catch (...) { iteration += steps; delta_x = dxl; fill(out, steps); throw; }
+        iteration += steps; delta_x = dxl;
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
+        index_counter = 1;                                               // SimMetaData.IndexCounter = 1 + occupied cells (:145-157)
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            if (!e.have_grid) continue;
+            HC(hipMemsetAsync(r.mm_d, 0, 4, r.main));
+            hipLaunchKernelGGL(k_dd_count_owned_cells, dim3((e.N + 255) / 256), dim3(256), 0, r.main, (const int*)e.key[e.cur], (const uint8_t*)e.type[e.cur], e.N, e.grid.ncell, r.mm_d);
+            HC(hipMemcpyAsync(r.mm_h, r.mm_d, 4, hipMemcpyDeviceToHost, r.main));
+            HC(hipStreamSynchronize(r.main));
+            index_counter += r.mm_h[0];
+        }
+        if (rank_mode) { std::vector<long long> v{index_counter - 1}; host_allreduce(v, 1, OP_SUM); index_counter = v[0] + 1; }
+        fill(out, steps);
+    }
+    void fill(sphmi_progress* out, int64_t steps) {
+        if (!out) return;
+        out->iteration = iteration; out->steps_done = steps; out->n_rebuilds = n_rebuilds; out->index_counter = index_counter;
+        out->total_time = total_time; out->last_dt = last_dt; out->delta_x = delta_x;
+    }
+
+    // ---- download: owned particles of every local slab, merged into the order of the UNSPLIT sort -------------------
+    int64_t owned_count_impl() {
+        int64_t n = 0;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            HC(hipStreamSynchronize(r.main));
+            std::vector<uint8_t> ty((size_t)e.N);
+            HC(hipMemcpy(ty.data(), e.type[e.cur], (size_t)e.N, hipMemcpyDeviceToHost));
+            for (auto t : ty) n += (t != 0 && !(t & kGhostMask)) ? 1 : 0;
+        }
+        return n;
+    }
+    void download(void* position, void* velocity, void* acceleration, void* density, void* pressure, int64_t* ids,
+                  uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
+        const size_t hb = (size_t)cfg.host_float_bytes, C = (size_t)out_comp;
+        struct Part { std::vector<char> pos, vel, acc, rho, prs, gho; std::vector<int64_t> id, cel; std::vector<uint8_t> ty; std::vector<uint64_t> grp, tag; size_t n; };
+        std::vector<Part> parts(R.size());
+        for (size_t q = 0; q < R.size(); ++q) {
+            Rank& r = R[q]; Part& P = parts[q];
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            const size_t n = (size_t)e.N; P.n = n;
+            e.set_output_components(out_comp);
+            if (position) P.pos.resize(n * C * hb); if (velocity) P.vel.resize(n * C * hb); if (acceleration) P.acc.resize(n * C * hb);
+            if (density) P.rho.resize(n * hb); if (pressure) P.prs.resize(n * hb); if (ghost_points) P.gho.resize(n * C * hb);
+            if (ids) P.id.resize(n); if (cells) P.cel.resize(n * (size_t)D); if (groups) P.grp.resize(n);
+            P.ty.resize(n); P.tag.resize(n);
+            e.download(position ? P.pos.data() : nullptr, velocity ? P.vel.data() : nullptr, acceleration ? P.acc.data() : nullptr,
+                       density ? P.rho.data() : nullptr, pressure ? P.prs.data() : nullptr, ids ? P.id.data() : nullptr, P.ty.data(),
+                       groups ? P.grp.data() : nullptr, ghost_points ? P.gho.data() : nullptr, cells ? P.cel.data() : nullptr);
+            HC(hipMemcpy(P.tag.data(), e.otag[e.cur], n * 8, hipMemcpyDeviceToHost));
+        }
+        // k-way merge by order tag = (cell z, y, x, rank in cell) of the last sort: the order one engine would hold
+        std::vector<size_t> at(R.size(), 0);
+        auto skip = [&](size_t q) { Part& P = parts[q]; while (at[q] < P.n && (P.ty[at[q]] == 0 || (P.ty[at[q]] & kGhostMask))) ++at[q]; };
+        for (size_t q = 0; q < R.size(); ++q) skip(q);
+        size_t o = 0;
+        const size_t cap = (size_t)cfg.n_particles;
+        for (;;) {
+            int best = -1;
+            for (size_t q = 0; q < R.size(); ++q) if (at[q] < parts[q].n && (best < 0 || parts[q].tag[at[q]] < parts[best].tag[at[best]])) best = (int)q;
+            if (best < 0) break;
+            if (o >= cap) throw EngineError(SPHMI_ERR_STATE, "sphmi_download: more owned particles than the handle was created for");
+            Part& P = parts[best]; const size_t i = at[best];
+            auto put = [&](void* dst, std::vector<char>& src, size_t elem) { if (dst) memcpy((char*)dst + o * elem, &src[i * elem], elem); };
+            put(position, P.pos, C * hb); put(velocity, P.vel, C * hb); put(acceleration, P.acc, C * hb);
+            put(density, P.rho, hb); put(pressure, P.prs, hb); put(ghost_points, P.gho, C * hb);
+            if (ids) ids[o] = P.id[i];
+            if (ty) ty[o] = P.ty[i] & kTypeMask;
+            if (groups) groups[o] = P.grp[i];
+            if (cells) for (int d = 0; d < D; ++d) cells[o * D + d] = P.cel[i * D + d];
+            ++o; ++at[best]; skip(best);
+        }
+        n_downloaded = (int64_t)o;
+    }
+    int64_t n_downloaded = 0;
+    int out_comp = 0;
+    void download_begin(void* a, void* b, void* c, void* d, void* e, int64_t* f, uint8_t* g, uint64_t* h, void* i, int64_t* j) override { download(a, b, c, d, e, f, g, h, i, j); }
+    void download_end() override {}
+    void set_output_components(int c) override {
+        if (c != D && c != 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_output_components: dims or 3");
+        out_comp = c;
+    }
+    void host_register(void*, size_t) override {}
+    void host_unregister(void*) override {}
+    void forces_once(int, void*, void*) override { throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once: single-device handles only (parity hook)"); }
+    void download_kernel_output(void*, void*) override { throw EngineError(SPHMI_ERR_STATE, "sphmi_download_kernel_output: single-device handles only"); }
+    void unique_cells(int64_t* out, int64_t cap, int64_t* n_out) override {
+        // occupied cells of the owned particles in sort order, from the merged Cells column
+        const size_t N = (size_t)cfg.n_particles;
+        std::vector<int64_t> cel(N * (size_t)D);
+        download(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cel.data());
+        int64_t n = 0;
+        for (int64_t i = 0; i < n_downloaded; ++i) {
+            bool fresh = i == 0;
+            for (int d = 0; d < D && !fresh; ++d) fresh = cel[(size_t)i * D + d] != cel[(size_t)(i - 1) * D + d];
+            if (!fresh) continue;
+            if (out) { if (n >= cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_unique_cells: capacity too small"); for (int d = 0; d < D; ++d) out[n * D + d] = cel[(size_t)i * D + d]; }
+            ++n;
+        }
+        if (n_out) *n_out = n;
+    }
+    void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
+        R[0].e->timers(cap, names, secs, calls, n);
+    }
+    void force_stats(int reset, double* avg_ms, int64_t* launches) override {
+        double ms = 0; int64_t ln = 0;
+        for (auto& r : R) { double a = 0; int64_t l = 0; r.e->force_stats(reset, &a, &l); ms += a * (double)l; ln += l; }
+        if (avg_ms) *avg_ms = ln ? ms / (double)ln : 0.0;
+        if (launches) *launches = ln;
+    }
+    void device_ptrs(void** p0, void** p1, int64_t* n) override { R[0].e->device_ptrs(p0, p1, n); }
+    void reset_count() override {}
+    int64_t owned_count() override { return owned_count_impl(); }
+    void multi_info(sphmi_multi_info* o) {
+        memset(o, 0, sizeof *o);
+        o->world = world; o->n_local = (int32_t)R.size(); o->axis = axis; o->halo_width = halo_width; o->n_recuts = n_recuts;
+        o->transport = use_rccl ? 1 : 0;
+        for (int r = 1; r < world && r < 16; ++r) o->cuts[r - 1] = plan.world() == world ? plan.lo[r] : 0;
+        for (auto& r : R) if (r.e && r.rank < 16) o->n_live[r.rank] = r.e->N;
+    }
+};
+
+}  // namespace sphmi

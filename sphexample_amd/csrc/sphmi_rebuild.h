@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_tile_class(const int* key, const uint8_
     bool owned = false, edge = false;
     if (i < N) {
         const int k = key[i];
-        owned = (type[i] & kGhostMask) == 0;
+        owned = type[i] != 0 && (type[i] & kGhostMask) == 0;
         const int col = axis == 0 ? k % nxp : (axis == 1 ? (k / nxp) % nyp : k / (nxp * nyp));
         edge = owned && (col == col_lo_pad || col == col_hi_pad);
     }
@@ -218,16 +218,20 @@ __global__ void __launch_bounds__(256) k_tile_class(const int* key, const uint8_
 
 // cost of a tile in its own list, 0 in the other
 __global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cstart, const uint8_t* cls, int N, int ntile,
-                                                   int nxp, int nxyp, int D, int* cost0, int* cost1) {
+                                                   int nxp, int nxyp, int D, int ncell, int* cost0, int* cost1) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntile) return;
-    const int kf = key[t * 64], kl = key[min(t * 64 + 63, N - 1)];
+    const int kf = key[t * 64], kl0 = key[min(t * 64 + 63, N - 1)];
     const int nseg = D == 3 ? 9 : 3;
     int c = 64;
-    for (int seg = 0; seg < nseg; ++seg) {
+    // dead particles (first sort of a slab rebuild) carry the graveyard key ncell: clamp to the last real cell, and a
+    // tile that starts in the graveyard costs nothing (cstart has ncell + 2 entries)
+    const int kl = min(kl0, ncell - 1);
+    for (int seg = 0; seg < nseg && kf < ncell; ++seg) {
         const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
-        c += cstart[kl + off + 2] - cstart[kf + off - 1];
+        c += cstart[min(kl + off + 2, ncell)] - cstart[max(kf + off - 1, 0)];
     }
+    if (kf >= ncell) c = 0;
     const int k = cls ? cls[t] : 0;
     cost0[t] = k == 0 ? c : 0;
     cost1[t] = k == 1 ? c : 0;
@@ -693,10 +697,13 @@ __global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::typ
     }
 }
 
-// the four reduction slots → a caller-owned buffer, slots reset (one launch instead of a copy and a fill)
+// the four reduction slots → a caller-owned buffer, slots reset (one launch instead of a copy and a fill).
+// MAX-merged into what the buffer holds: k_step_control zeroes the buffer when a step consumes it, so whatever is
+// still there belongs to a control that returned early (loop bound reached, rebuild pending) and must survive until
+// the next executed step — the first step of the next output interval would otherwise run with Δt from empty maxima.
 __global__ void k_take_reductions(unsigned long long* red, unsigned long long* out) {
     const int i = threadIdx.x;
-    if (i < 4) { out[i] = red[i]; red[i] = 0; }
+    if (i < 4) { const unsigned long long a = out[i], b = red[i]; out[i] = a > b ? a : b; red[i] = 0; }
 }
 
 // ProgressMotion, src/SPHCellList.jl:575-596: particles of Type Moving whose GroupMarker has a MotionDetails get

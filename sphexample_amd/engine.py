@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from . import build as _build
-from ._abi import Backend, SphmiConfig, SphmiError, make_config
+from ._abi import MAX_DEVICES, OK, Backend, SphmiConfig, SphmiError, make_config
 
 _lib = None
 
@@ -43,11 +43,59 @@ def backend_info() -> str:
     return load_library().sphmi_backend_info().decode()
 
 
-class Engine(Backend):
-    """One simulation on one GPU behind the C ABI (`include/sphmi.h`)."""
+class SphmiMultiInfo(C.Structure):
+    _fields_ = [("world", C.c_int32), ("n_local", C.c_int32), ("axis", C.c_int32), ("halo_width", C.c_int32),
+                ("transport", C.c_int32), ("reserved", C.c_int32), ("n_recuts", C.c_int64),
+                ("cuts", C.c_int64 * MAX_DEVICES), ("n_live", C.c_int64 * MAX_DEVICES)]
 
-    def __init__(self, cfg: SphmiConfig):
-        super().__init__(load_library(), "sphmi_", cfg)
+
+def rccl_unique_id() -> bytes:
+    """128 bytes for sphmi_create_rank: made on rank 0, handed to the other ranks by the launcher."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().sphmi_rccl_unique_id(buf)
+    if rc != OK:
+        raise SphmiError(rc, (load_library().sphmi_last_error(None) or b"").decode())
+    return buf.raw
+
+
+class Engine(Backend):
+    """One simulation behind the C ABI (`include/sphmi.h`): on one GPU, on the GPUs of `cfg.devices` (slabs of the
+    domain, all driven by this process), or — `rank=` — one slab of a run whose other slabs live in other processes."""
+
+    def __init__(self, cfg: SphmiConfig, rank: int = None, world: int = None, unique_id: bytes = None):
+        lib = load_library()
+        if rank is None:
+            super().__init__(lib, "sphmi_", cfg)
+        else:
+            lib.sphmi_create_rank.argtypes = [C.POINTER(SphmiConfig), C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]
+            create = lambda c, h: lib.sphmi_create_rank(c, rank, world, unique_id, h)  # noqa: E731
+            super().__init__(lib, "sphmi_", cfg, create=create)
+        self.rank_mode = rank is not None
+
+    def multi_info(self) -> SphmiMultiInfo:
+        info = SphmiMultiInfo()
+        self._lib.sphmi_multi_info_get.argtypes = [C.c_void_p, C.POINTER(SphmiMultiInfo)]
+        self._check(self._lib.sphmi_multi_info_get(self._h, C.byref(info)))
+        return info
+
+    def owned_count(self) -> int:
+        n = C.c_int64()
+        self._lib.sphmi_owned_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self._check(self._lib.sphmi_owned_count(self._h, C.byref(n)))
+        return n.value
+
+    def set_cuts(self, cuts) -> None:
+        """Test hook: initial slab cuts (first cell column of slabs 1 … world-1) instead of the balanced ones."""
+        a = np.ascontiguousarray(cuts, dtype=np.int64)
+        self._lib.sphmi_multi_set_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        self._check(self._lib.sphmi_multi_set_cuts(self._h, a.ctypes.data_as(C.c_void_p), len(a)))
+
+    def download(self, *args, **kw) -> dict:
+        out = super().download(*args, **kw)
+        if self.rank_mode:                 # this process's slab: the first owned_count rows
+            n = self.owned_count()
+            out = {k: v[:n] for k, v in out.items()}
+        return out
 
     def timers(self) -> dict:
         names = (C.c_char_p * 16)()
@@ -64,15 +112,30 @@ class Engine(Backend):
         return ms.value, n.value
 
 
-def make_engine(particles, setup, device_float_bytes: int = 4, device: int = 0) -> Engine:
-    """Engine for a SimParticles + CaseSetup pair, with the particles uploaded."""
+def make_engine(particles, setup, device_float_bytes: int = 4, device: int = 0, devices=None, slab_axis: int = None,
+                cuts=None, rank: int = None, world: int = None, unique_id: bytes = None) -> Engine:
+    """Engine for a SimParticles + CaseSetup pair, with the particles uploaded.
+    devices=[0, 1, …]: one slab per listed GPU, all inside this handle (an ordinal may repeat: slabs sharing a GPU).
+    rank= / world= / unique_id=: this process holds slab `rank` on GPU `device`; every process uploads the full set."""
     host_bytes = np.dtype(particles.FloatType).itemsize
     cfg = make_config(len(particles), setup.SimConstants, setup.SimKernel, setup.SimMetaData,
                       setup.SimViscosity, setup.SimDensityDiffusion,
                       device_float_bytes=device_float_bytes, host_float_bytes=host_bytes, device=device)
-    e = Engine(cfg)
+    if devices is not None:
+        if len(devices) > MAX_DEVICES:
+            raise ValueError(f"at most {MAX_DEVICES} devices per handle")
+        cfg.n_devices = len(devices)
+        for k, d in enumerate(devices):
+            cfg.devices[k] = int(d)
+    if slab_axis is not None:
+        cfg.slab_axis = int(slab_axis) + 1
+    e = Engine(cfg, rank=rank, world=world, unique_id=unique_id)
+    if cuts is not None:
+        e.set_cuts(cuts)
+    if getattr(particles, "geometries", None) is not None:
+        e.set_motions(particles.geometries)
     e.upload_particles(particles)
     return e
 
 
-__all__ = ["Engine", "make_engine", "load_library", "backend_info", "SphmiError"]
+__all__ = ["Engine", "make_engine", "load_library", "backend_info", "rccl_unique_id", "SphmiError", "SphmiMultiInfo"]

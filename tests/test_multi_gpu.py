@@ -1,0 +1,209 @@
+"""The slab driver inside libsphmi.so (csrc/sphmi_multi.h) behind the ordinary sphmi_create / sphmi_advance.
+
+CPU part: the host-side planner (axis, cuts by work, halo width, capacities) through sphmi_plan_slabs — no device needed.
+GPU part: a handle created with a device list — here the list repeats GPU 0, so the slabs share the one GPU of the test
+box and their messages are stream-ordered device copies; the step sequence, the migration, the ghost layers, the order
+tags, the re-cut and the device-side step control are the ones an 8-GPU run uses — must reproduce the single-device
+handle: same dt sequence, same rebuild cadence, density / position to summation order (the tiles differ).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sphexample_amd._abi import make_config
+from sphexample_amd.distributed import SlabPlan, cell_x_of, choose_axis, particle_work
+
+
+def _plan(p, s, world, fb=8, axis=None):
+    from sphexample_amd.engine import load_library
+    lib = load_library(rebuild_if_stale=False)
+    cfg = make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, s.SimViscosity, s.SimDensityDiffusion,
+                      device_float_bytes=fb, host_float_bytes=8)
+    if axis is not None:
+        cfg.slab_axis = axis + 1
+    ax, hw = C.c_int32(), C.c_int32()
+    cuts = (C.c_int64 * 16)(); owned = (C.c_int64 * 16)(); cap = (C.c_int64 * 16)()
+    pos = np.ascontiguousarray(p.Position, dtype=np.float64)
+    gp = np.ascontiguousarray(p.GhostPoints, dtype=np.float64) if cfg.mdbc else None
+    lib.sphmi_plan_slabs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5
+    rc = lib.sphmi_plan_slabs(C.byref(cfg), pos.ctypes.data_as(C.c_void_p), None if gp is None else gp.ctypes.data_as(C.c_void_p),
+                              len(p), world, C.byref(ax), C.byref(hw), cuts, owned, cap)
+    assert rc == 0, rc
+    return ax.value, hw.value, list(cuts)[:world - 1], list(owned)[:world], list(cap)[:world]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_planner_matches_the_python_reference_plan(dam_break_3d_shipped, world):
+    """sphmi_plan_slabs = distributed.py's choose_axis + SlabPlan.from_columns (work-balanced exact cuts)."""
+    p, s = dam_break_3d_shipped
+    cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(3)]
+    w = particle_work(cols)
+    ax, hw, cuts, owned, cap = _plan(p, s, world)
+    assert hw == 1
+    assert ax == choose_axis(cols, world, 2, w)
+    ref = SlabPlan.from_columns(cols[ax], world, 2, w)
+    assert cuts == ref.cuts()
+    assert owned == list(np.bincount(ref.owner_of(cols[ax]), minlength=world))
+    assert sum(owned) == len(p) and all(c > o for c, o in zip(cap, owned))
+    for a in range(3):
+        ax2, _, cuts2, _, _ = _plan(p, s, 2, axis=a)
+        assert ax2 == a and cuts2 == SlabPlan.from_columns(cols[a], 2, 2, w).cuts()
+
+
+def test_planner_mdbc_halo_width(dam_break_2d_mdbc, still_wedge):
+    """Ghost nodes sit up to `off` columns from their boundary particle: ghost layers 2 + off columns wide, slabs never
+    narrower than that."""
+    p, s = dam_break_2d_mdbc
+    ax, hw, cuts, owned, cap = _plan(p, s, 2)
+    assert hw == 5 and sum(owned) == len(p)
+    ax, hw, cuts, owned, cap = _plan(*still_wedge, 2)
+    assert hw >= 3
+
+
+def test_planner_rejects_too_many_slabs(dam_break_2d):
+    from sphexample_amd.engine import load_library
+    p, s = dam_break_2d
+    lib = load_library(rebuild_if_stale=False)
+    cfg = make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, s.SimViscosity, s.SimDensityDiffusion)
+    pos = np.ascontiguousarray(p.Position, dtype=np.float64)
+    lib.sphmi_plan_slabs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5
+    cfg.slab_axis = 2                                     # y: 39 cell columns host 16 slabs of ≥ 2 columns …
+    assert lib.sphmi_plan_slabs(C.byref(cfg), pos.ctypes.data_as(C.c_void_p), None, len(p), 16, None, None, None, None, None) == 0
+    cfg.k, cfg.H_inv = 4.0, cfg.H_inv / 2                 # … but not with cells twice as wide (20 columns)
+    assert lib.sphmi_plan_slabs(C.byref(cfg), pos.ctypes.data_as(C.c_void_p), None, len(p), 16, None, None, None, None, None) != 0
+    assert lib.sphmi_plan_slabs(C.byref(cfg), pos.ctypes.data_as(C.c_void_p), None, len(p), 17, None, None, None, None, None) != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _by_id(st):
+    o = np.argsort(st["ID"], kind="stable")
+    return {k: v[o] for k, v in st.items()}
+
+
+def _compare(case, steps, fb, tol, axis, world, request, calls=1, cuts_shift=0, env=None, monkeypatch=None):
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    if env:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+    ref = make_engine(p, s, device_float_bytes=fb)
+    cuts = None
+    if cuts_shift:
+        cx = cell_x_of(p.Position[:, axis], s.SimKernel.H_inv)
+        cuts = [c + cuts_shift for c in SlabPlan.from_columns(cx, world).cuts()]
+    dd = make_engine(p, s, device_float_bytes=fb, devices=[0] * world, slab_axis=axis, cuts=cuts)
+    for _ in range(calls):
+        pr = ref.advance(1e9, max_steps=steps // calls)
+        pd = dd.advance(1e9, max_steps=steps // calls)
+        assert (pd.iteration, pd.steps_done, pd.n_rebuilds) == (pr.iteration, pr.steps_done, pr.n_rebuilds)
+        assert pd.total_time == pytest.approx(pr.total_time, rel=1e-12 if fb == 8 else 1e-6)
+        assert pd.last_dt == pytest.approx(pr.last_dt, rel=1e-12 if fb == 8 else 1e-5)
+        assert pd.index_counter == pr.index_counter
+    info = dd.multi_info()
+    assert info.world == world and info.n_local == world and info.transport == 0
+    assert axis is None or info.axis == axis
+    from sphexample_amd.config import SimpleMDBC
+    assert (info.halo_width >= 3) if s.SimMetaData.BMode is SimpleMDBC else (info.halo_width == 1)
+    r = ref.download(("Position", "Density", "ID", "Velocity", "Cells"))
+    d = dd.download(("Position", "Density", "ID", "Velocity", "Cells"))
+    assert dd.owned_count() == len(p)
+    # the merged download is in the order ONE engine holds: cell-sorted, in-cell order by history (order tags)
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    np.testing.assert_array_equal(d["Cells"], r["Cells"])
+    assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < tol
+    assert np.abs(d["Position"] - r["Position"]).max() / np.abs(r["Position"]).max() < tol
+    np.testing.assert_array_equal(dd.unique_cells(), ref.unique_cells())
+    return info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,steps,fb,tol,axis", [
+    ("dam_break_3d_shipped", 30, 8, 1e-9, None), ("dam_break_3d_shipped", 30, 4, 1e-5, None),
+    ("dam_break_3d_shipped", 30, 8, 1e-9, 0), ("dam_break_3d_shipped", 30, 8, 1e-9, 1), ("dam_break_3d_shipped", 30, 8, 1e-9, 2),
+    ("dam_break_2d", 60, 8, 1e-9, None), ("dam_break_2d", 60, 8, 1e-9, 0), ("dam_break_2d", 60, 8, 1e-9, 1),
+    ("dam_break_2d_variants", 40, 8, 1e-9, None),
+    # a Moving body crossing nothing / the cut; 150 steps along y: fluid pushed by the body crosses the cut particle by
+    # particle, and a migrant must take the in-cell place its previous GLOBAL sorted index gives it (order tags)
+    ("moving_square", 40, 8, 1e-9, 0), ("moving_square", 150, 8, 1e-9, 1),
+    # mDBC: ghost layers 2 + off columns wide, ghost copies corrected locally
+    ("dam_break_2d_mdbc", 40, 8, 1e-9, None), ("dam_break_2d_mdbc", 40, 8, 1e-9, 0), ("dam_break_2d_mdbc", 40, 8, 1e-9, 1),
+    ("dam_break_2d_mdbc", 40, 4, 2e-5, None), ("still_wedge", 40, 8, 1e-9, None), ("duckling", 12, 8, 1e-9, None)])
+def test_two_slabs_in_one_handle_match_one_device(case, steps, fb, tol, axis, request):
+    _compare(case, steps, fb, tol, axis, 2, request)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [3, 4, 8])
+def test_more_slabs_in_one_handle(world, request):
+    """Middle slabs have two neighbours (two ghost layers, two messages per pass, migration both ways)."""
+    _compare("dam_break_3d_shipped", 40, 8, 1e-9, None, world, request)
+
+
+@pytest.mark.gpu
+def test_serial_halo_path(request, monkeypatch):
+    """SPHMI_DD_OVERLAP=0: halo → whole pass on one stream (the path mDBC's pass 1 always takes)."""
+    _compare("dam_break_3d_shipped", 30, 8, 1e-9, 1, 2, request, env={"SPHMI_DD_OVERLAP": "0"}, monkeypatch=monkeypatch)
+
+
+@pytest.mark.gpu
+def test_cuts_move_with_the_work(request):
+    """Start four columns off balance: the first rebuilds move the cuts back (particles migrate, ghost layers and halo
+    lists are rebuilt) and the result is still the one-device one."""
+    info = _compare("dam_break_3d_shipped", 80, 8, 1e-9, 0, 2, request, calls=2, cuts_shift=4)
+    assert info.n_recuts >= 1
+
+
+@pytest.mark.gpu
+def test_cuts_move_with_the_work_mdbc(request, monkeypatch):
+    info = _compare("dam_break_2d_mdbc", 80, 8, 1e-9, 0, 2, request, calls=2, cuts_shift=3, env={"SPHMI_DD_RECUT": "1.02"}, monkeypatch=monkeypatch)
+    assert info.n_recuts >= 1 and info.halo_width == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["dam_break_2d", "dam_break_3d_shipped"])
+def test_output_intervals_keep_the_reductions(case, request):
+    """Several SimulationLoop calls (advance to a TIME, as the reference's driver does): the control that ends an
+    interval returns before it has used the maxima of the last corrector — they must still be there for the first Δt
+    of the next interval, or the multi-device run takes a different first step than the one-device handle."""
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    ref = make_engine(p, s, device_float_bytes=8)
+    dd = make_engine(p, s, device_float_bytes=8, devices=[0, 0])
+    dt0 = 0.2 * s.SimKernel.h / s.SimConstants.c0
+    for k in range(1, 5):
+        pr, pd = ref.advance(7.3 * k * dt0), dd.advance(7.3 * k * dt0)
+        assert (pd.iteration, pd.steps_done, pd.n_rebuilds) == (pr.iteration, pr.steps_done, pr.n_rebuilds)
+        assert pd.last_dt == pytest.approx(pr.last_dt, rel=1e-12)
+        assert pd.total_time == pytest.approx(pr.total_time, rel=1e-12)
+    r, d = _by_id(ref.download(("ID", "Density"))), _by_id(dd.download(("ID", "Density")))
+    assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_rccl_binds_and_a_one_rank_world_runs(dam_break_3d_shipped):
+    """sphmi_create_rank with world = 1: RCCL is bound (librccl.so.1 resolved, unique id made), the slab driver runs its
+    full step sequence with no peers, and the slab's download is the whole particle set.  (More than one RCCL rank
+    needs more than one GPU: the 8-GPU run is the driver's.)"""
+    from sphexample_amd.engine import make_engine, rccl_unique_id
+    p, s = dam_break_3d_shipped
+    uid = rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ref = make_engine(p, s, device_float_bytes=8)
+    dd = make_engine(p, s, device_float_bytes=8, rank=0, world=1, unique_id=uid)
+    pr, pd = ref.advance(1e9, max_steps=20), dd.advance(1e9, max_steps=20)
+    assert (pd.iteration, pd.n_rebuilds, pd.total_time) == (pr.iteration, pr.n_rebuilds, pr.total_time)
+    r, d = ref.download(("ID", "Density")), dd.download(("ID", "Density"))
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_multi_handle_rejects_the_single_device_hooks(dam_break_2d):
+    from sphexample_amd._abi import ERR_STATE, SphmiError
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d
+    dd = make_engine(p, s, device_float_bytes=8, devices=[0, 0])
+    with pytest.raises(SphmiError) as ei:
+        dd.forces_once()
+    assert ei.value.status == ERR_STATE
