@@ -173,6 +173,7 @@ struct Engine final : EngineBase {
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) force_wpt = v; }
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
+        if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
         if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
         HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
@@ -239,7 +240,7 @@ struct Engine final : EngineBase {
         (void)hipFree(ctrl_d); (void)hipHostFree(ctrl_h);
         (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
-        (void)hipFree(cellx_d);
+        (void)hipFree(cellx_d); (void)hipFree(uc_tsum);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 
@@ -295,6 +296,7 @@ struct Engine final : EngineBase {
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
         P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
+        P.Cfac = (T)(-8.0 * (cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h))); P.nhinv_half = (T)(-0.5 * cfg.h_inv); P.big = (T)1099511627776.0;
         P.m0 = (T)cfg.m0;
         P.Kddt = (T)(cfg.delta_phi * cfg.h * cfg.c0 * cfg.m0);
         P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
@@ -321,7 +323,20 @@ struct Engine final : EngineBase {
         return P;
     }
 
+    // tiles per block of the one-wave-per-tile launches (3-D fp32 compiled-in model; $SPHMI_TPB = 1, 2 or 4 overrides).  Measured at
+    // 1.06 M particles (kernel ms per launch): 1 → 0.5601, 2 → 0.5591, 4 → 0.5558; it is what lets ONE tile segment per XCD
+    // (the L2-friendly schedule) run as fast as sixteen: 0.5562 against 0.5585 / 0.5558
+    int tpb = 4;
+    template <int PASS, int MODEL, int TPB> void launch_force_tpb(const ForceParams<T>& P, int list) {
+        dim3 g(8 * ((part_max[list] + TPB - 1) / TPB)), b(kWave * TPB);
+        hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, 1, TPB>), g, b, 0, stream, P);
+        HC(hipGetLastError());
+    }
     template <int PASS, int MODEL, int WPT> void launch_force_wpt(const ForceParams<T>& P, int list) {
+        if constexpr (WPT == 1 && MODEL == kModelDefault && sizeof(T) == 4) {
+            if (D == 3 && tpb == 4) { launch_force_tpb<PASS, MODEL, 4>(P, list); return; }
+            if (D == 3 && tpb == 2) { launch_force_tpb<PASS, MODEL, 2>(P, list); return; }
+        }
         dim3 g(8 * part_max[list]), b(kWave * WPT);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, WPT>), g, b, 0, stream, P);
         else        hipLaunchKernelGGL((k_neighbor_force<T, 2, PASS, MODEL, WPT>), g, b, 0, stream, P);
@@ -497,9 +512,10 @@ struct Engine final : EngineBase {
                 hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, tile_cost[l], tile_scan, ntile, tile_tsum, misc_d + 2);
                 hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
                 hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
-                // segments per XCD run (k_tile_order): measured best 1 / 16 / 32 / 64 at 2.5 k / 16.5 k / 44.6 k / 120 k tiles
-                // (+3.0 / +2.2 / +2.4 % for the three large cases); the short slab-edge list keeps one run per XCD
-                const int nseg = l == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1));
+                // segments per XCD run (k_tile_order): ONE — a contiguous stretch of the domain per XCD, whose source rows stay in
+                // that XCD's L2 (round 1 dealt 16 … 64 segments round-robin for a 2–3 % shorter launch tail at 2.85× the
+                // algorithmic traffic; with four neighbouring tiles per block the gain is gone: 0.5562 vs 0.5558 ms at 1.06 M)
+                const int nseg = l == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : 1);
                 XcdShares W{};
                 // (with the measured re-schedule the shares belong to IT: the estimate-based order lives for one step)
                 for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 && !resched ? xcd_w[x] : 0.125);
@@ -530,7 +546,7 @@ struct Engine final : EngineBase {
         hipLaunchKernelGGL(k_scan_tile, dim3(sb), dim3(kScanThreads), 0, stream, work, tile_scan, ntile, tile_tsum, misc_d + 2);
         hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum, sb, misc_d + 3);
         hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(kScanThreads), 0, stream, tile_scan, ntile, tile_tsum, misc_d + 3);
-        const int nseg = list == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : (ntile >= kWptMedium ? std::max(1, std::min(64, (int)std::lround(std::sqrt(ntile / 64.0)))) : 1));
+        const int nseg = list == 1 ? 1 : (xcd_segs > 0 ? xcd_segs : 1);
         XcdShares W{};
         for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(list == 0 ? xcd_w[x] : 0.125);
         W.cum[8] = 1.0f;
@@ -840,25 +856,39 @@ struct Engine final : EngineBase {
         if (drhodt) for (int i = 0; i < N; ++i) { if (h8) ((double*)drhodt)[i] = (double)tmp[i].w; else ((float*)drhodt)[i] = (float)tmp[i].w; }
     }
 
+    // UniqueCells[2:IndexCounter] (src/SPHCellList.jl:148-157) for the grid export of the output side: heads of the key
+    // runs, compacted on the device (tmp_idx / perm are scratch between rebuilds); the host receives the cell coordinates
     void unique_cells(int64_t* out, int64_t cap, int64_t* n_out) override {
         HC(hipSetDevice(cfg.device));
-        HC(hipStreamSynchronize(stream));
         if (!have_grid) { if (n_out) *n_out = 0; return; }
-        std::vector<int> k(N);
-        HC(hipMemcpy(k.data(), key[cur], (size_t)N * 4, hipMemcpyDeviceToHost));
-        std::vector<int> u;
-        for (int i = 0; i < N; ++i) if (i == 0 || k[i] != k[i - 1]) u.push_back(k[i]);
-        if (n_out) *n_out = (int64_t)u.size();
-        if (!out) return;
-        if (cap < (int64_t)u.size()) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_unique_cells: capacity too small");
-        for (size_t i = 0; i < u.size(); ++i) {
-            int kk = u[i];
-            int cx = kk % grid.np[0]; kk /= grid.np[0];
-            int cy = kk % grid.np[1]; int cz = kk / grid.np[1];
-            out[i * D] = (int64_t)cx - 1 + grid.gmin[0];
-            out[i * D + 1] = (int64_t)cy - 1 + grid.gmin[1];
-            if (D == 3) out[i * D + 2] = (int64_t)cz - 1 + grid.gmin[2];
-        }
+        const int nb256 = (N + 255) / 256;
+        int *flag = tmp_idx, *pos = perm;              // N ints each; pos needs N + 1: the total goes through misc_d
+        hipLaunchKernelGGL(k_cell_heads, dim3(nb256), dim3(256), 0, stream, (const int*)key[cur], N, grid.ncell, flag);
+        const int ntiles = (N + kScanTile - 1) / kScanTile;
+        HC(hipMemsetAsync(misc_d + 4, 0, 3 * 4, stream));
+        hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, (const int*)flag, pos, N, tile_tsum_u(ntiles), misc_d + 4);
+        hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tile_tsum_u(ntiles), ntiles, misc_d + 5);
+        hipLaunchKernelGGL(k_scan_add_nototal, dim3(ntiles), dim3(kScanThreads), 0, stream, pos, N, (const int*)tile_tsum_u(ntiles));
+        HC(hipGetLastError());
+        HC(hipMemcpyAsync(misc_h + 4, misc_d + 4, 2 * 4, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+        const int64_t nu = misc_h[5];
+        if (n_out) *n_out = nu;
+        if (!out || nu == 0) return;
+        if (cap < nu) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_unique_cells: capacity too small");
+        long long* od = nullptr;
+        HC(hipMalloc(&od, (size_t)nu * D * 8));
+        hipLaunchKernelGGL(k_cells_out, dim3(nb256), dim3(256), 0, stream, (const int*)key[cur], (const int*)flag, (const int*)pos, N, grid, D, od);
+        hipError_t e1 = hipGetLastError();
+        hipError_t e2 = hipMemcpyAsync(out, od, (size_t)nu * D * 8, hipMemcpyDeviceToHost, stream);
+        hipError_t e3 = hipStreamSynchronize(stream);
+        (void)hipFree(od);
+        HC(e1); HC(e2); HC(e3);
+    }
+    int* uc_tsum = nullptr; int uc_tsum_n = 0;
+    int* tile_tsum_u(int ntiles) {
+        if (ntiles + 2 > uc_tsum_n) { (void)hipFree(uc_tsum); uc_tsum = nullptr; uc_tsum_n = ntiles + 64; HC(hipMalloc(&uc_tsum, (size_t)uc_tsum_n * 4)); }
+        return uc_tsum;
     }
 
 

@@ -130,6 +130,7 @@ struct ForceParams {
     V4* kout;                // StoreKernelOutput: { Σ∇W, ΣW } of the corrector pass, or null
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
+    T nhinv_half, Cfac, big;   // −1/(2h);  −8·Cgw: ∇W factor = Cfac·u³ with u = clamp(1 − q/2);  2⁴⁰ (step01)
     T alphaD, tens_eps, inv_Wdx;   // CubicSpline: αD, CubicSpline.eps, 1 / W(q := dx) (src/SPHKernels.jl:114-126)
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
@@ -183,16 +184,42 @@ __device__ __forceinline__ float min_raw(float a, float b) {
 }
 __device__ __forceinline__ double min_raw(double a, double b) { return a < b ? a : b; }
 
+// u = clamp(a·b + 1, 0, 1) in ONE instruction (output modifier): with a = r, b = −1/(2h) this is 1 − q/2 clamped, and
+// (q − 2)³ of the Wendland gradient (src/SPHKernels.jl:85-86, q = clamp(r/h, 0, 2) of src/SPHCellList.jl:280) = −8u³
+__device__ __forceinline__ float fma1_clamp01(float a, float b) {
+#ifdef SPHMI_NO_ASM_CLAMP
+    return __builtin_fmaxf(__builtin_fmaf(a, b, 1.0f), 0.0f);
+#else
+    // s_nop: `a` is the result of v_sqrt_f32 one instruction earlier, and a VALU instruction that reads the result of a
+    // transcendental needs one wait state on gfx950 — the compiler pads its own instructions but cannot see into an asm
+    float r; asm("s_nop 0\n\tv_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "s"(b)); return r;
+#endif
+}
+__device__ __forceinline__ double fma1_clamp01(double a, double b) {
+    const double t = __builtin_fma(a, b, 1.0);
+    return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+}
+// 1 for a positive (Fluid) signed density, 0 for a negative one — the MotionLimiter of the neighbour as a factor
+__device__ __forceinline__ float step01(float s, float big) {
+#ifdef SPHMI_NO_ASM_CLAMP
+    return s > 0.0f ? 1.0f : 0.0f;
+#else
+    float r; asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(s), "s"(big)); return r;
+#endif
+}
+__device__ __forceinline__ double step01(double s, double) { return s > 0.0 ? 1.0 : 0.0; }
+
 // 16-/32-byte packet gathers through buffer loads: 32-bit offsets, one address instruction per gather
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 gather_packet(__amdgpu_buffer_rsrc_t r, int j, float) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, j << 4, 0, 0);
+// (j16 = 16·j: the queue entries hold the candidate base pre-multiplied, so that base + 16·bit is ONE v_lshl_add_u32)
+__device__ __forceinline__ float4 gather_packet(__amdgpu_buffer_rsrc_t r, int j16, float) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, j16, 0, 0);
     float4 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
     return f;
 }
-__device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, int j, double) {
-    const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(r, j << 5, 0, 0);
-    const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(r, (j << 5) + 16, 0, 0);
+__device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, int j16, double) {
+    const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(r, j16 << 1, 0, 0);
+    const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(r, (j16 << 1) + 16, 0, 0);
     double4 f;
     f.x = __longlong_as_double(((long long)lo.y << 32) | lo.x); f.y = __longlong_as_double(((long long)lo.w << 32) | lo.z);
     f.z = __longlong_as_double(((long long)hi.y << 32) | hi.x); f.w = __longlong_as_double(((long long)hi.w << 32) | hi.z);
@@ -273,9 +300,13 @@ __device__ __forceinline__ void wave_sync() {
 // (chunk c of a row goes to wave (c + row) % WPT); wave 0 adds the partial sums in wave order and runs the
 // epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
 // last round of a 1 M-particle launch) shorter-lived waves keep the SIMDs filled.
-template <class T, int D, int PASS, int MODEL, int WPT>
-__global__ void __launch_bounds__(kWave * WPT)
+// TPB: tiles per block (WPT = 1 only).  The TPB waves of a workgroup take TPB consecutive entries of the XCD's run —
+// neighbouring tiles, whose candidate rows overlap by three quarters — and run on the four SIMDs of ONE compute unit,
+// so the rows are fetched into that unit's L1 once instead of by four units.
+template <class T, int D, int PASS, int MODEL, int WPT, int TPB = 1>
+__global__ void __launch_bounds__(kWave * WPT * TPB)
 k_neighbor_force(const ForceParams<T> P) {
+    static_assert(TPB == 1 || WPT == 1, "several tiles per block only with one wave per tile");
     if (P.ctrl && !P.ctrl->active) return;                 // a queued step that the control kernel cancelled
     const T step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt, step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
     const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;
@@ -285,20 +316,21 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
     static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
-    // entry = { 32-bit accept mask, candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
-    __shared__ uint2 s_q_all[WPT * QCAP * kWave];          // [wave][entry][lane]
+    // entry = { 32-bit accept mask, 16 × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
+    __shared__ uint2 s_q_all[WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
+    const int wvb = threadIdx.x >> 6;                      // wave of the block
+    const int wv = TPB == 1 ? wvb : 0;                     // wave of the tile
     // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
     // program order is all the synchronisation the queue needs
-    uint2* const s_q = s_q_all + wv * QCAP * kWave + lane;
+    uint2* const s_q = s_q_all + wvb * QCAP * kWave + lane;
     // Tile schedule (sphmi_rebuild.h): the dispatcher places block b on XCD b % 8; every XCD works through
     // one contiguous, cost-balanced run of tiles, expensive tiles first.  Measured on the 1 M-particle dam
     // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
     int b;
     {
-        const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+        const int x = blockIdx.x & 7, r = TPB == 1 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * TPB + wvb;
         if (r >= P.part[8 + x]) return;
         b = P.order[P.part[x] + r];
     }
@@ -332,6 +364,11 @@ k_neighbor_force(const ForceParams<T> P) {
     const T inv_rho_a = fast_rcp(rho_a);
     const T inv_rhon_a = (PASS == PASS_CORRECTOR) ? fast_rcp(rhon_a) : inv_rho_a;
     const T rm_a = rho_a * P.m0;
+    // lane constants of the pair terms: −m₀/ρₐ (pressure), −2·δᵩhc₀m₀·MLₐ (density diffusion; ZeroGravityLinear has no
+    // MotionLimiter factor), Pₐ − Cb/γ·… (corrector: Pₐ + P_b = Cbe·r_b⁷ + (Pₐ − Cbe))
+    const T c_a = -P.m0 * inv_rho_a;
+    const T Kd_a = (ddt == kDdtZeroGravityLinear || fluid_a) ? T(-2) * P.Kddt : T(0);
+    const T PaC = P_a - P.Cbe;
 
     const int key_a = P.key[ac];
     const int cs_a = P.cstart[key_a], ce_a = P.cstart[key_a + 1];
@@ -365,27 +402,26 @@ k_neighbor_force(const ForceParams<T> P) {
     // SimParticles.Velocity of the neighbours (LaminarSPS in the corrector pass)
     const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.a1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
     // ---- pair physics for one accepted neighbour j ------------------------------------------
-    auto pair = [&](const int j, const V4& n0, const V4& n1) {
+    T sum_c = 0, sum_d = 0;                             // Σ (1/ρ_b)·(∇W·vᵢⱼ) (continuity without ρₐm₀), Σ density diffusion
+    const int cs_a16 = cs_a << 4, ce_a16 = ce_a << 4, a16 = a << 4;
+    auto pair = [&](const int j16, const V4& n0, const V4& n1, const bool a_is_i) {
         // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
         const T dx = xa - n0.x, dy = ya - n0.y, dz = (D == 3) ? za - n0.z : T(0);
         const T r2 = (D == 3) ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
-        T rho_b, rhon_b, P_b, s_b;
-        if constexpr (PASS == PASS_CORRECTOR) {
-            rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w;
-            P_b = eos7<T>(rho_b, P.rho0, P.inv_rho0, P.Cbe);
-        } else {
-            rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; P_b = n1.w;
-        }
-        // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280).
+        T rho_b, rhon_b, s_b;
+        if constexpr (PASS == PASS_CORRECTOR) { rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w; }
+        else { rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; }
+        // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280): (q − 2)³ = −8u³,
+        // u = clamp(1 − q/2, 0, 1) — one fused multiply-add with the clamp output modifier.
         // The phase-1 mask is slightly generous; with H = 2h (the default k = 2) the r² ≤ H² cut of :275 needs no
-        // branch: beyond H the clamp makes (q−2)³ = 0 and every pair term below carries the factor `fac`.
+        // branch: beyond H the clamp makes u = 0 and every pair term below carries the factor `fac`.
         const T r = fast_sqrt(r2);
-        const T tq = min_raw(r * P.h_inv, T(2)) - T(2);
-        T fac = P.Cgw * (tq * tq * tq);
+        const T u = fma1_clamp01(r, P.nhinv_half);
+        T fac = P.Cfac * (u * u * u);
         T Wq = T(0);                                            // W(q): tensile correction / kernel output
         const bool cubic = MODEL < 0 && P.kernel == 1;
         if (MODEL < 0 && (cubic || P.kout)) {
-            const T q = tq + T(2);
+            const T q = min_raw(r * P.h_inv, T(2)), tq = q - T(2);
             if (cubic) {
                 // CubicSpline, src/SPHKernels.jl:89-106: ∇W = dW/dq·h⁻¹·xᵢⱼ/(|xᵢⱼ| + η²)
                 const T dWdq = q <= T(1) ? P.alphaD * (T(-3) * q + T(2.25) * q * q) : P.alphaD * T(-0.75) * (tq * tq);
@@ -402,15 +438,14 @@ k_neighbor_force(const ForceParams<T> P) {
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = (D == 3) ? q1.z - n1.z : T(0);
         const T vdx = (D == 3) ? dvx * dx + dvy * dy + dvz * dz : dvx * dx + dvy * dy;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);
-        // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term)
-        drho += rm_a * inv_rho_b * (fac * vdx);
+        // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term); ρₐm₀ after the loop
+        sum_c += inv_rho_b * (fac * vdx);
         const T inv_r2e = fast_rcp(r2 + P.eta2);
         if (ddt != kDdtNone) {
             // density diffusion, src/SPHDensityDiffusionModels.jl:56-87 (no hydrostatic part, no MLcond),
             // :100-136 (linear), :150-188 (inverse hydrostatic EOS); orientation rule of SURVEY §8(a)-Q4:
-            // the target plays "i" iff j sorts before its cell, or after it inside it
+            // the target plays "i" iff j sorts before its cell, or after it inside it (a_is_i, kept by the caller)
             const T dlast = (D == 3) ? dz : dy;
-            const bool a_is_i = (j < cs_a) || (j > a && j < ce_a);
             T rhoH = T(0);
             if (ddt == kDdtLinear) rhoH = P.linfac * dlast;
             else if (ddt == kDdtComplex) {
@@ -420,16 +455,25 @@ k_neighbor_force(const ForceParams<T> P) {
                 rhoH = (T)(a_is_i ? rh : -rh);
             }
             const T drn = (rhon_b - rhon_a) - rhoH;
-            const T psigw = T(-2) * drn * fac * r2 * inv_r2e;
             T inv_sel;
             if constexpr (PASS == PASS_CORRECTOR) inv_sel = a_is_i ? fast_rcp(rhon_b) : inv_rhon_a;
             else inv_sel = a_is_i ? inv_rho_b : inv_rho_a;
-            const T Dv = P.Kddt * inv_sel * psigw;
-            const bool on = ddt == kDdtZeroGravityLinear ? true : (fluid_a && s_b > T(0));
-            drho += on ? Dv : T(0);
+            // Dᵢ = δᵩhc₀·(m₀/ρ_sel)·ψ·∇W·MLᵢMLⱼ with ψ·∇W = −2·Δρ·fac·r²/(r²+η²); MLᵢ sits in Kd_a, MLⱼ is a 0/1 factor
+            const T Dv = (Kd_a * inv_sel) * (drn * (fac * (r2 * inv_r2e)));
+            const T on = ddt == kDdtZeroGravityLinear ? T(1) : step01(s_b, P.big);
+            sum_d += Dv * on;
         }
-        // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland)
-        T coef = -P.m0 * ((P_a + P_b) * inv_rho_a * inv_rho_b);
+        // pressure, src/SPHCellList.jl:301-303 (tensile term is 0 for Wendland): −m₀(Pᵢ+Pⱼ)/(ρᵢρⱼ)
+        T Psum, P_b;
+        if constexpr (PASS == PASS_CORRECTOR) {
+            // EquationOfStateGamma7 (src/SimulationEquations.jl:9-11) of the neighbour's ρ⁺, folded into the sum
+            T rr;
+            if constexpr (sizeof(T) == 8) rr = rho_b / P.rho0; else rr = rho_b * P.inv_rho0;
+            const T rr2 = rr * rr, rr4 = rr2 * rr2, rr7 = (rr4 * rr2) * rr;
+            Psum = P.Cbe * rr7 + PaC;
+            P_b = Psum - P_a;
+        } else { P_b = n1.w; Psum = P_a + P_b; }
+        T coef = Psum * (c_a * inv_rho_b);
         if (cubic) {
             // tensile_correction, :114-126 (n = 4; the reference evaluates the reference kernel value at q := dx)
             const T w = Wq * P.inv_Wdx, w2 = w * w;
@@ -438,7 +482,7 @@ k_neighbor_force(const ForceParams<T> P) {
         if (visc == kViscArtificial) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
             const T vneg = min_raw(vdx, T(0));
-            coef += P.Kv2 * vneg * inv_r2e * fast_rcp(rhon_a + rhon_b);
+            coef += (P.Kv2 * (vneg * inv_r2e)) * fast_rcp(rhon_a + rhon_b);
         }
         coef *= fac;
         ax += coef * dx; ay += coef * dy;
@@ -453,7 +497,7 @@ k_neighbor_force(const ForceParams<T> P) {
                 // tensors are multiples of O = (vⱼ−vᵢ)⊗∇W:  Sᵢ = (m₀/ρⱼ)O, Sⱼ = (m₀/ρᵢ)O.
                 T wx, wy, wz;                                   // vⁿ_b − vⁿ_a
                 if constexpr (PASS == PASS_CORRECTOR) {
-                    const V4 nv = gather_packet(rsA1, j, T());
+                    const V4 nv = gather_packet(rsA1, j16, T());
                     wx = nv.x - vn_a.x; wy = nv.y - vn_a.y; wz = nv.z - vn_a.z;
                 } else { wx = -dvx; wy = -dvy; wz = -dvz; }
                 const T gx = fac * dx, gy = fac * dy, gz = fac * dz;
@@ -475,7 +519,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         if (MODEL < 0 && P.kout && PASS == PASS_CORRECTOR) {
             // KernelOutput!, src/SPHCellList.jl:106-116
-            const bool in = (r2 <= P.H2) && (j != a);              // the pair loop never meets i == j
+            const bool in = (r2 <= P.H2) && (j16 != a16);          // the pair loop never meets i == j
             kw += in ? Wq : T(0);
             kgx += fac * dx; kgy += fac * dy; kgz += fac * dz;
         }
@@ -499,39 +543,50 @@ k_neighbor_force(const ForceParams<T> P) {
     unsigned long long st_it = 0, st_lane = 0, st_ref = 0, st_emp = 0, st_chunks = 0;
 #endif
     int work_it = 0, work_ch = 0;    // wave-uniform work counters (scalar unit): pair-loop iterations, chunks scanned
-    int wpos = 0, rpos = 0;          // this lane's queue: entries written / fetched so far
+    // this lane's queue: entries written / fetched so far, kept as BYTE offsets of the entry inside the lane's column
+    // (entry k of a lane sits k·64·8 bytes further: one v_and_or gives the address)
+    constexpr int kEntryStride = kWave * 8;
+    constexpr int kQMask = (QCAP - 1) * kEntryStride;
+    int wpos = 0, rpos = 0;
     int cbase = 0;                   // candidate index of bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
+    char* const s_qb = reinterpret_cast<char*>(s_q);
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
     // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
     auto run_pairs = [&](const int keep, const bool drain) {
-        auto any_owes = [&]() -> bool {
-            bool owes = (wpos - rpos) > keep;
-            if (drain) owes |= (cm != 0);
-            return __builtin_amdgcn_ballot_w64(owes) != 0;
-        };
-        bool go = any_owes();
-        while (go) {
-            const bool need = (cm == 0) & (rpos != wpos);
-            const uint2 ne = s_q[(rpos & (QCAP - 1)) * kWave];
-            cm = need ? ne.x : cm;
-            cbase = need ? (int)ne.y : cbase;
-            rpos += need ? 1 : 0;
+        const int wlim = wpos - keep * kEntryStride;     // (wpos is fixed during a burst)
+        // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
+        bool more = rpos != wpos, have = cm != 0;
+        if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (rpos < wlim)) != 0) do {
+            unsigned m = cm;
+            if (!have & more) {                                  // fetch the next non-empty mask of MY queue
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + (rpos & kQMask));
+                m = ne.x; cbase = (int)ne.y; rpos += kEntryStride;
+            }
+            cm = m & (m - 1);                                    // (0 stays 0)
             work_it += 1;
 #ifdef SPHMI_STATS
-            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cm != 0));
-            st_ref += __builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
+            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0));
 #endif
-            if (cm != 0) {
-                const int j = cbase + __builtin_ctz(cm);
-                cm &= cm - 1;
-                const V4 n0 = gather_packet(rs0, j, T());
-                const V4 n1 = gather_packet(rs1, j, T());
-                pair(j, n0, n1);
+            if (m != 0) {
+                const int j16 = (__builtin_ctz(m) << 4) + cbase;      // 16 × the neighbour's index
+                const V4 n0 = gather_packet(rs0, j16, T());
+                const V4 n1 = gather_packet(rs1, j16, T());
+                // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
+                // cell (j < cs_a) or after it inside it (a < j < ce_a)
+                const bool a_is_i = (j16 < cs_a16) | ((j16 > a16) & (j16 < ce_a16));
+#ifdef SPHMI_EXP_GATHER3
+                if constexpr (PASS == PASS_CORRECTOR && sizeof(T) == 4) {      // experiment: what does a third (8-byte) gather cost?
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t e3 = __builtin_amdgcn_raw_buffer_load_b64(rsA1, j16, 0, 0);
+                    sum_c += __uint_as_float(e3.x) * T(0) + __uint_as_float(e3.y) * T(0);
+                }
+#endif
+                pair(j16, n0, n1, a_is_i);
             }
-            go = any_owes();
-        }
+            more = rpos != wpos; have = cm != 0;
+        } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (rpos < wlim)) != 0);
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -594,7 +649,7 @@ k_neighbor_force(const ForceParams<T> P) {
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
             if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;
             // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
-            if (__builtin_amdgcn_ballot_w64((wpos - rpos) > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
+            if (__builtin_amdgcn_ballot_w64((wpos - rpos) > (QCAP - 2) * kEntryStride) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
             unsigned long long m = scan_chunk(cb, HI);
             work_ch += 1;
 #ifdef SPHMI_STATS
@@ -607,11 +662,12 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
             m = (w > 0) ? (m & rm) : 0ull;
             const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            if (mlo != 0) { s_q[(wpos & (QCAP - 1)) * kWave] = make_uint2(mlo, (unsigned)cb); wpos += 1; }
-            if (mhi != 0) { s_q[(wpos & (QCAP - 1)) * kWave] = make_uint2(mhi, (unsigned)(cb + 32)); wpos += 1; }
+            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mlo, (unsigned)cb << 4); wpos += kEntryStride; }
+            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mhi, (unsigned)(cb + 32) << 4); wpos += kEntryStride; }
         }
     }
     run_pairs(0, true);
+    drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
     int tile_work = 9 * work_it + 16 * work_ch + 16;

@@ -187,6 +187,17 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add(int* out, int n, cons
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
+// (the same without the total written behind the array: for scans over arrays that have no slot n)
+__global__ void __launch_bounds__(kScanThreads) k_scan_add_nototal(int* out, int n, const int* tsum) {
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    const int off = tsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        int idx = base + k;
+        if (idx < n) out[idx] += off;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Tile schedule of the neighbour kernel.  The dispatcher hands block b to XCD b % 8 and workgroups start
 // in block order, so the engine decides (at every rebuild) WHICH tile each block processes:
@@ -695,6 +706,22 @@ __global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::typ
             if (D == 3) o.cells[bc + 2] = (long long)cz - 1 + g.gmin[2];
         }
     }
+}
+
+// UniqueCells (src/SPHCellList.jl:148-157) on the device: heads of the runs of equal keys → compacted cell coordinates
+__global__ void __launch_bounds__(256) k_cell_heads(const int* key, int N, int ncell, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { const int k = key[i]; flag[i] = (k < ncell && (i == 0 || key[i - 1] != k)) ? 1 : 0; }
+}
+__global__ void __launch_bounds__(256) k_cells_out(const int* key, const int* flag, const int* pos, int N, GridDesc g, int D, long long* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || !flag[i]) return;
+    int kk = key[i];
+    const int cx = kk % g.np[0]; kk /= g.np[0];
+    const int cy = kk % g.np[1], cz = kk / g.np[1];
+    long long* o = out + (size_t)pos[i] * D;
+    o[0] = (long long)cx - 1 + g.gmin[0]; o[1] = (long long)cy - 1 + g.gmin[1];
+    if (D == 3) o[2] = (long long)cz - 1 + g.gmin[2];
 }
 
 // the four reduction slots → a caller-owned buffer, slots reset (one launch instead of a copy and a fill).

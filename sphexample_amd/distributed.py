@@ -1,4 +1,12 @@
-"""Domain decomposition of the SPH hot path over the GPUs of one node.
+"""TEST HARNESS — the Python twin of the slab driver that ships inside libsphmi.so (csrc/sphmi_multi.h).
+
+The product path for more than one GPU is `sphmi_create` with a device list (one process, what the reference's Julia
+caller needs) or `sphmi_create_rank` (one process per GPU, what bench.py uses): C++ host loop, RCCL linked into the
+library.  This module drives the same kernels verb by verb (`sphmi_dd_*`) with `torch.distributed` and is kept because
+its planning helpers (`SlabPlan`, `best_cuts`, `particle_work`, `choose_axis`) are the independent reference the C++
+planner is tested against (tests/test_multi_gpu.py) and because its gloo path covers the message pattern on CPU.
+
+Domain decomposition of the SPH hot path over the GPUs of one node.
 
 The reference has no multi-process path at all; this module is new work for the MI355X
 engine.  One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI), 1-D slabs cut on
@@ -614,7 +622,11 @@ class DistributedEngine:
         cfg = self.cfg
         self.delta_x = 1.0 + cfg.h                                   # :739
         steps = 0
-        red_t = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
+        # persistent: sphmi_dd_reductions_dev MAX-merges into it and k_step_control zeroes it when a step consumes it, so the
+        # maxima a control left unused at the end of an interval are still there for the first Δt of the next one
+        if getattr(self, "_red_t", None) is None:
+            self._red_t = self.torch.zeros(4, dtype=self.torch.int64, device=self.device)
+        red_t = self._red_t
         self._call("dd_ctrl_init", C.c_double(self.delta_x), C.c_double(t_target), C.c_int64(max_steps))
         st = SphmiDdControl()
         first = True

@@ -182,25 +182,18 @@ def test_comm_over_gloo_world3():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,steps,fb,tol,axis,overlap", [
+    # (the full matrix — axes, variants, moving bodies, mDBC — runs through the in-library driver: tests/test_multi_gpu.py;
+    #  the Python harness keeps one case per mechanism)
     ("dam_break_3d_shipped", 30, 8, 1e-9, None, True), ("dam_break_3d_shipped", 30, 4, 1e-5, None, True),
-    ("dam_break_3d_shipped", 30, 8, 1e-9, 0, True), ("dam_break_3d_shipped", 30, 8, 1e-9, 1, False),
-    ("dam_break_3d_shipped", 30, 8, 1e-9, 2, True),
-    ("dam_break_2d", 60, 8, 1e-9, None, True), ("dam_break_2d", 60, 8, 1e-9, 0, False), ("dam_break_2d", 60, 8, 1e-9, 1, True),
-    ("dam_break_2d_variants", 40, 8, 1e-9, None, True),
-    # a Moving body (ProgressMotion on owned particles and ghost copies) crossing nothing / the cut (axis 0: it moves in +x)
-    # — 150 steps along y: fluid pushed by the body crosses the cut particle by particle, and a migrant must take the
-    # in-cell place its previous GLOBAL sorted index gives it (order tags), or same-cell pairs swap their i / j roles
-    ("moving_square", 40, 8, 1e-9, 0, True), ("moving_square", 150, 8, 1e-9, 1, True),
-    # mDBC: ghost layers 2 + off columns wide, ghost copies corrected locally
-    ("dam_break_2d_mdbc", 40, 8, 1e-9, None, True), ("dam_break_2d_mdbc", 40, 8, 1e-9, 0, True), ("dam_break_2d_mdbc", 40, 8, 1e-9, 1, False),
-    ("dam_break_2d_mdbc", 40, 4, 2e-5, None, True),
-    ("still_wedge", 40, 8, 1e-9, None, True), ("duckling", 12, 8, 1e-9, None, True)])
+    ("dam_break_2d", 60, 8, 1e-9, 0, False),
+    ("moving_square", 150, 8, 1e-9, 1, True),
+    ("dam_break_2d_mdbc", 40, 8, 1e-9, None, True)])
 def test_two_slabs_match_single_gpu(case, steps, fb, tol, axis, overlap, request):
     _two_slabs(case, steps, fb, tol, axis, overlap, 1.05, request)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [3, 4])
+@pytest.mark.parametrize("world", [3])
 def test_more_slabs_match_single_gpu(world, request):
     """Middle ranks have two neighbours (two ghost layers, two halo messages per pass, migration both ways)."""
     _two_slabs("dam_break_3d_shipped", 40, 8, 1e-9, None, True, 1.05, request, world=world)
