@@ -81,7 +81,7 @@ typedef struct sphmi_config {
     int32_t device;              /* HIP device ordinal                                           */
     int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
     int32_t kernel_output;       /* SPHMI_KOUT_* (KMode of SimulationMetaData)                   */
-    int64_t n_particles;         /* length(SimParticles); at most 2^27 per handle (32-bit gather offsets) */
+    int64_t n_particles;         /* length(SimParticles); below 2^27 (fp32 kernels) / 2^26 (fp64) per device: 32-bit gather offsets */
     int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
     /* SimulationConstants */
     double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;
@@ -217,7 +217,8 @@ int sphmi_unique_cells(sphmi_handle* h, int64_t* cells_out, int64_t capacity, in
 int sphmi_timers(sphmi_handle* h, int32_t capacity, const char** names_out, double* seconds_out,
                  int64_t* calls_out, int32_t* n_out);
 
-/* Raw device pointers of the packed neighbour stream (state set A) and the live particle count. */
+/* Raw device pointers of the packed neighbour stream (state set A) and the live particle count.  The two packets of a
+ * particle are interleaved in ONE array of records: packet h of particle i is pk_h[2*i] (pk1 == pk0 + 1 packet). */
 int sphmi_device_ptrs(sphmi_handle* h, void** pk0, void** pk1, int64_t* n_local);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------- */

@@ -105,7 +105,9 @@ struct Engine final : EngineBase {
     int* cellx_d = nullptr;
     hipStream_t stream = nullptr;
     // state sets: 0..2 rotate through the roles A (state n), H (half step), B (state n+1 / permute target)
-    V4 *pk0[3] = {}, *pk1[3] = {};
+    // particle records: rec[k] holds 2·cap packets, packet h of particle i at rec[k][2i + h]; pk0 / pk1 are the strided views
+    V4* rec[3] = {};
+    Half<V4> pk0[3], pk1[3];
     int iA = 0, iH = 1, iB = 2;
     V4 *acc[2] = {}, *ghost[2] = {};
     uint8_t* type[2] = {};
@@ -178,7 +180,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
         const size_t n = (size_t)N;
-        for (int k = 0; k < 3; ++k) { HC(hipMalloc(&pk0[k], n * sizeof(V4))); HC(hipMalloc(&pk1[k], n * sizeof(V4))); }
+        for (int k = 0; k < 3; ++k) { HC(hipMalloc(&rec[k], 2 * n * sizeof(V4))); pk0[k] = Half<V4>(rec[k]); pk1[k] = Half<V4>(rec[k] + 1); }
         for (int k = 0; k < 2; ++k) {
             HC(hipMalloc(&acc[k], n * sizeof(V4)));
             HC(hipMalloc(&ghost[k], n * sizeof(V4)));
@@ -205,7 +207,7 @@ struct Engine final : EngineBase {
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& e : ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto& e : ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        for (int k = 0; k < 3; ++k) { (void)hipFree(pk0[k]); (void)hipFree(pk1[k]); }
+        for (int k = 0; k < 3; ++k) (void)hipFree(rec[k]);
         for (int k = 0; k < 2; ++k) {
             (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]); (void)hipFree(otag[k]);
             (void)hipFree(grp[k]); (void)hipFree(key[k]);
@@ -706,8 +708,9 @@ struct Engine final : EngineBase {
             if (!(std::fabs((double)h0[i].w) > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
         iA = 0; iH = 1; iB = 2; cur = 0;
         const size_t n = (size_t)N;
-        HC(hipMemcpyAsync(pk0[iA], h0.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(pk1[iA], h1.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
+        std::vector<V4> hrec(2 * n);                                     // the two packets of a particle side by side
+        for (size_t i = 0; i < n; ++i) { hrec[2 * i] = h0[i]; hrec[2 * i + 1] = h1[i]; }
+        HC(hipMemcpyAsync(rec[iA], hrec.data(), 2 * n * sizeof(V4), hipMemcpyHostToDevice, stream));
         HC(hipMemcpyAsync(acc[cur], ha.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
         HC(hipMemcpyAsync(ghost[cur], hg.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
         HC(hipMemcpyAsync(type[cur], ty, n, hipMemcpyHostToDevice, stream));
@@ -786,7 +789,7 @@ struct Engine final : EngineBase {
         o.cells = (long long*)take(cells, ncell_d * 8);
         char* a_id = take(ids, n * 8); char* a_ty = take(ty, n); char* a_grp = take(groups, n * 8);
         hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
-                           stepped ? pk0[iH] : (const V4*)nullptr, acc[cur], ghost[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
+                           stepped ? Half<const V4>(pk0[iH]) : Half<const V4>(), acc[cur], ghost[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
                            (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
         HC(hipGetLastError());
         if (a_id) HC(hipMemcpyAsync(a_id, id[cur], n * 8, hipMemcpyDeviceToDevice, stream));
@@ -844,13 +847,13 @@ struct Engine final : EngineBase {
         if (apply_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();
         // the forces-only pass writes {a, dρ/dt} into a scratch set so SimParticles.Acceleration survives
         ForceParams<T> P = force_params(iA, iA, iH, 0.0);
-        P.accbuf = pk0[iB];
+        P.accbuf = rec[iB];                       // (scratch: N contiguous packets at the start of the third record array)
         Ev e1 = begin_phase(PH_PASS1);
         launch_force<PASS_FORCES_ONLY>(P);
         end_phase(e1);
         sync_and_collect();
         std::vector<V4> tmp(N);
-        HC(hipMemcpy(tmp.data(), pk0[iB], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        HC(hipMemcpy(tmp.data(), rec[iB], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
         const bool h8 = cfg.host_float_bytes == 8;
         if (acceleration) { if (h8) unpack3(tmp, (double*)acceleration, N, D); else unpack3(tmp, (float*)acceleration, N, D); }
         if (drhodt) for (int i = 0; i < N; ++i) { if (h8) ((double*)drhodt)[i] = (double)tmp[i].w; else ((float*)drhodt)[i] = (float)tmp[i].w; }
@@ -1098,8 +1101,11 @@ struct Engine final : EngineBase {
         std::vector<V4> h0(N), h1(N);
         std::vector<uint8_t> ty(N);
         std::vector<long long> idv(N);
-        HC(hipMemcpy(h0.data(), pk0[iA], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
-        HC(hipMemcpy(h1.data(), pk1[iA], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        {
+            std::vector<V4> hrec(2 * (size_t)N);
+            HC(hipMemcpy(hrec.data(), rec[iA], 2 * (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+            for (int i = 0; i < N; ++i) { h0[i] = hrec[2 * (size_t)i]; h1[i] = hrec[2 * (size_t)i + 1]; }
+        }
         HC(hipMemcpy(ty.data(), type[cur], (size_t)N, hipMemcpyDeviceToHost));
         HC(hipMemcpy(idv.data(), id[cur], (size_t)N * 8, hipMemcpyDeviceToHost));
         int64_t m = 0;
@@ -1129,8 +1135,8 @@ struct Engine final : EngineBase {
         if (reset) { force_ms = 0; force_launches = 0; ev_always_until = iteration + 2; }   // short windows still get samples
     }
     void device_ptrs(void** p0, void** p1, int64_t* n) override {
-        if (p0) *p0 = pk0[iA];
-        if (p1) *p1 = pk1[iA];
+        if (p0) *p0 = pk0[iA].p;            // packet h of particle i at p[2·i] (the two pointers are one array, 1 packet apart)
+        if (p1) *p1 = pk1[iA].p;
         if (n) *n = N;
     }
 };
@@ -1259,9 +1265,9 @@ static int check_config(const sphmi_config* cfg, std::string& why) {
     // (n × sizeof(packet) < 4 GB: 2^27 packets of 16 bytes, 2^26 of 32; a multi-device handle holds n / devices per slab)
     {
         const int64_t per = (cfg->n_devices > 1) ? (cfg->n_particles + cfg->n_devices - 1) / cfg->n_devices : cfg->n_particles;
-        const int64_t lim = cfg->device_float_bytes == 8 ? (1ll << 26) : (1ll << 27);
+        const int64_t lim = (cfg->device_float_bytes == 8 ? (1ll << 26) : (1ll << 27)) - 1;     // N × record size (64 / 32 bytes) < 4 GB
         if (cfg->n_particles < 1 || per > lim)
-            return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27] (fp32 kernels) / [1, 2^26] (fp64 kernels) per device");
+            return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27) (fp32 kernels) / [1, 2^26) (fp64 kernels) per device");
     }
     if (cfg->kernel != SPHMI_KERNEL_WENDLAND_C2 && cfg->kernel != SPHMI_KERNEL_CUBIC_SPLINE)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: kernel not implemented");

@@ -38,6 +38,19 @@ template <class T> struct Vec4;
 template <> struct Vec4<float>  { using type = float4;  };
 template <> struct Vec4<double> { using type = double4; };
 
+// One half of the interleaved particle records.  A particle's two packets — pk0 = {x, y, z, ρ·s}, pk1 = {v, P} —
+// sit side by side in ONE array, rec[2i] and rec[2i + 1]: the two gathers of a neighbour then touch ONE cache line
+// instead of one line in each of two arrays (−4 % kernel time at 1.06 M particles, measured by pointing the second
+// gather at the line of the first).  Half<V>{rec + h}[i] is packet h of particle i; kernels index it like an array.
+template <class V> struct Half {
+    V* p;
+    __host__ __device__ Half() : p(nullptr) {}
+    __host__ __device__ explicit Half(V* q) : p(q) {}
+    template <class U> __host__ __device__ Half(const Half<U>& o) : p(o.p) {}           // Half<V4> → Half<const V4>
+    __host__ __device__ V& operator[](long long i) const { return p[2 * i]; }
+    __host__ __device__ explicit operator bool() const { return p != nullptr; }
+};
+
 constexpr int kWave = 64;
 #ifndef SPHMI_SEQ_BLOCKS
 #define SPHMI_SEQ_BLOCKS 1
@@ -106,12 +119,12 @@ __global__ void k_step_control(unsigned long long* red, StepCtrl* c, double h, d
 template <class T>
 struct ForceParams {
     using V4 = typename Vec4<T>::type;
-    const V4* src0;      // neighbour stream packet 0 (A for pass 1, H for pass 2)
-    const V4* src1;      // neighbour stream packet 1
-    const V4* a0;        // state A (corrector epilogue)
-    const V4* a1;
-    V4* out0;            // H (predictor) or B (corrector)
-    V4* out1;
+    Half<const V4> src0; // neighbour stream packet 0 (A for pass 1, H for pass 2) — src1.p == src0.p + 1: one record array
+    Half<const V4> src1; // neighbour stream packet 1
+    Half<const V4> a0;   // state A (corrector epilogue)
+    Half<const V4> a1;
+    Half<V4> out0;       // H (predictor) or B (corrector)
+    Half<V4> out1;
     V4* accbuf;          // { a, dρ/dt }
     const int* key;      // padded linear cell id of every sorted particle
     const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
@@ -211,15 +224,16 @@ __device__ __forceinline__ double step01(double s, double) { return s > 0.0 ? 1.
 
 // 16-/32-byte packet gathers through buffer loads: 32-bit offsets, one address instruction per gather
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// (j16 = 16·j: the queue entries hold the candidate base pre-multiplied, so that base + 16·bit is ONE v_lshl_add_u32)
-__device__ __forceinline__ float4 gather_packet(__amdgpu_buffer_rsrc_t r, int j16, float) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, j16, 0, 0);
+// (jr = the neighbour's index × the record size, 32 or 64 bytes: the queue entries hold the candidate base pre-multiplied, so
+// that base + bit·size is ONE v_lshl_add_u32; `half` = 0 / 1 selects the packet of the record)
+__device__ __forceinline__ float4 gather_packet(__amdgpu_buffer_rsrc_t r, unsigned jr, int half, float) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(jr + 16u * half), 0, 0);
     float4 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
     return f;
 }
-__device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, int j16, double) {
-    const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(r, j16 << 1, 0, 0);
-    const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(r, (j16 << 1) + 16, 0, 0);
+__device__ __forceinline__ double4 gather_packet(__amdgpu_buffer_rsrc_t r, unsigned jr, int half, double) {
+    const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(jr + 32u * half), 0, 0);
+    const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(jr + 32u * half + 16u), 0, 0);
     double4 f;
     f.x = __longlong_as_double(((long long)lo.y << 32) | lo.x); f.y = __longlong_as_double(((long long)lo.w << 32) | lo.z);
     f.z = __longlong_as_double(((long long)hi.y << 32) | hi.x); f.w = __longlong_as_double(((long long)hi.w << 32) | hi.z);
@@ -316,7 +330,7 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
     static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
-    // entry = { 32-bit accept mask, 16 × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
+    // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -400,11 +414,12 @@ k_neighbor_force(const ForceParams<T> P) {
     if constexpr (PASS == PASS_CORRECTOR) { if (visc == kViscLaminarSPS) vn_a = P.a1[ac]; }
 
     // SimParticles.Velocity of the neighbours (LaminarSPS in the corrector pass)
-    const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.a1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.a0.p, 0, (int)((unsigned)P.N * 2u * (unsigned)sizeof(V4)), 0x00020000);
     // ---- pair physics for one accepted neighbour j ------------------------------------------
     T sum_c = 0, sum_d = 0;                             // Σ (1/ρ_b)·(∇W·vᵢⱼ) (continuity without ρₐm₀), Σ density diffusion
-    const int cs_a16 = cs_a << 4, ce_a16 = ce_a << 4, a16 = a << 4;
-    auto pair = [&](const int j16, const V4& n0, const V4& n1, const bool a_is_i) {
+    constexpr int kRecShift = sizeof(T) == 4 ? 5 : 6;      // log2 of the record size
+    const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
+    auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
         // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
         const T dx = xa - n0.x, dy = ya - n0.y, dz = (D == 3) ? za - n0.z : T(0);
         const T r2 = (D == 3) ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
@@ -497,7 +512,7 @@ k_neighbor_force(const ForceParams<T> P) {
                 // tensors are multiples of O = (vⱼ−vᵢ)⊗∇W:  Sᵢ = (m₀/ρⱼ)O, Sⱼ = (m₀/ρᵢ)O.
                 T wx, wy, wz;                                   // vⁿ_b − vⁿ_a
                 if constexpr (PASS == PASS_CORRECTOR) {
-                    const V4 nv = gather_packet(rsA1, j16, T());
+                    const V4 nv = gather_packet(rsA, jr, 1, T());
                     wx = nv.x - vn_a.x; wy = nv.y - vn_a.y; wz = nv.z - vn_a.z;
                 } else { wx = -dvx; wy = -dvy; wz = -dvz; }
                 const T gx = fac * dx, gy = fac * dy, gz = fac * dz;
@@ -519,7 +534,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         if (MODEL < 0 && P.kout && PASS == PASS_CORRECTOR) {
             // KernelOutput!, src/SPHCellList.jl:106-116
-            const bool in = (r2 <= P.H2) && (j16 != a16);          // the pair loop never meets i == j
+            const bool in = (r2 <= P.H2) && (jr != a_r);           // the pair loop never meets i == j
             kw += in ? Wq : T(0);
             kgx += fac * dx; kgy += fac * dy; kgz += fac * dz;
         }
@@ -533,8 +548,8 @@ k_neighbor_force(const ForceParams<T> P) {
     };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src1, 0, (int)((unsigned)P.N * (unsigned)sizeof(V4)), 0x00020000);
+    // ONE descriptor over the neighbour records (2 packets each): 32-bit byte offsets, N·2·sizeof(packet) < 4 GB
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.src0.p, 0, (int)((unsigned)P.N * 2u * (unsigned)sizeof(V4)), 0x00020000);
     const unsigned long long xcd_t0 = P.xcd_clock ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -548,7 +563,7 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int kEntryStride = kWave * 8;
     constexpr int kQMask = (QCAP - 1) * kEntryStride;
     int wpos = 0, rpos = 0;
-    int cbase = 0;                   // candidate index of bit 0 of the current mask
+    unsigned cbase = 0;              // record offset of the candidate at bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
     char* const s_qb = reinterpret_cast<char*>(s_q);
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
@@ -562,7 +577,7 @@ k_neighbor_force(const ForceParams<T> P) {
             unsigned m = cm;
             if (!have & more) {                                  // fetch the next non-empty mask of MY queue
                 const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + (rpos & kQMask));
-                m = ne.x; cbase = (int)ne.y; rpos += kEntryStride;
+                m = ne.x; cbase = ne.y; rpos += kEntryStride;
             }
             cm = m & (m - 1);                                    // (0 stays 0)
             work_it += 1;
@@ -570,20 +585,13 @@ k_neighbor_force(const ForceParams<T> P) {
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0));
 #endif
             if (m != 0) {
-                const int j16 = (__builtin_ctz(m) << 4) + cbase;      // 16 × the neighbour's index
-                const V4 n0 = gather_packet(rs0, j16, T());
-                const V4 n1 = gather_packet(rs1, j16, T());
+                const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
+                const V4 n0 = gather_packet(rs0, jr, 0, T());
+                const V4 n1 = gather_packet(rs0, jr, 1, T());
                 // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
                 // cell (j < cs_a) or after it inside it (a < j < ce_a)
-                const bool a_is_i = (j16 < cs_a16) | ((j16 > a16) & (j16 < ce_a16));
-#ifdef SPHMI_EXP_GATHER3
-                if constexpr (PASS == PASS_CORRECTOR && sizeof(T) == 4) {      // experiment: what does a third (8-byte) gather cost?
-                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                    const u32x2_t e3 = __builtin_amdgcn_raw_buffer_load_b64(rsA1, j16, 0, 0);
-                    sum_c += __uint_as_float(e3.x) * T(0) + __uint_as_float(e3.y) * T(0);
-                }
-#endif
-                pair(j16, n0, n1, a_is_i);
+                const bool a_is_i = (jr < cs_ar) | ((jr > a_r) & (jr < ce_ar));
+                pair(jr, n0, n1, a_is_i);
             }
             more = rpos != wpos; have = cm != 0;
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (rpos < wlim)) != 0);
@@ -662,8 +670,8 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
             m = (w > 0) ? (m & rm) : 0ull;
             const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mlo, (unsigned)cb << 4); wpos += kEntryStride; }
-            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mhi, (unsigned)(cb + 32) << 4); wpos += kEntryStride; }
+            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mlo, (unsigned)cb << kRecShift); wpos += kEntryStride; }
+            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mhi, (unsigned)(cb + 32) << kRecShift); wpos += kEntryStride; }
         }
     }
     run_pairs(0, true);

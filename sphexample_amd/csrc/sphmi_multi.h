@@ -78,7 +78,7 @@ __global__ void k_dd_take(unsigned long long* red, unsigned long long* T) {
 }
 // both halo lists of a side in one launch: [0, nl) → buf_l, [nl, nl + nr) → buf_r
 template <class T>
-__global__ void __launch_bounds__(256) k_halo_pack2(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_halo_pack2(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                     const int* idx_l, int nl, typename Vec4<T>::type* buf_l,
                                                     const int* idx_r, int nr, typename Vec4<T>::type* buf_r) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_halo_pack2(const typename Vec4<T>::type
     if (k < nr) { const int i = idx_r[k]; buf_r[k] = pk0[i]; buf_r[nr + k] = pk1[i]; }
 }
 template <class T>
-__global__ void __launch_bounds__(256) k_halo_unpack2(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_halo_unpack2(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                       const int* idx_l, int nl, const typename Vec4<T>::type* buf_l,
                                                       const int* idx_r, int nr, const typename Vec4<T>::type* buf_r) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -585,7 +585,7 @@ struct MultiEngine final : EngineBase {
             HC(hipSetDevice(r.device));
             sphmi_config c = cfg;
             c.n_particles = S.capacity[r.rank]; c.device = r.device; c.n_devices = 0;
-            if (c.n_particles > (1ll << 27)) throw EngineError(SPHMI_ERR_ARGUMENT, "slab capacity beyond 2^27 particles: use more devices");
+            if (c.n_particles >= (cfg.device_float_bytes == 8 ? (1ll << 26) : (1ll << 27))) throw EngineError(SPHMI_ERR_ARGUMENT, "slab capacity beyond 2^27 particles: use more devices");
             r.e.reset(new Engine<T>(c));
             r.main = r.e->stream;
             r.e->dd_set_slab(axis, std::max(plan.lo[r.rank], -SlabPlan::INF), std::min(plan.hi[r.rank], SlabPlan::INF), r.has_left, r.has_right);

@@ -39,7 +39,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr uint8_t kGhostLeft = 0x80, kGhostRight = 0x40, kGhostMask = 0xC0, kTypeMask = 0x3F;
 
 template <class T, int D>
-__global__ void __launch_bounds__(256) k_cell_bbox(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
+__global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
                                                    T inv_cutoff, int* bbox) {
     // grid-stride: a few hundred blocks, so that the six atomics per WAVE are a few thousand in total — one wave per
     // 64 particles (16 k waves at 1 M) spent 228 µs queueing on the one cache line, for 16 MB of streaming reads
@@ -74,7 +74,7 @@ struct GridDesc {
 };
 
 template <class T, int D>
-__global__ void __launch_bounds__(256) k_cell_count(const typename Vec4<T>::type* pk0, const uint8_t* type, int N,
+__global__ void __launch_bounds__(256) k_cell_count(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
                                                     T inv_cutoff, GridDesc g, int* count, int* key, int* slot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(256) k_make_tags(int N, const int* key, const 
 template <class T>
 struct PermuteArgs {
     using V4 = typename Vec4<T>::type;
-    const V4 *pk0_in, *pk1_in, *acc_in, *ghost_in;
-    V4 *pk0_out, *pk1_out, *acc_out, *ghost_out;
+    Half<const V4> pk0_in, pk1_in; const V4 *acc_in, *ghost_in;
+    Half<V4> pk0_out, pk1_out; V4 *acc_out, *ghost_out;
     const uint8_t* type_in; uint8_t* type_out;
     const long long* id_in; long long* id_out;
     const unsigned long long* grp_in; unsigned long long* grp_out;
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
 
 // Pressure! (src/SimulationEquations.jl:18-24) on a state set: pk1.w = EOS(|pk0.w|)
 template <class T>
-__global__ void __launch_bounds__(256) k_eos(const typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_eos(Half<const typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                              int N, T rho0, T inv_rho0, T Cbe) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -423,8 +423,8 @@ __global__ void __launch_bounds__(256) k_eos(const typename Vec4<T>::type* pk0, 
 
 // ---- start-up reductions (Δt on the uploaded state; Positionₙ⁺ = 0 → |x|) ---------------------
 template <class T>
-__global__ void __launch_bounds__(256) k_init_reduce(const typename Vec4<T>::type* pk0,
-                                                     const typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_init_reduce(Half<const typename Vec4<T>::type> pk0,
+                                                     Half<const typename Vec4<T>::type> pk1,
                                                      const typename Vec4<T>::type* acc, int N, T h, T eta2,
                                                      unsigned long long* red) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) k_init_reduce(const typename Vec4<T>::typ
 // ---- mDBC -------------------------------------------------------------------------------------
 template <class T> struct MdbcParams {
     using V4 = typename Vec4<T>::type;
-    V4* pk0;               // state A: ρ of boundary particles is rewritten in place
+    Half<V4> pk0;          // state A: ρ of boundary particles is rewritten in place
     const V4* ghost;       // { g, flag }  flag != 0 ⇔ !iszero(GhostPoint)
     const uint8_t* type;   // ghost-copy bits (domain decomposition)
     const int* cstart;
@@ -667,8 +667,8 @@ template <class H> struct OutFields {
     long long* cells;                              // N×D
 };
 template <class T, class H>
-__global__ void __launch_bounds__(256) k_pack_output(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
-                                                     const typename Vec4<T>::type* half0, const typename Vec4<T>::type* accv,
+__global__ void __launch_bounds__(256) k_pack_output(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
+                                                     Half<const typename Vec4<T>::type> half0, const typename Vec4<T>::type* accv,
                                                      const typename Vec4<T>::type* ghostv, const int* key, int N, int D, int C,
                                                      GridDesc g, int have_grid, T rho0, T inv_rho0, T Cbe, OutFields<H> o) {
     // C: components per vector in the output (D, or 3 for the VTKHDF point layout: 2-D handles keep z = 0)
@@ -741,7 +741,7 @@ struct MotionTable {
     double vel[16], start[16], dur[16], dir[16][3];
 };
 template <class T>
-__global__ void __launch_bounds__(256) k_progress_motion(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_progress_motion(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                          const uint8_t* type, const unsigned long long* group, int N,
                                                          MotionTable M, double total_time, double dt2, const StepCtrl* ctrl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(256) k_progress_motion(typename Vec4<T>::type*
 // ---- domain decomposition (one process per GPU, x-slabs; sphexample_amd/distributed.py) -----------
 // global cell index along the slab axis of every particle, current order
 template <class T>
-__global__ void __launch_bounds__(256) k_dd_cellx(const typename Vec4<T>::type* pk0, int N, T inv_cutoff, int axis, int* out) {
+__global__ void __launch_bounds__(256) k_dd_cellx(Half<const typename Vec4<T>::type> pk0, int N, T inv_cutoff, int axis, int* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) {
         const typename Vec4<T>::type q = pk0[i];
@@ -810,7 +810,7 @@ template <class T> struct DdRecord {
 };
 
 template <class T>
-__global__ void __launch_bounds__(256) k_dd_gather(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                    const typename Vec4<T>::type* acc, const typename Vec4<T>::type* ghost,
                                                    const long long* id, const unsigned long long* grp,
                                                    const unsigned long long* tag, const uint8_t* type,
@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(256) k_dd_gather(const typename Vec4<T>::type*
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) k_dd_append(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_dd_append(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                    typename Vec4<T>::type* acc, typename Vec4<T>::type* ghost, long long* id,
                                                    unsigned long long* grp, unsigned long long* tag, uint8_t* type, int at, int n,
                                                    void* buf, uint8_t flag) {
@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(256) k_dd_kill_ghosts(uint8_t* type, int N) {
 
 // per-step halo: packets of the listed particles → contiguous [n×V4 pk0][n×V4 pk1] and back
 template <class T>
-__global__ void __launch_bounds__(256) k_halo_pack(const typename Vec4<T>::type* pk0, const typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_halo_pack(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                    const int* idx, int n, typename Vec4<T>::type* buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(256) k_halo_pack(const typename Vec4<T>::type*
     buf[n + k] = pk1[i];
 }
 template <class T>
-__global__ void __launch_bounds__(256) k_halo_unpack(typename Vec4<T>::type* pk0, typename Vec4<T>::type* pk1,
+__global__ void __launch_bounds__(256) k_halo_unpack(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                      const int* idx, int n, const typename Vec4<T>::type* buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
