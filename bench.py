@@ -18,9 +18,9 @@ Extra objects on the JSON line:
   roofline     — dominant kernel (k_neighbor_force): ALGORITHMIC bytes per launch ÷ its average launch
                  duration (HIP events on the engine's stream) against the 8 TB/s HBM peak.
                  Algorithmic bytes: (11·D+5)·4+2 = 154 B per particle-update = 77 B per
-                 particle per launch (two launches per update).  The kernel is VALU-bound by design
+                 particle per launch (two launches per update).  The kernel is bound by vector-ALU issue
                  (≈1.1 k distance tests + ≈174 pair evaluations per particle per launch), so `frac` is
-                 small; `valu` reports the companion figure against the fp32 vector peak.
+                 small; `valu` reports the binding resource from the committed counters of the shipped kernel.
   cpu_baseline — the CPU oracle (OpenMP restatement of the reference algorithm, fp64, "port") timed on
                  this box's host cores on a bounded sample of the same workload.
 """
@@ -34,28 +34,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: peak FP32 vector
 BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
-FLOP_PER_UPDATE_3D = 4.5e4       # SURVEY.md §8d estimate (2 passes × (≈1120 × 8 + ≈174 × 78))
+# vector-ALU issue peak of the data sheet: 256 CUs × 4 SIMD-32, one wave64 instruction per 2 cycles each at 2.4 GHz (= the
+# 157.3 TFLOP/s fp32 vector peak when every instruction is an FMA; MI355X_MICROARCH.md).  The SQ "busy" counter charges a
+# quad-cycle per instruction instead (measured issue cost of most of this kernel's instructions: tools/ubench/valu_rates2.hip).
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+TRAFFIC_RECORD = "profiles/r02_hbm_traffic.json"
+VALU_RECORD = "profiles/r02_valu_counters.json"
 
 
 def measured_traffic(n_local):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_final_hbm_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
-    plus WRITE_SIZE), scaled from the profiled particle count.  None when the record is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+    """Bytes per launch of the dominant kernel that leave the L2s, from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled — MI355X_MICROARCH.md's gfx950 correction, re-calibrated in the same passes on two kernels
+    of known traffic — plus WRITE_SIZE), scaled from the profiled particle count.  None when the record is missing."""
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(os.path.join(ROOT, TRAFFIC_RECORD)))
         return rec["bytes_per_particle_per_launch_corrected"] * n_local
     except Exception:
         return None
 
 
-def cpu_baseline(dp=0.0085, steps=160):
-    """Bounded CPU sample: same case at dp = 0.0085 (the reference example's own resolution,
-    ≈159 k particles), `steps` steps after a warm-up.  The restatement keeps the reference's nthreads full-length
+def valu_from_counters(n_local, kern_ms):
+    """The binding resource of the kernel, from COUNTERS (profiles/r02_valu_counters.json: SQ_INSTS_VALU and
+    SQ_ACTIVE_INST_VALU of the shipped kernel, rocprofv3 --pmc): vector instructions per launch scaled from the profiled
+    particle count ÷ the launch duration measured live, against the issue peak of the chip; `busy_frac_pmc` is the
+    fraction of SIMD cycles with a vector instruction executing in the profiled run itself."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, VALU_RECORD)))
+        f = rec["final"]
+        insts = 0.5 * (f["predictor"]["valu_insts"] + f["corrector"]["valu_insts"]) * n_local / rec["n_particles"]
+        rate = insts / (kern_ms * 1e-3) if kern_ms > 0 else 0.0
+        return {"wave_insts_per_launch": insts, "issue_rate": rate, "issue_peak": VALU_ISSUE_PEAK, "frac": rate / VALU_ISSUE_PEAK,
+                "busy_frac_pmc": 0.5 * (f["predictor"]["valu_busy_frac"] + f["corrector"]["valu_busy_frac"]),
+                "unit": "wave64 vector instructions/s", "source": VALU_RECORD}
+    except Exception:
+        return None
+
+
+def cpu_baseline(dp=0.00425, steps=12):
+    """Bounded CPU sample of THE BENCH WORKLOAD: the same 1.06 M-particle lattice (dp = 0.00425), `steps` steps after
+    the step that holds the one-off sort (≈15 s).  The restatement keeps the reference's nthreads full-length
     accumulator copies (src/PreProcess.jl:204-205), so more threads is not always faster: the thread count is
-    picked by a 2-step probe over {cores, cores/2, cores/4, 16, 8}."""
+    picked by a 1-step probe over {cores, cores/2, cores/4, 16, 8}."""
     from oracle.oracle import Oracle, make_oracle
     from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
     cores = min(os.cpu_count() or 1, Oracle.max_threads())
@@ -66,7 +86,7 @@ def cpu_baseline(dp=0.0085, steps=160):
     for t in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), min(16, cores), min(8, cores)}, reverse=True):
         o.set_threads(t)
         t0 = time.perf_counter()
-        o.advance(1e9, max_steps=2)
+        o.advance(1e9, max_steps=1)
         el = time.perf_counter() - t0
         if el < best_t:
             best, best_t = t, el
@@ -163,11 +183,10 @@ def main():
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
-                         "traffic_source": "profiles/r01_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                         "traffic_source": TRAFFIC_RECORD + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes leaving the L2s, Infinity-Cache hits included)",
                          "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "valu": {"achieved_tflops": FLOP_PER_UPDATE_3D / 2.0 * n_local / (kern_ms * 1e-3) / 1e12
-                                  if kern_ms > 0 else 0.0, "peak_tflops": FP32_PEAK_TFLOPS}},
+                         "valu": valu_from_counters(n_local, kern_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

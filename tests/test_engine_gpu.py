@@ -613,3 +613,43 @@ def test_async_output_delivers_the_same_snapshots(dam_break_2d):
         assert a[:3] == b[:3]
         for x, y in zip(a[3:], b[3:]):
             np.testing.assert_array_equal(x, y)
+
+
+def test_output_side_against_the_oracle_backed_driver(dam_break_2d_mdbc):
+    """SURVEY §8 row f3 against the ORACLE, not against the engine itself: the asynchronous, device-packed, n×3-padded
+    output of the HIP engine (sphmi_download_begin / _end + sphmi_set_output_components) equals, snapshot by snapshot,
+    what the same RunSimulation driver produces with the CPU oracle as backend and the padding done on the host —
+    positions, densities, pressures, ghost points, cells and the UniqueCells list of the grid export."""
+    import copy
+    from oracle.oracle import Oracle
+    from sphexample_amd.simulation import RunSimulation
+    p, s = dam_break_2d_mdbc
+    got = {}
+    for name, kw in (("gpu", dict(device_float_bytes=8, async_output=True)), ("cpu", dict(backend_factory=Oracle))):
+        meta = copy.deepcopy(s.SimMetaData)
+        meta.SimulationTime, meta.OutputTimes = 0.003, 0.001
+        q = p.copy()
+        snaps = []
+        RunSimulation(SimGeometry=None, SimMetaData=meta, SimConstants=s.SimConstants, SimKernel=s.SimKernel, SimLogger=None,
+                      SimParticles=q, SimViscosity=s.SimViscosity, SimDensityDiffusion=s.SimDensityDiffusion,
+                      on_output=lambda m, pp: snaps.append((m.OutputIterationCounter, m.Iteration, m.TotalTime, m.IndexCounter,
+                                                            {k: getattr(pp, k).copy() for k in ("ID", "Position", "Density", "Pressure", "GhostPoints", "Cells")})), **kw)
+        got[name] = snaps
+    assert len(got["gpu"]) == len(got["cpu"]) >= 4
+    for a, b in zip(got["gpu"][1:], got["cpu"][1:]):
+        assert a[:2] == b[:2] and a[3] == b[3]
+        assert a[2] == pytest.approx(b[2], rel=1e-12)
+        np.testing.assert_array_equal(a[4]["ID"], b[4]["ID"])            # same cell-sorted order (fp64 both sides)
+        np.testing.assert_array_equal(a[4]["Cells"], b[4]["Cells"])
+        for k in ("Position", "Density", "Pressure", "GhostPoints"):
+            assert relmax(a[4][k], b[4][k]) < 1e-9, k
+    # the VTKHDF point layout (2-D vectors padded to n×3 on the device) and the grid-cell list, engine vs oracle
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    eng, orc = make_engine(p, s, device_float_bytes=8), make_oracle(p, s)
+    eng.advance(1e9, max_steps=30); orc.advance(1e9, max_steps=30)
+    e3, o3 = eng.download(components=3), orc.download(components=3)
+    for k in ("Position", "Velocity", "Acceleration", "GhostPoints"):
+        assert e3[k].shape == o3[k].shape == (len(p), 3) and not e3[k][:, 2].any()
+        assert relmax(e3[k], o3[k]) < 1e-9, k
+    np.testing.assert_array_equal(eng.unique_cells(), orc.unique_cells())
