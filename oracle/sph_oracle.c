@@ -10,7 +10,10 @@
  * oracle/_ref.  Upstream's own tests (test/runtests.jl:6-16 and :18-75) pin only the time-step
  * criterion and an isolated particle; this restatement is checked against those two tests, the
  * closed-form two-particle values of SURVEY.md appendix A and an independent O(N^2) numpy
- * enumeration (tests/test_oracle.py).  All citations below are relative to /root/reference/.
+ * enumeration (tests/test_oracle.py).  The pin by the real reference is staged, not done: tools/dump_fixture.jl
+ * (Julia >= 1.11) writes its state after one output interval on five layouts to tests/golden/reference/ and
+ * tests/test_reference_fixtures.py checks THIS file against them; until someone runs it the status stays unpinned.
+ * All citations below are relative to /root/reference/.
  *
  * Each function names the reference lines it follows.  Known, documented deviation:
  *   Q5  the reference's end sentinel ParticleRanges[IndexCounter+1] = length(ParticleRanges) = N+2
