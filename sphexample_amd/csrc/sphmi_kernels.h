@@ -56,11 +56,21 @@ constexpr int kWave = 64;
 #define SPHMI_SEQ_BLOCKS 1
 #endif
 #ifndef SPHMI_QUEUE
-#define SPHMI_QUEUE 8           // per-lane queue of non-empty 32-candidate accept masks (entries; power of two)
+#define SPHMI_QUEUE 0           // per-lane queue of non-empty 32-candidate accept masks (entries); 0 = by kernel variant, below
 #endif
 #ifndef SPHMI_QUEUE_SLACK
-#define SPHMI_QUEUE_SLACK 4     // a full queue is consumed down to QUEUE − 1 − SLACK entries before scanning goes on
+#define SPHMI_QUEUE_SLACK 1     // a full queue is consumed down to QUEUE − 1 − SLACK entries before scanning goes on
 #endif
+// Queue depth.  A simulation of the queues on real tiles and the loop counters of the kernel agree: with 8
+// entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the pair-loop iterations (the bound set by the
+// lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.  LDS pays for the depth —
+// 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32): 8 → 1.013e9 /
+// –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
+// 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
+// The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
+template <class T, int PASS> constexpr int queue_entries() {
+    return SPHMI_QUEUE > 0 ? SPHMI_QUEUE : (sizeof(T) == 8 ? 16 : 12);
+}
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 // model tags (values of include/sphmi.h)
@@ -328,8 +338,8 @@ k_neighbor_force(const ForceParams<T> P) {
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    constexpr int QCAP = SPHMI_QUEUE;                      // per-lane queue of non-empty accept masks
-    static_assert((QCAP & (QCAP - 1)) == 0 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
+    constexpr int QCAP = queue_entries<T, PASS>();         // per-lane queue of non-empty accept masks
+    static_assert(QCAP >= 4 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
 
@@ -558,11 +568,13 @@ k_neighbor_force(const ForceParams<T> P) {
     unsigned long long st_it = 0, st_lane = 0, st_ref = 0, st_emp = 0, st_chunks = 0;
 #endif
     int work_it = 0, work_ch = 0;    // wave-uniform work counters (scalar unit): pair-loop iterations, chunks scanned
-    // this lane's queue: entries written / fetched so far, kept as BYTE offsets of the entry inside the lane's column
-    // (entry k of a lane sits k·64·8 bytes further: one v_and_or gives the address)
-    constexpr int kEntryStride = kWave * 8;
-    constexpr int kQMask = (QCAP - 1) * kEntryStride;
-    int wpos = 0, rpos = 0;
+    // this lane's queue: a ring of QCAP entries in the lane's LDS column (entry k sits k·64·8 bytes further).  waddr / raddr
+    // are the BYTE offsets of the next entry to write / fetch, wrapped with one subtract + unsigned min (QCAP need not be a
+    // power of two: LDS per wave decides it); qn counts the queued entries.
+    constexpr unsigned kEntryStride = kWave * 8, kQBytes = QCAP * kEntryStride;
+    auto q_next = [](unsigned a) -> unsigned { a += kEntryStride; const unsigned b = a - kQBytes; return b < a ? b : a; };
+    unsigned waddr = 0, raddr = 0;
+    int qn = 0;
     unsigned cbase = 0;              // record offset of the candidate at bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
     char* const s_qb = reinterpret_cast<char*>(s_q);
@@ -570,14 +582,13 @@ k_neighbor_force(const ForceParams<T> P) {
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
     // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
     auto run_pairs = [&](const int keep, const bool drain) {
-        const int wlim = wpos - keep * kEntryStride;     // (wpos is fixed during a burst)
         // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
-        bool more = rpos != wpos, have = cm != 0;
-        if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (rpos < wlim)) != 0) do {
+        bool more = qn != 0, have = cm != 0;
+        if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0) do {
             unsigned m = cm;
             if (!have & more) {                                  // fetch the next non-empty mask of MY queue
-                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + (rpos & kQMask));
-                m = ne.x; cbase = ne.y; rpos += kEntryStride;
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
+                m = ne.x; cbase = ne.y; raddr = q_next(raddr); qn -= 1;
             }
             cm = m & (m - 1);                                    // (0 stays 0)
             work_it += 1;
@@ -593,8 +604,8 @@ k_neighbor_force(const ForceParams<T> P) {
                 const bool a_is_i = (jr < cs_ar) | ((jr > a_r) & (jr < ce_ar));
                 pair(jr, n0, n1, a_is_i);
             }
-            more = rpos != wpos; have = cm != 0;
-        } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (rpos < wlim)) != 0);
+            more = qn != 0; have = cm != 0;
+        } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -657,7 +668,7 @@ k_neighbor_force(const ForceParams<T> P) {
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
             if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;
             // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
-            if (__builtin_amdgcn_ballot_w64((wpos - rpos) > (QCAP - 2) * kEntryStride) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
+            if (__builtin_amdgcn_ballot_w64(qn > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
             unsigned long long m = scan_chunk(cb, HI);
             work_ch += 1;
 #ifdef SPHMI_STATS
@@ -670,8 +681,8 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
             m = (w > 0) ? (m & rm) : 0ull;
             const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mlo, (unsigned)cb << kRecShift); wpos += kEntryStride; }
-            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + (wpos & kQMask)) = make_uint2(mhi, (unsigned)(cb + 32) << kRecShift); wpos += kEntryStride; }
+            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(mlo, (unsigned)cb << kRecShift); waddr = q_next(waddr); qn += 1; }
+            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(mhi, (unsigned)(cb + 32) << kRecShift); waddr = q_next(waddr); qn += 1; }
         }
     }
     run_pairs(0, true);
