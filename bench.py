@@ -126,12 +126,13 @@ def main():
     dp = args.dp or dp1 / (world ** (1.0 / 3.0))
     setup = setup_dam_break_3d(dp)
 
-    from sphexample_amd.engine import make_engine, rccl_unique_id
-    particles = dam_break_3d(dp)
-    n_total = len(particles)
+    from sphexample_amd.engine import dam_break_3d_count, make_engine, make_generated_dam_break_engine, rccl_unique_id
     info = None
     if world == 1 and not args.force_distributed:
-        eng = make_engine(particles, setup, device_float_bytes=4, device=local_rank)
+        # the lattice is generated ON THE DEVICE (sphmi_generate_dam_break_3d, SURVEY §8 f4: identical to the host generator's
+        # upload, tests/test_engine_gpu.py::test_device_side_case_generator) — nothing of it exists on the host
+        n_total = sum(dam_break_3d_count(dp))
+        eng = make_generated_dam_break_engine(dp, setup, device_float_bytes=4, device=local_rank)
         barrier = lambda: None  # noqa: E731
         reduce_max = lambda x: x  # noqa: E731
     else:
@@ -140,6 +141,8 @@ def main():
         # inside libsphmi.so on RCCL (csrc/sphmi_multi.h, sphmi_create_rank).  Every rank generates the deterministic
         # lattice and keeps its slab.
         import torch.distributed as dist
+        particles = dam_break_3d(dp)
+        n_total = len(particles)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -139,6 +139,18 @@ int sphmi_upload(sphmi_handle* h,
                  const void* density, const uint8_t* type, const int64_t* id,
                  const uint64_t* group_marker, const void* ghost_points);
 
+/*
+ * Pre-processing on the device for the case the headline is quoted on.  The reference builds
+ * SimParticles from CSV point lists (LoadSpecificCSV / AllocateDataStructures, src/PreProcess.jl:45-119) and ships the
+ * 3-D dam break only at Dp 0.02; sphmi_generate_dam_break_3d fills the handle with the lattice of that case at any
+ * spacing dp — same node set, order, IDs (1 … N, boundary first), Type / GroupMarker and hydrostatic densities as the
+ * files (and as the host generator the tests compare with) — without host arrays or an upload, and leaves the handle
+ * in the state sphmi_upload leaves it in.  cfg->n_particles must equal n_bound + n_fluid of sphmi_dam_break_3d_count;
+ * rho0, g, c0 come from the handle's config.  3-D single-device handles.
+ */
+int sphmi_dam_break_3d_count(double dp, int64_t* n_bound_out, int64_t* n_fluid_out);
+int sphmi_generate_dam_break_3d(sphmi_handle* h, double dp);
+
 /* Set / read SimMetaData.Iteration and SimMetaData.TotalTime (they live in the host struct). */
 int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
 

@@ -63,6 +63,7 @@ struct EngineBase {
     virtual void device_ptrs(void** pk0, void** pk1, int64_t* n) = 0;
     virtual void reset_count() = 0;
     virtual int64_t owned_count() { return cfg.n_particles; }
+    virtual void generate_dam_break_3d(double) { throw EngineError(SPHMI_ERR_STATE, "sphmi_generate_dam_break_3d: single-device handles only"); }
     // domain decomposition, verb by verb (slab handles only)
     [[noreturn]] static void not_a_slab() { throw EngineError(SPHMI_ERR_STATE, "not a slab handle: sphmi_dd_* verbs need a single-device handle"); }
     virtual void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) = 0;
@@ -730,6 +731,64 @@ struct Engine final : EngineBase {
         uploaded = true; stepped = false; have_grid = false; index_counter = 0;
     }
 
+    // ---- the bench lattice generated on the device (no host arrays, no upload) ---------------------
+    static int rnd(double x) { return (int)std::floor(x + 0.5); }
+    static DamBreakGrid dam_break_grid(double dp, const sphmi_config& c) {
+        DamBreakGrid G{};
+        G.nx = rnd(1.6 / dp) + 1; G.ny = rnd(0.66 / dp) + 1;
+        G.kwall = rnd(0.40 / dp); G.kcap = rnd(0.44 / dp); G.nk = std::max(G.kwall, G.kcap) + 1;
+        G.pi0 = rnd(0.90 / dp); G.pi1 = G.pi0 + rnd(0.12 / dp); G.pj0 = rnd(0.22 / dp); G.pj1 = G.pj0 + rnd(0.14 / dp);
+        G.fi = rnd(0.38 / dp) + 1; G.fj = rnd(0.62 / dp) + 1; G.fk = rnd(0.28 / dp) + 1;
+        G.dp = dp; G.rho0 = c.rho0; G.g = c.g; G.B = c.c0 * c.c0 * c.rho0 / 7.0;
+        return G;
+    }
+    void generate_dam_break_3d(double dp) override {
+        if (D != 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: the handle is not 3-D");
+        if (!(dp > 0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: dp must be positive");
+        HC(hipSetDevice(cfg.device));
+        const DamBreakGrid G = dam_break_grid(dp, cfg);
+        const long long M = (long long)G.nx * G.ny * G.nk;
+        const long long nf = (long long)G.fi * G.fj * G.fk;
+        if (M > (1ll << 31) - 4096) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: lattice too fine for one device");
+        int *flag = nullptr, *pos = nullptr, *tsum = nullptr, *tot_d = nullptr;
+        const int ntiles = (int)((M + kScanTile - 1) / kScanTile);
+        HC(hipMalloc(&flag, (size_t)M * 4)); HC(hipMalloc(&pos, (size_t)M * 4)); HC(hipMalloc(&tsum, (size_t)(ntiles + 2) * 4)); HC(hipMalloc(&tot_d, 16));
+        auto release = [&]() { (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(tsum); (void)hipFree(tot_d); };
+        try {
+            iA = 0; iH = 1; iB = 2; cur = 0;
+            int base = 0;
+            const unsigned nbM = (unsigned)((M + 255) / 256);
+            for (int which = 1; which <= 2; ++which) {              // the tank first, then the pillar object
+                HC(hipMemsetAsync(tot_d, 0, 16, stream));
+                hipLaunchKernelGGL(k_gen_flags, dim3(nbM), dim3(256), 0, stream, G, M, which, flag);
+                hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, (const int*)flag, pos, (int)M, tsum, tot_d);
+                hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, tot_d + 1);
+                hipLaunchKernelGGL(k_scan_add_nototal, dim3(ntiles), dim3(kScanThreads), 0, stream, pos, (int)M, (const int*)tsum);
+                int tot[2] = {0, 0};
+                HC(hipMemcpyAsync(tot, tot_d, 8, hipMemcpyDeviceToHost, stream));
+                HC(hipStreamSynchronize(stream));
+                if ((long long)base + tot[1] + nf > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: n_particles of the handle is smaller than the lattice (sphmi_dam_break_3d_count)");
+                hipLaunchKernelGGL(k_gen_boundary<T>, dim3(nbM), dim3(256), 0, stream, G, M, (const int*)flag, (const int*)pos, base, pk0[iA], pk1[iA],
+                                   type[cur], id[cur], grp[cur]);
+                HC(hipGetLastError());
+                base += tot[1];
+            }
+            if ((long long)base + nf != (long long)cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: n_particles of the handle differs from the lattice (sphmi_dam_break_3d_count)");
+            N = cap;
+            hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur]);
+            const size_t n = (size_t)N;
+            HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
+            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+            const int nb256 = (N + 255) / 256;
+            hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
+            hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d);
+            HC(hipGetLastError());
+            HC(hipStreamSynchronize(stream));
+        } catch (...) { release(); throw; }
+        release();
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
+    }
+
     template <class H> static void unpack3(const std::vector<V4>& s, H* out, int N, int D) {
         for (int i = 0; i < N; ++i) {
             out[i * D] = (H)s[i].x; out[i * D + 1] = (H)s[i].y;
@@ -1213,6 +1272,17 @@ int sphmi_rccl_unique_id(void* id_out) {
         return SPHMI_OK;
     } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
 }
+int sphmi_dam_break_3d_count(double dp, int64_t* n_bound_out, int64_t* n_fluid_out) {
+    if (!(dp > 0)) return SPHMI_ERR_ARGUMENT;
+    auto rnd = [](double x) { return (long long)std::floor(x + 0.5); };
+    const long long nx = rnd(1.6 / dp) + 1, ny = rnd(0.66 / dp) + 1, kwall = rnd(0.40 / dp), kcap = rnd(0.44 / dp);
+    const long long px = rnd(0.12 / dp) + 1, py = rnd(0.14 / dp) + 1;
+    auto perim = [](long long a, long long b) { return 2 * (a + b) - 4; };
+    if (n_bound_out) *n_bound_out = nx * ny - (px - 2) * (py - 2) + kwall * perim(nx, ny) + (kcap - 1) * perim(px, py) + px * py;
+    if (n_fluid_out) *n_fluid_out = (rnd(0.38 / dp) + 1) * (rnd(0.62 / dp) + 1) * (rnd(0.28 / dp) + 1);
+    return SPHMI_OK;
+}
+int sphmi_generate_dam_break_3d(sphmi_handle* h, double dp) { SPHMI_GUARD(h, h->e->generate_dam_break_3d(dp)); }
 int sphmi_owned_count(sphmi_handle* h, int64_t* n_out) {
     if (!n_out) return SPHMI_ERR_ARGUMENT;
     SPHMI_GUARD(h, *n_out = h->e->owned_count());

@@ -138,4 +138,27 @@ def make_engine(particles, setup, device_float_bytes: int = 4, device: int = 0, 
     return e
 
 
-__all__ = ["Engine", "make_engine", "load_library", "backend_info", "rccl_unique_id", "SphmiError", "SphmiMultiInfo"]
+def dam_break_3d_count(dp: float):
+    """(boundary, fluid) particles of the 3-D dam-break lattice at spacing dp (host formula of the library)."""
+    nb, nf = C.c_int64(), C.c_int64()
+    lib = load_library()
+    lib.sphmi_dam_break_3d_count.argtypes = [C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rc = lib.sphmi_dam_break_3d_count(dp, C.byref(nb), C.byref(nf))
+    if rc != OK:
+        raise SphmiError(rc, "sphmi_dam_break_3d_count")
+    return nb.value, nf.value
+
+
+def make_generated_dam_break_engine(dp: float, setup, device_float_bytes: int = 4, device: int = 0) -> Engine:
+    """the 3-D dam-break lattice generated ON THE DEVICE (sphmi_generate_dam_break_3d) — no host
+    arrays, no upload; the handle ends in the state make_engine(dam_break_3d(dp), setup) leaves it in."""
+    nb, nf = dam_break_3d_count(dp)
+    cfg = make_config(nb + nf, setup.SimConstants, setup.SimKernel, setup.SimMetaData, setup.SimViscosity,
+                      setup.SimDensityDiffusion, device_float_bytes=device_float_bytes, host_float_bytes=8, device=device)
+    e = Engine(cfg)
+    e._lib.sphmi_generate_dam_break_3d.argtypes = [C.c_void_p, C.c_double]
+    e._check(e._lib.sphmi_generate_dam_break_3d(e._h, dp))
+    return e
+
+
+__all__ = ["Engine", "make_engine", "make_generated_dam_break_engine", "dam_break_3d_count", "load_library", "backend_info", "rccl_unique_id", "SphmiError", "SphmiMultiInfo"]

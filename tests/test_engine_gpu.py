@@ -653,3 +653,27 @@ def test_output_side_against_the_oracle_backed_driver(dam_break_2d_mdbc):
         assert e3[k].shape == o3[k].shape == (len(p), 3) and not e3[k][:, 2].any()
         assert relmax(e3[k], o3[k]) < 1e-9, k
     np.testing.assert_array_equal(eng.unique_cells(), orc.unique_cells())
+
+
+@pytest.mark.parametrize("dp,fb", [(0.02, 8), (0.02, 4), (0.0085, 4)])
+def test_device_side_case_generator(dp, fb):
+    """sphmi_generate_dam_break_3d builds the lattice on the device — same particles, order, IDs, types,
+    densities as the host generator (which reproduces the reference's shipped Dp0.02 files, test_host_logic.py), and the
+    run that follows is the run of the uploaded case."""
+    from sphexample_amd.engine import dam_break_3d_count, make_engine, make_generated_dam_break_engine
+    p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
+    nb, nf = dam_break_3d_count(dp)
+    assert nb + nf == len(p) and nf == int((p.Type == 1).sum())
+    up, gen = make_engine(p, s, device_float_bytes=fb), make_generated_dam_break_engine(dp, s, device_float_bytes=fb)
+    a, b = up.download(), gen.download()
+    for k in ("ID", "Type", "GroupMarker", "Velocity", "Acceleration"):
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_array_equal(a["Position"], b["Position"])
+    np.testing.assert_allclose(b["Density"], a["Density"], rtol=1e-7 if fb == 4 else 1e-15, atol=0)
+    np.testing.assert_allclose(b["Pressure"], a["Pressure"], rtol=0, atol=(1e-4 if fb == 4 else 1e-9) * np.abs(a["Pressure"]).max())
+    pa, pb = up.advance(1e9, max_steps=12), gen.advance(1e9, max_steps=12)
+    assert (pa.iteration, pa.n_rebuilds) == (pb.iteration, pb.n_rebuilds)
+    assert pb.total_time == pytest.approx(pa.total_time, rel=1e-6 if fb == 4 else 1e-12)
+    a, b = by_id(up.download()), by_id(gen.download())
+    assert relmax(b["Density"], a["Density"]) < (1e-6 if fb == 4 else 1e-12)
+    assert relmax(b["Position"], a["Position"]) < (1e-6 if fb == 4 else 1e-12)
