@@ -119,7 +119,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libsphmi has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU is the contract.  With MORE ranks than GPUs (the one-GPU test box: `torchrun --nproc-per-node 2
+    # bench.py --gpus 2` exercises this file's multi-rank path end to end) the ranks share devices, which RCCL refuses:
+    # the slab driver then talks through its host shared-memory transport (SPHMI_TRANSPORT=shm) and the line says so.
+    n_dev = torch.cuda.device_count()
+    device = local_rank % n_dev
+    if world > n_dev:
+        os.environ.setdefault("SPHMI_TRANSPORT", "shm")
+    torch.cuda.set_device(device)
 
     from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
     dp1 = 0.00425
@@ -132,7 +139,7 @@ def main():
         # the lattice is generated ON THE DEVICE (sphmi_generate_dam_break_3d, SURVEY §8 f4: identical to the host generator's
         # upload, tests/test_engine_gpu.py::test_device_side_case_generator) — nothing of it exists on the host
         n_total = sum(dam_break_3d_count(dp))
-        eng = make_generated_dam_break_engine(dp, setup, device_float_bytes=4, device=local_rank)
+        eng = make_generated_dam_break_engine(dp, setup, device_float_bytes=4, device=device)
         barrier = lambda: None  # noqa: E731
         reduce_max = lambda x: x  # noqa: E731
     else:
@@ -148,7 +155,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         uid = [rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        eng = make_engine(particles, setup, device_float_bytes=4, device=local_rank, rank=rank, world=world, unique_id=uid[0])
+        eng = make_engine(particles, setup, device_float_bytes=4, device=device, rank=rank, world=world, unique_id=uid[0])
         info = eng.multi_info()
         barrier = dist.barrier
 
@@ -181,8 +188,10 @@ def main():
                                    f"example/Dambreak3d.jl parameters, fp32 kernels",
                        "particles": n_total, "particles_per_gpu": n_local,
                        "parallelism": "single GPU" if world == 1 else
-                       f"{'xyz'[info.axis]}-slab domain decomposition x{world} inside libsphmi.so, 1-cell halo over RCCL "
-                       f"(ncclSend/ncclRecv between slab neighbours + one 4-word ncclAllReduce per step), interior tiles overlap the exchange",
+                       f"{'xyz'[info.axis]}-slab domain decomposition x{world} inside libsphmi.so, 1-cell halo over " +
+                       ("RCCL (ncclSend/ncclRecv between slab neighbours + one 4-word ncclAllReduce per step), interior tiles overlap the exchange"
+                        if info.transport == 1 else
+                        f"the HOST SHARED-MEMORY test transport ({world} ranks on {n_dev} GPU(s): not a multi-GPU measurement)"),
                        "rebuilds_in_window": int(prog.n_rebuilds), "sim_time": prog.total_time},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),

@@ -244,20 +244,28 @@ int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int
  * processes (torchrun: one process per GPU).  Every process passes the SAME full particle set to sphmi_upload and keeps
  * its slab; sphmi_download then returns the particles this process owns (sphmi_owned_count of them, at most
  * cfg->n_particles).  `unique_id`: the 128 bytes sphmi_rccl_unique_id produced on rank 0, distributed by the launcher
- * (a file, MPI, torch.distributed's store …).  cfg->device is this rank's GPU. */
+ * (a file, MPI, torch.distributed's store …).  cfg->device is this rank's GPU.
+ * SPHMI_TRANSPORT=shm in the environment puts the peers behind a POSIX shared-memory segment of the node instead of
+ * RCCL (messages and reductions staged through the host, csrc/sphmi_shm.h): RCCL refuses two ranks on one device, so
+ * this is how the rank-mode driver runs — and is tested — with more ranks than GPUs.  Every wait has a deadline
+ * (SPHMI_SHM_TIMEOUT seconds, default 120). */
 int sphmi_rccl_unique_id(void* id_out /* 128 bytes */);
 int sphmi_create_rank(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out);
 int sphmi_owned_count(sphmi_handle* h, int64_t* n_out);   /* particles sphmi_download returns (any handle)        */
 typedef struct sphmi_multi_info {
     int32_t world, n_local;        /* slabs in total / held by this handle                                         */
     int32_t axis, halo_width;      /* slab axis (0 = x …); ghost-layer width in cell columns (1; 2 + off with mDBC) */
-    int32_t transport;             /* 0 = stream-ordered device copies, 1 = RCCL                                    */
+    int32_t transport;             /* 0 = stream-ordered device copies, 1 = RCCL, 2 = host shared memory (below)    */
     int32_t reserved;
     int64_t n_recuts;              /* rebuilds at which the cuts moved (load balance by work)                        */
     int64_t cuts[SPHMI_MAX_DEVICES];    /* cuts[r-1] = first cell column of slab r                                  */
     int64_t n_live[SPHMI_MAX_DEVICES];  /* particles incl. ghost copies currently held per local slab               */
 } sphmi_multi_info;
 int sphmi_multi_info_get(sphmi_handle* h, sphmi_multi_info* out);
+/* Test hook, no device needed: rank `rank` of `world` processes attaches to the shared-memory transport keyed by
+ * `unique_id` (128 bytes, the same in every process), runs SUM / MAX reductions of known vectors and a neighbour
+ * exchange of `n_bytes` per direction with known patterns, and checks what arrives.  0 = everything matched. */
+int sphmi_shm_selftest(const void* unique_id, int32_t rank, int32_t world, int64_t n_bytes);
 /* Test hook: start from these cuts (world-1 first columns) instead of the balanced ones; call before sphmi_upload. */
 int sphmi_multi_set_cuts(sphmi_handle* h, const int64_t* cuts, int32_t n);
 /* Host-only planning (no device needed; CPU tests): slab axis, cuts, halo width, owned particles and capacity per

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsphmi.so")
 SOURCES = ["sphmi_engine.hip"]
-HEADERS = ["sphmi_kernels.h", "sphmi_rebuild.h", os.path.join("..", "..", "include", "sphmi.h")]
+HEADERS = ["sphmi_kernels.h", "sphmi_rebuild.h", "sphmi_multi.h", "sphmi_shm.h", os.path.join("..", "..", "include", "sphmi.h")]
 
 
 def hipcc() -> str:

@@ -1272,6 +1272,41 @@ int sphmi_rccl_unique_id(void* id_out) {
         return SPHMI_OK;
     } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
 }
+int sphmi_shm_selftest(const void* unique_id, int32_t rank, int32_t world, int64_t n_bytes) {
+    using namespace sphmi;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world || n_bytes < 0) return SPHMI_ERR_ARGUMENT;
+    try {
+        ShmWorld w(unique_id, 128, rank, world);
+        // reductions: a vector longer than one reduce slot, SUM and MAX
+        const size_t n = ShmWorld::kReduceWords + 37;
+        std::vector<int64_t> v(n), u(n);
+        for (size_t k = 0; k < n; ++k) { v[k] = (int64_t)(k % 101) * (rank + 1); u[k] = (int64_t)((k * 7 + (size_t)rank * 13) % 1009); }
+        w.allreduce(v.data(), n, ShmWorld::SUM);
+        w.allreduce(u.data(), n, ShmWorld::MAX);
+        for (size_t k = 0; k < n; ++k) {
+            if (v[k] != (int64_t)(k % 101) * world * (world + 1) / 2) { g_create_error = "shm selftest: SUM mismatch"; return SPHMI_ERR_STATE; }
+            int64_t m = 0; for (int r = 0; r < world; ++r) m = std::max<int64_t>(m, (int64_t)((k * 7 + (size_t)r * 13) % 1009));
+            if (u[k] != m) { g_create_error = "shm selftest: MAX mismatch"; return SPHMI_ERR_STATE; }
+        }
+        // neighbour exchange: two rounds, n_bytes per direction (longer than a ring when the caller asks for it)
+        auto pat = [](int from, int to, int round, size_t i) { return (char)((i * 31 + (size_t)from * 7 + (size_t)to * 3 + (size_t)round) & 0xff); };
+        for (int round = 0; round < 2; ++round) {
+            const size_t nb = (size_t)n_bytes + (size_t)round;
+            std::vector<char> sl(nb), sr(nb), rl(nb), rr(nb);
+            for (size_t i = 0; i < nb; ++i) { sl[i] = pat(rank, rank - 1, round, i); sr[i] = pat(rank, rank + 1, round, i); }
+            std::vector<ShmWorld::Xfer> x;
+            if (rank > 0) { x.push_back({true, 0, sl.data(), nb, 0}); x.push_back({false, 0, rl.data(), nb, 0}); }
+            if (rank < world - 1) { x.push_back({true, 1, sr.data(), nb, 0}); x.push_back({false, 1, rr.data(), nb, 0}); }
+            w.exchange(x);
+            for (size_t i = 0; i < nb; ++i) {
+                if (rank > 0 && rl[i] != pat(rank - 1, rank, round, i)) { g_create_error = "shm selftest: message from the left differs"; return SPHMI_ERR_STATE; }
+                if (rank < world - 1 && rr[i] != pat(rank + 1, rank, round, i)) { g_create_error = "shm selftest: message from the right differs"; return SPHMI_ERR_STATE; }
+            }
+        }
+        w.barrier();
+        return SPHMI_OK;
+    } catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_DEVICE; }
+}
 int sphmi_dam_break_3d_count(double dp, int64_t* n_bound_out, int64_t* n_fluid_out) {
     if (!(dp > 0)) return SPHMI_ERR_ARGUMENT;
     auto rnd = [](double x) { return (long long)std::floor(x + 0.5); };

@@ -16,13 +16,17 @@
 //
 // Transport: RCCL (ncclSend / ncclRecv between slab neighbours — each a direct xGMI link — and one ncclAllReduce of
 // four uint64 bit patterns per step), bound at run time from librccl.so.1; or, when the ranks of ONE process share a
-// device (the single-GPU test configuration) or SPHMI_TRANSPORT=local, stream-ordered device copies.
+// device (the single-GPU test configuration) or SPHMI_TRANSPORT=local, stream-ordered device copies; or, for
+// sphmi_create_rank with SPHMI_TRANSPORT=shm, host staging through a shared-memory segment (sphmi_shm.h: processes that
+// share a GPU — RCCL refuses that — run the rank-mode driver unchanged; a bring-up / test transport, nothing overlaps).
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <memory>
 #include <numeric>
+
+#include "sphmi_shm.h"
 
 namespace sphmi {
 
@@ -373,6 +377,22 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// a page-locked host buffer that only grows (staging of the shm transport)
+struct HostBuf {
+    char* p = nullptr; size_t cap = 0;
+    char* need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void**)&p, want) != hipSuccess) throw EngineError(SPHMI_ERR_DEVICE, "hipHostMalloc failed (shm transport staging)");
+            cap = want;
+        }
+        return p;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // one point-to-point message of a phase (global ranks; buffers are device memory of the local end(s))
 struct Msg { int src, dst; const void* sbuf; void* rbuf; size_t bytes; int slot; };   // slot: which persistent buffer pair (WAR tracking of the local transport)
 
@@ -404,6 +424,9 @@ struct MultiEngine final : EngineBase {
     std::vector<Rank> R;               // the LOCAL ones (all of them in one-process mode, one in rank mode)
     bool rank_mode = false;            // one local slab, peers in other processes
     bool use_rccl = false;
+    std::unique_ptr<ShmWorld> shm;     // rank mode with SPHMI_TRANSPORT=shm: peers behind a shared-memory segment instead of RCCL
+    HostBuf stage_s, stage_r;
+    unsigned long long* red_h = nullptr;
     int D = 0, axis = 0, halo_width = 1;
     SlabPlan plan;
     bool overlap = true, moving = false, have_halo = false;
@@ -438,8 +461,15 @@ struct MultiEngine final : EngineBase {
         for (auto& r : R) if (r.device < 0 || r.device >= ndev) throw EngineError(SPHMI_ERR_ARGUMENT, "device ordinal out of range");
         const char* tr = getenv("SPHMI_TRANSPORT");
         // (a one-rank world under sphmi_create_rank still runs its allreduce through RCCL: the binding is exercised)
-        use_rccl = rank_mode || (world > 1 && !shared_device && !(tr && !strcmp(tr, "local")));
+        const bool want_shm = tr && !strcmp(tr, "shm");
+        if (want_shm && !rank_mode) throw EngineError(SPHMI_ERR_ARGUMENT, "SPHMI_TRANSPORT=shm is the transport of sphmi_create_rank (one slab per process)");
+        use_rccl = (rank_mode && !want_shm) || (!rank_mode && world > 1 && !shared_device && !(tr && !strcmp(tr, "local")));
         if (tr && !strcmp(tr, "rccl") && shared_device) throw EngineError(SPHMI_ERR_ARGUMENT, "RCCL cannot run two ranks on one device");
+        if (want_shm) {
+            if (!unique_id) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_create_rank: null unique id");
+            shm.reset(new ShmWorld(unique_id, 128, my_rank, world));
+            HC(hipHostMalloc((void**)&red_h, 4 * 8));
+        }
         if (use_rccl) {
             Rccl& N = Rccl::get();
             if (rank_mode) {
@@ -483,6 +513,8 @@ struct MultiEngine final : EngineBase {
             if (r.side) { (void)hipStreamSynchronize(r.side); }
             if (r.comm) { try { Rccl::get().CommDestroy(r.comm); } catch (...) {} }
             for (auto& h : r.halo) for (DevBuf* b : {&h.send_l, &h.send_r, &h.slot_l, &h.slot_r, &h.sb_l, &h.sb_r, &h.rb_l, &h.rb_r}) b->release();
+            stage_s.release(); stage_r.release();
+            if (red_h) { (void)hipHostFree(red_h); red_h = nullptr; }
             for (DevBuf* b : {&r.cx, &r.flag, &r.pos, &r.idx[0], &r.idx[1], &r.idx[2], &r.idx[3], &r.rec_s[0], &r.rec_s[1], &r.rec_r[0], &r.rec_r[1], &r.cost}) b->release();
             (void)hipFree(r.T2); (void)hipFree(r.M); (void)hipFree(r.stage); (void)hipFree(r.mm_d); (void)hipHostFree(r.mm_h); (void)hipHostFree(r.cnt_h);
             if (r.ev_pack) { (void)hipEventDestroy(r.ev_pack); (void)hipEventDestroy(r.ev_edge); (void)hipEventDestroy(r.ev_red); }
@@ -506,6 +538,7 @@ struct MultiEngine final : EngineBase {
             return;
         }
         if (world == 1) return;
+        if (shm) { shm->allreduce((int64_t*)v.data(), (size_t)n, op == OP_SUM ? ShmWorld::SUM : ShmWorld::MAX); return; }
         Rank& r = R[0];
         HC(hipSetDevice(r.device));
         void* d = r.cost.need((size_t)n * 8);
@@ -525,6 +558,15 @@ struct MultiEngine final : EngineBase {
         }
         if (world == 1) return;
         Rank& r = R[0];
+        if (shm) {
+            long long out[2] = {to_l[0], to_r[0]}, in[2] = {0, 0};
+            std::vector<ShmWorld::Xfer> x;
+            if (r.has_left) { x.push_back({true, 0, (char*)&out[0], 8, 0}); x.push_back({false, 0, (char*)&in[0], 8, 0}); }
+            if (r.has_right) { x.push_back({true, 1, (char*)&out[1], 8, 0}); x.push_back({false, 1, (char*)&in[1], 8, 0}); }
+            shm->exchange(x);
+            from_l[0] = in[0]; from_r[0] = in[1];
+            return;
+        }
         HC(hipSetDevice(r.device));
         long long* d = (long long*)r.cost.need(4 * 8);
         r.cnt_h[0] = to_l[0]; r.cnt_h[1] = to_r[0]; r.cnt_h[2] = 0; r.cnt_h[3] = 0;
@@ -544,6 +586,29 @@ struct MultiEngine final : EngineBase {
     // (and whatever the caller queues behind them) go to the side streams, so that the interior launch on main overlaps.
     void exchange(const std::vector<Msg>& msgs, bool side) {
         if (msgs.empty()) return;
+        if (shm) {
+            // device → page-locked host → shared-memory ring → peer's host → peer's device, on the stream the phase runs on
+            Rank& r = R[0];
+            hipStream_t q = side ? r.side : r.main;
+            HC(hipSetDevice(r.device));
+            size_t tot_s = 0, tot_r = 0;
+            for (const Msg& m : msgs) { if (m.src == r.rank) tot_s += m.bytes; if (m.dst == r.rank) tot_r += m.bytes; }
+            char* hs = stage_s.need(tot_s + 1); char* hr = stage_r.need(tot_r + 1);
+            size_t os = 0, orr = 0;
+            for (const Msg& m : msgs) if (m.src == r.rank && m.bytes) { HC(hipMemcpyAsync(hs + os, m.sbuf, m.bytes, hipMemcpyDeviceToHost, q)); os += m.bytes; }
+            HC(hipStreamSynchronize(q));
+            std::vector<ShmWorld::Xfer> x;
+            os = 0;
+            for (const Msg& m : msgs) {
+                if (m.src == r.rank) { x.push_back({true, m.dst > r.rank ? 1 : 0, hs + os, m.bytes, 0}); os += m.bytes; }
+                if (m.dst == r.rank) { x.push_back({false, m.src > r.rank ? 1 : 0, hr + orr, m.bytes, 0}); orr += m.bytes; }
+            }
+            shm->exchange(x);
+            orr = 0;
+            for (const Msg& m : msgs) if (m.dst == r.rank && m.bytes) { HC(hipMemcpyAsync(m.rbuf, hr + orr, m.bytes, hipMemcpyHostToDevice, q)); orr += m.bytes; }
+            HC(hipStreamSynchronize(q));                                  // the staging buffers serve the next phase
+            return;
+        }
         if (use_rccl) {
             Rccl& N = Rccl::get();
             NC(N.GroupStart());
@@ -567,7 +632,7 @@ struct MultiEngine final : EngineBase {
         }
     }
     void wait_consumed(Rank& r, int slot) {
-        if (!use_rccl && r.consumed_valid[slot]) { HC(hipStreamWaitEvent(r.main, r.ev_consumed[slot], 0)); r.consumed_valid[slot] = false; }
+        if (!use_rccl && !shm && r.consumed_valid[slot]) { HC(hipStreamWaitEvent(r.main, r.ev_consumed[slot], 0)); r.consumed_valid[slot] = false; }
     }
 
     // ---- upload: split the particle set, one slab engine per local rank ------------------------------------------
@@ -918,6 +983,14 @@ struct MultiEngine final : EngineBase {
             for (auto& r : R) { HC(hipSetDevice(r.device)); NC(N.AllReduce(r.T2 + 4 * p, r.T2 + 4 * p, 4, ncclUint64, ncclMax, r.comm, r.main)); }
             NC(N.GroupEnd());
         }
+        if (shm) {
+            Rank& r = R[0];
+            HC(hipMemcpyAsync(red_h, r.T2 + 4 * p, 32, hipMemcpyDeviceToHost, r.main));
+            HC(hipStreamSynchronize(r.main));
+            shm->allreduce((int64_t*)red_h, 4, ShmWorld::MAXU);
+            HC(hipMemcpyAsync(r.T2 + 4 * p, red_h, 32, hipMemcpyHostToDevice, r.main));
+            HC(hipStreamSynchronize(r.main));
+        }
         for (auto& r : R) {
             HC(hipSetDevice(r.device));
             RedPtrs P{}; P.n = 0;
@@ -1099,7 +1172,7 @@ struct MultiEngine final : EngineBase {
     void multi_info(sphmi_multi_info* o) {
         memset(o, 0, sizeof *o);
         o->world = world; o->n_local = (int32_t)R.size(); o->axis = axis; o->halo_width = halo_width; o->n_recuts = n_recuts;
-        o->transport = use_rccl ? 1 : 0;
+        o->transport = shm ? 2 : (use_rccl ? 1 : 0);
         for (int r = 1; r < world && r < 16; ++r) o->cuts[r - 1] = plan.world() == world ? plan.lo[r] : 0;
         for (auto& r : R) if (r.e && r.rank < 16) o->n_live[r.rank] = r.e->N;
     }
