@@ -144,7 +144,7 @@ struct Engine final : EngineBase {
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
     // measured (both with the order from measured work): 108 tiles 4 > 2 > 1; 2481 … 6344 tiles 2 > 1 (+6 … +2 %);
     // 10512 tiles 2 = 1; 14032 / 16528 / 24676 tiles 1 > 2 (+3 / +5 / +7 %)
-    static constexpr int kWptSmall = 1024, kWptMedium = 10000;
+    static constexpr int kWptTiny = 512, kWptSmall = 1024, kWptMedium = 10000;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -174,7 +174,7 @@ struct Engine final : EngineBase {
         if (c.device < 0 || c.device >= ndev) throw EngineError(SPHMI_ERR_ARGUMENT, "device ordinal out of range");
         HC(hipSetDevice(c.device));
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) force_wpt = v; }
+        if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) force_wpt = v; }
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
         if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
@@ -196,7 +196,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4)); HC(hipMalloc(&tile_work1_d, nt * 4));
         if (cfg.kernel_output == SPHMI_KOUT_STORE) { HC(hipMalloc(&kout_d, n * sizeof(V4))); HC(hipMemset(kout_d, 0, n * sizeof(V4))); }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
-        HC(hipMalloc(&trace_d, nt * 16)); HC(hipMemset(trace_d, 0, nt * 16));
+        HC(hipMalloc(&trace_d, nt * 32)); HC(hipMemset(trace_d, 0, nt * 32));
 #endif
         HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
         HC(hipMalloc(&ctrl_d, sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
@@ -224,7 +224,7 @@ struct Engine final : EngineBase {
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         if (trace_d) {   // experiment build: start / end clock of every tile of the LAST launch → $SPHMI_TRACE_FILE
             const char* fn = getenv("SPHMI_TRACE_FILE");
-            std::vector<unsigned long long> tr((size_t)(cap / kWave + 2) * 2);
+            std::vector<unsigned long long> tr((size_t)(cap / kWave + 2) * 4);
             if (fn && hipMemcpy(tr.data(), trace_d, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                 FILE* f = fopen(fn, "wb");
                 if (f) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
@@ -351,7 +351,7 @@ struct Engine final : EngineBase {
         // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip (per list: the
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
         const int ntile = list_tiles[list];        // fixed at the rebuild: the choice must not follow the measured run lengths
-        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1));
+        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptTiny ? 8 : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1)));
         bool resched_after = false;
         if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && batch_step == 0) {
             // (the first step of a batch executes unless the batch starts with a rebuild request; then nothing is
@@ -380,7 +380,8 @@ struct Engine final : EngineBase {
             P.tile_work = tile_work1_d;
             sched1_state = 0; resched1_pending = true;
         }
-        if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
+        if (wpt == 8) launch_force_wpt<PASS, MODEL, 8>(P, list);
+        else if (wpt == 4) launch_force_wpt<PASS, MODEL, 4>(P, list);
         else if (wpt == 2) launch_force_wpt<PASS, MODEL, 2>(P, list);
         else launch_force_wpt<PASS, MODEL, 1>(P, list);
     }

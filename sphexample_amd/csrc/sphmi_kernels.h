@@ -68,8 +68,9 @@ constexpr int kWave = 64;
 // –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
 // 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
 // The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
-template <class T, int PASS> constexpr int queue_entries() {
-    return SPHMI_QUEUE > 0 ? SPHMI_QUEUE : (sizeof(T) == 8 ? 16 : 12);
+// Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues.
+template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
+    return SPHMI_QUEUE > 0 ? SPHMI_QUEUE : (WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12));
 }
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
@@ -100,30 +101,35 @@ struct StepCtrl {
 // one thread: the per-step decisions of Δt (src/TimeStepping.jl:30-43) and update_delta_x! on the reduction slots the
 // previous corrector filled (bit patterns of non-negative values)
 template <class T>
-__global__ void k_step_control(unsigned long long* red, StepCtrl* c, double h, double c0, double CFL) {
-    if (c->stop || c->error || c->need_rebuild) { c->active = 0; return; }
-    if (!c->resume) {
-        if (!(c->total_time <= c->t_target) || (c->max_steps >= 0 && c->steps_done >= c->max_steps)) { c->stop = 1; c->active = 0; return; }
+__global__ void k_step_control(unsigned long long* red, StepCtrl* cp, double h, double c0, double CFL) {
+    // everything the decision needs is requested at once (one round trip instead of a chain of dependent ones: the kernel
+    // is a single thread, and a step of a small case is three launches of which this is the shortest — 4.4 → ≈2.5 µs)
+    StepCtrl c = *cp;
+    const unsigned long long r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+    if (c.stop || c.error || c.need_rebuild) { cp->active = 0; return; }
+    if (!c.resume) {
+        if (!(c.total_time <= c.t_target) || (c.max_steps >= 0 && c.steps_done >= c.max_steps)) { cp->stop = 1; cp->active = 0; return; }
         auto dec = [](unsigned long long b) -> double {
             if constexpr (sizeof(T) == 4) return (double)__uint_as_float((unsigned)b); else return __longlong_as_double((long long)b);
         };
-        if (red[3]) { c->error = 2; c->active = 0; return; }
-        const double maxdisp = sqrt(dec(red[0])), visc = dec(red[1]), amax = sqrt(dec(red[2]));
-        c->delta_x += 4.0 * maxdisp;
+        if (r3) { cp->error = 2; cp->active = 0; return; }
+        const double maxdisp = sqrt(dec(r0)), visc = dec(r1), amax = sqrt(dec(r2));
+        c.delta_x += 4.0 * maxdisp;
         const double dt1 = sqrt(h / amax), dt2 = h / (c0 + visc);
         const double dt = CFL * (dt1 < dt2 ? dt1 : dt2);
-        c->last_visc = visc; c->last_amax = amax;
-        c->dt = dt; c->dt2 = dt * 0.5;
-        if (!(dt > 0.0) || dt != dt || c->delta_x != c->delta_x) { c->error = 1; c->active = 0; return; }
-        if (c->delta_x >= h) { c->need_rebuild = 1; c->resume = 1; c->active = 0; return; }
+        c.last_visc = visc; c.last_amax = amax;
+        c.dt = dt; c.dt2 = dt * 0.5;
+        if (!(dt > 0.0) || dt != dt || c.delta_x != c.delta_x) { c.error = 1; c.active = 0; *cp = c; return; }
+        if (c.delta_x >= h) { c.need_rebuild = 1; c.resume = 1; c.active = 0; *cp = c; return; }
     }
-    c->resume = 0;
+    c.resume = 0;
     red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0;
-    c->t_step_start = c->total_time;
-    c->total_time += c->dt;                                 // UpdateMetaData!, :679-685 (nothing reads it before the
-    c->steps_done += 1;                                     // next control kernel except through t_step_start)
-    c->last_dt = c->dt;
-    c->active = 1;
+    c.t_step_start = c.total_time;
+    c.total_time += c.dt;                                   // UpdateMetaData!, :679-685 (nothing reads it before the
+    c.steps_done += 1;                                      // next control kernel except through t_step_start)
+    c.last_dt = c.dt;
+    c.active = 1;
+    *cp = c;
 }
 
 template <class T>
@@ -320,9 +326,9 @@ __device__ __forceinline__ void wave_sync() {
 // uniform branches per pair; kModelDefault = ArtificialViscosity + LinearDensityDiffusion, what every stock
 // example but one uses).  MODEL < 0: the tags are read from the parameter block at run time (all other
 // combinations: Laminar / LaminarSPS, ZeroGravityLinear / Complex diffusion, PlanarShifting).
-// WPT: waves per tile.  The waves of a workgroup share the tile's 64 targets and split its candidate chunks
-// (chunk c of a row goes to wave (c + row) % WPT); wave 0 adds the partial sums in wave order and runs the
-// epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
+// WPT: waves per tile (1, 2, 4, 8).  The waves of a workgroup share the tile's 64 targets and split its candidate chunks
+// round-robin over ALL rows (chunk c of a row whose predecessors hold g chunks goes to wave (g + c) % WPT: the waves'
+// chunk counts differ by one at most); wave 0 adds the partial sums in wave order and runs the epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
 // last round of a 1 M-particle launch) shorter-lived waves keep the SIMDs filled.
 // TPB: tiles per block (WPT = 1 only).  The TPB waves of a workgroup take TPB consecutive entries of the XCD's run —
 // neighbouring tiles, whose candidate rows overlap by three quarters — and run on the four SIMDs of ONE compute unit,
@@ -331,6 +337,9 @@ template <class T, int D, int PASS, int MODEL, int WPT, int TPB = 1>
 __global__ void __launch_bounds__(kWave * WPT * TPB)
 k_neighbor_force(const ForceParams<T> P) {
     static_assert(TPB == 1 || WPT == 1, "several tiles per block only with one wave per tile");
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     if (P.ctrl && !P.ctrl->active) return;                 // a queued step that the control kernel cancelled
     const T step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt, step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
     const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;
@@ -338,7 +347,7 @@ k_neighbor_force(const ForceParams<T> P) {
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    constexpr int QCAP = queue_entries<T, PASS>();         // per-lane queue of non-empty accept masks
+    constexpr int QCAP = queue_entries<T, PASS, WPT>();         // per-lane queue of non-empty accept masks
     static_assert(QCAP >= 4 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
@@ -651,18 +660,51 @@ k_neighbor_force(const ForceParams<T> P) {
         return ((unsigned long long)W[1] << 32) | W[0];
     };
 
+    int g0 = 0;                      // WPT > 1: chunks of the rows before this one, mod WPT (wave-uniform)
+    auto row_offset = [&](const int seg) { return (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp : (seg - 1) * P.nxp; };
+    // Several waves per tile = a case too small to hide latency behind other waves: a lone wave pays the round trip of
+    // every row's range look-up one after the other (≈0.8 µs each; tools/trace_small.py).  The waves of the tile need the
+    // same ranges: they fetch them TOGETHER — row s by wave s % WPT, all requests in flight at once — and share them in LDS.
+#ifndef SPHMI_RNG_MIN_WPT
+#define SPHMI_RNG_MIN_WPT 4
+#endif
+#ifndef SPHMI_RR_MIN_WPT
+#define SPHMI_RR_MIN_WPT 4
+#endif
+    constexpr bool kShareRanges = WPT >= SPHMI_RNG_MIN_WPT && WPT > 1;
+    __shared__ int2 s_rng[kShareRanges ? NSEG * kWave : 1];
+    if constexpr (kShareRanges) {
+#pragma unroll
+        for (int k = 0; k < (NSEG + WPT - 1) / WPT; ++k) {
+            const int seg = wv + k * WPT;
+            if (seg < NSEG) {
+                const int off = row_offset(seg);
+                s_rng[seg * kWave + lane] = make_int2(valid ? P.cstart[key_a + off - 1] : 0, valid ? P.cstart[key_a + off + 2] : 0);
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int seg = 0; seg < NSEG; ++seg) {
-        const int off = (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp
-                                 : (seg - 1) * P.nxp;
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
-        const int lo_l = valid ? P.cstart[key_a + off - 1] : 0;
-        const int hi_l = valid ? P.cstart[key_a + off + 2] : 0;
+        int lo_l, hi_l;
+        if constexpr (kShareRanges) { const int2 rg = s_rng[seg * kWave + lane]; lo_l = rg.x; hi_l = rg.y; }
+        else {
+            const int off = row_offset(seg);
+            lo_l = valid ? P.cstart[key_a + off - 1] : 0;
+            hi_l = valid ? P.cstart[key_a + off + 2] : 0;
+        }
         // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
         const int LO = rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
+        int first = 0;
+        if constexpr (WPT > 1) {
+            if constexpr (WPT >= SPHMI_RR_MIN_WPT) first = (wv - g0) & (WPT - 1);
+            else first = (wv + WPT - seg % WPT) % WPT;
+            g0 = (g0 + (HI > LO ? (HI - LO + kWave - 1) / kWave : 0)) & (WPT - 1);
+        }
 #pragma unroll 1
-        for (int cb = LO + ((wv + WPT - seg % WPT) % WPT) * kWave; cb < HI; cb += kWave * WPT) {
+        for (int cb = LO + first * kWave; cb < HI; cb += kWave * WPT) {
             // A tile of a sparse region (spray, a thin sheet) spans many cells: the union range of a row is then
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
@@ -698,8 +740,9 @@ k_neighbor_force(const ForceParams<T> P) {
     }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     if (lane == 0 && wv == 0 && P.trace) {
-        P.trace[2 * b] = st_t0;
-        P.trace[2 * b + 1] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(blockIdx.x & 7) << 60);   // + XCD of the block
+        P.trace[4 * b] = st_entry;                                                                               // kernel entry of the wave
+        P.trace[4 * b + 1] = st_t0;                                                                              // prologue done, scan starts
+        P.trace[4 * b + 2] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(blockIdx.x & 7) << 60);   // pair loop done (+ XCD of the block)
     }
 #endif
 #ifdef SPHMI_STATS
@@ -709,7 +752,9 @@ k_neighbor_force(const ForceParams<T> P) {
     }
 #endif
     if constexpr (WPT > 1) {
-        __shared__ V4 s_part[3 * (WPT - 1) * kWave];        // partial sums of waves 1 … WPT−1
+        // partial sums of waves 1 … WPT−1: { a, dρ/dt }, and for the run-time variant the shifting and kernel-output sums
+        constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;
+        __shared__ V4 s_part[kPartArrays * (WPT - 1) * kWave];
         __shared__ int s_work[WPT];
         // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
         if (lane == 0) s_work[wv] = tile_work;
@@ -720,6 +765,9 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
         if (wv > 0) return;
+#ifdef SPHMI_TRACE_SYNC
+        if (lane == 0 && P.trace) P.trace[4 * b + 1] = __builtin_amdgcn_s_memrealtime();     // experiment: when the slowest wave of the tile arrived
+#endif
         // the workgroup holds its WPT wave slots until the slowest wave is done
 #pragma unroll
         for (int k = 1; k < WPT; ++k) tile_work = max(tile_work, s_work[k]);
@@ -734,6 +782,8 @@ k_neighbor_force(const ForceParams<T> P) {
     }
     if (P.tile_work && lane == 0) P.tile_work[b] = tile_work;
     // ---- epilogue ---------------------------------------------------------------------------
+    // (the pre-test reading of the reduction slots is issued first: it comes from beyond the XCD's L2 and is needed last)
+
     const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
     const T ml = fluid_a ? T(1) : T(0);
@@ -794,12 +844,17 @@ k_neighbor_force(const ForceParams<T> P) {
         T a2 = ax * ax + ay * ay + az * az;
         if (!owned) { disp2 = T(0); vis = T(0); a2 = T(0); }      // tail lanes of the last tile
         disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
-        if (lane == 0) {
-            atomic_max_bits(&P.red[0], disp2);
-            atomic_max_bits(&P.red[1], vis);
-            atomic_max_bits(&P.red[2], a2);
-        }
+        // every lane holds the three maxima: lanes 0, 1, 2 serve one slot each — ONE pre-test load and ONE atomic instruction
+        // per wave instead of three dependent round trips to the coherence point (a device-scope load is served beyond the
+        // XCD's L2; the epilogue of a lone wave: 5.3 → 4.1 µs, tools/trace_small.py)
+        if (lane < 3) atomic_max_bits(&P.red[lane], lane == 0 ? disp2 : (lane == 1 ? vis : a2));
     }
+#if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+    if (lane == 0 && wv == 0 && P.trace) {
+        __builtin_amdgcn_s_waitcnt(0);                       // stores and atomics of the epilogue issued and returned
+        P.trace[4 * b + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 }  // namespace sphmi
