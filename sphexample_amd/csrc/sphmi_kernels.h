@@ -590,6 +590,13 @@ k_neighbor_force(const ForceParams<T> P) {
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
     // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
+#ifndef SPHMI_TWO_PAIRS_MIN_WPT
+#define SPHMI_TWO_PAIRS_MIN_WPT 4
+#endif
+    // (measured, µs per step one → two pairs: 2-D dam break 35.1 → 32.5, Dambreak3d Dp0.02 84.8 → 76.6, MovingSquare2d 53.0 →
+    // 49.4; the 3-D run-time-model kernel at four waves per tile — DucklingMDBC — loses, 147.6 → 157.8: its corrector has no
+    // registers left for a second neighbour)
+    constexpr bool kTwoPairs = WPT >= 2 * SPHMI_TWO_PAIRS_MIN_WPT || (WPT >= SPHMI_TWO_PAIRS_MIN_WPT && (MODEL >= 0 || D == 2));
     auto run_pairs = [&](const int keep, const bool drain) {
         // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
         bool more = qn != 0, have = cm != 0;
@@ -599,19 +606,38 @@ k_neighbor_force(const ForceParams<T> P) {
                 const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
                 m = ne.x; cbase = ne.y; raddr = q_next(raddr); qn -= 1;
             }
-            cm = m & (m - 1);                                    // (0 stays 0)
             work_it += 1;
 #ifdef SPHMI_STATS
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0));
 #endif
-            if (m != 0) {
-                const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
-                const V4 n0 = gather_packet(rs0, jr, 0, T());
-                const V4 n1 = gather_packet(rs0, jr, 1, T());
-                // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
-                // cell (j < cs_a) or after it inside it (a < j < ce_a)
-                const bool a_is_i = (jr < cs_ar) | ((jr > a_r) & (jr < ce_ar));
-                pair(jr, n0, n1, a_is_i);
+            // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
+            // cell (j < cs_a) or after it inside it (a < j < ce_a)
+            auto plays_i = [&](const unsigned jr) { return (jr < cs_ar) | ((jr > a_r) & (jr < ce_ar)); };
+            if constexpr (kTwoPairs) {
+                // Lone waves (a tile of four or eight waves = a launch too small to hide latency behind other waves): TWO
+                // neighbours per iteration, their four gathers in flight together; the pairs are still accumulated one after
+                // the other, in mask order, so the sums are those of the one-pair loop bit for bit.
+                const unsigned m1 = m & (m - 1);
+                cm = m1 & (m1 - 1);
+                if (m != 0) {
+                    const bool two = m1 != 0;
+                    const unsigned jr0 = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
+                    const unsigned jr1 = two ? ((unsigned)__builtin_ctz(m1) << kRecShift) + cbase : jr0;
+                    const V4 n0a = gather_packet(rs0, jr0, 0, T());
+                    const V4 n1a = gather_packet(rs0, jr0, 1, T());
+                    const V4 n0b = gather_packet(rs0, jr1, 0, T());
+                    const V4 n1b = gather_packet(rs0, jr1, 1, T());
+                    pair(jr0, n0a, n1a, plays_i(jr0));
+                    if (two) pair(jr1, n0b, n1b, plays_i(jr1));
+                }
+            } else {
+                cm = m & (m - 1);                                    // (0 stays 0)
+                if (m != 0) {
+                    const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
+                    const V4 n0 = gather_packet(rs0, jr, 0, T());
+                    const V4 n1 = gather_packet(rs0, jr, 1, T());
+                    pair(jr, n0, n1, plays_i(jr));
+                }
             }
             more = qn != 0; have = cm != 0;
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
