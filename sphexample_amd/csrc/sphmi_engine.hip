@@ -144,6 +144,8 @@ struct Engine final : EngineBase {
     int xcd_segs = 0;                  // contiguous segments of the tile list per XCD run; 0 = by size ($SPHMI_XCD_SEGS overrides)
     // measured (both with the order from measured work): 108 tiles 4 > 2 > 1; 2481 … 6344 tiles 2 > 1 (+6 … +2 %);
     // 10512 tiles 2 = 1; 14032 / 16528 / 24676 tiles 1 > 2 (+3 / +5 / +7 %)
+    // cost classes of the tile order (sphmi_rebuild.h): fine where the launch fits the chip at once, coarse where it does not
+    int tile_classes(int ntile) const { return ntile < kWptMedium ? SPHMI_TILE_CLASSES_ONE_ROUND : SPHMI_TILE_CLASSES; }
     static constexpr int kWptTiny = 512, kWptSmall = 1024, kWptMedium = 10000;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
@@ -524,7 +526,7 @@ struct Engine final : EngineBase {
                 // (with the measured re-schedule the shares belong to IT: the estimate-based order lives for one step)
                 for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 && !resched ? xcd_w[x] : 0.125);
                 W.cum[8] = 1.0f;
-                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W, 0);
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W, 0, tile_classes(ntile));
             }
             HC(hipGetLastError());
             HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
@@ -554,7 +556,7 @@ struct Engine final : EngineBase {
         XcdShares W{};
         for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(list == 0 ? xcd_w[x] : 0.125);
         W.cum[8] = 1.0f;
-        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, work, tile_scan, ntile, tile_order[list], part_d + 16 * list, nseg, W, 1);
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, work, tile_scan, ntile, tile_order[list], part_d + 16 * list, nseg, W, 1, tile_classes(ntile));
         HC(hipGetLastError());
         // the grid of the following launches needs the longest run: one short host round trip per rebuild interval
         // (≈30 µs every ≈40 steps); a sample whose step was cancelled left the table as it was

@@ -248,10 +248,17 @@ __global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cs
     cost1[t] = k == 1 ? c : 0;
 }
 
+// Cost classes of a run (most expensive first).  Four for launches of several rounds of the wave slots: inside a class the
+// tiles keep their sorted order and with it the L2 locality of the run (16 / 64 classes at 1.06 M particles: −9 / −10 %).
+// Sixteen for the launches that fit the chip at once (two waves per tile, below 10 k tiles): there every tile starts at
+// t = 0, the dispatcher deals the blocks round the compute units in launch order, and the finer the deal follows the
+// cost the more even the units' sums — 158 791 particles 7.23e8 → 7.53e8 updates/s, 517 818 particles 9.40 → 9.57e8.
 #ifndef SPHMI_TILE_CLASSES
 #define SPHMI_TILE_CLASSES 4
 #endif
-constexpr int kTileClasses = SPHMI_TILE_CLASSES;
+#ifndef SPHMI_TILE_CLASSES_ONE_ROUND
+#define SPHMI_TILE_CLASSES_ONE_ROUND 16
+#endif
 // one workgroup per XCD run: find the run, then a STABLE partition of its tiles into cost classes, most
 // expensive class first.  Inside a class the tiles keep their sorted order, so the ~1000 tiles an XCD has
 // in flight at any time are still neighbours in space and share their source rows in its L2 (a full sort
@@ -259,7 +266,7 @@ constexpr int kTileClasses = SPHMI_TILE_CLASSES;
 // cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
 struct XcdShares { float cum[9]; };      // cumulative share of the estimated cost per XCD: cum[0] = 0 … cum[8] = 1
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
-                                                     int* part, int nseg, XcdShares W, int keep_if_empty) {
+                                                     int* part, int nseg, XcdShares W, int keep_if_empty, int nclass) {
     // nseg contiguous segments per XCD, dealt round-robin (segment s of 8·nseg equal-cost segments goes to XCD s % 8):
     // with nseg = 1 an XCD's run is one stretch of the domain, and a stretch of interior fluid has no cheap tiles to
     // end its launch with.  The XCD's tiles are written to order[x·ntile …].
@@ -298,11 +305,11 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     __syncthreads();
     const int cmin = s_min;
-    const float scale = s_max > cmin ? (float)kTileClasses / (float)(s_max - cmin + 1) : 0.f;
+    const float scale = s_max > cmin ? (float)nclass / (float)(s_max - cmin + 1) : 0.f;
     // class 0 = most expensive
-    auto cls_of = [&](int c) { return kTileClasses - 1 - min(kTileClasses - 1, (int)((float)(c - cmin) * scale)); };
+    auto cls_of = [&](int c) { return nclass - 1 - min(nclass - 1, (int)((float)(c - cmin) * scale)); };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int cls = 0; cls < kTileClasses; ++cls) {
+    for (int cls = 0; cls < nclass; ++cls) {
         for (int k = 0; k < nseg; ++k) {
             const int beg = seg_beg(k), end = seg_end(k);
             for (int t0 = beg; t0 < end; t0 += 1024) {

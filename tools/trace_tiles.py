@@ -12,10 +12,11 @@ sys.path.insert(0, ROOT)
 from sphexample_amd import build  # noqa: E402
 
 lib = "/tmp/libsphmi_stats.so"
-build.build(force=True, extra_flags=["-DSPHMI_TRACE"] + sys.argv[1:], out=lib)
+build.build(force=True, extra_flags=["-DSPHMI_TRACE"] + [a for a in sys.argv[1:] if a.startswith("-D")], out=lib)
+bench_extra = [a for a in sys.argv[1:] if not a.startswith("-D")]      # e.g. --dp 0.0085
 fn = "/tmp/tiles.bin"
 env = dict(os.environ, SPHMI_LIB=lib, SPHMI_TRACE_FILE=fn)
-subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], env=env,
+subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--precondition-ms", "0"] + bench_extra, env=env,
                capture_output=True)
 raw = np.fromfile(fn, dtype=np.uint64).reshape(-1, 4)[:, 1:3]     # { kernel entry, scan start, pair loop end | XCD, exit }
 raw = raw[raw[:, 1] > 0]
