@@ -10,7 +10,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $line -d $R/gpurun_out/$out/p$i -o p -- ${PMC_CMD:-python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@"} > $R/gpurun_out/$out/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $line -d $R/gpurun_out/$out/p$i -o p -- ${PMC_CMD:-python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --precondition-ms 0 "$@"} > $R/gpurun_out/$out/p$i.log 2>&1
   db=$(find $R/gpurun_out/$out/p$i -name '*.db' | head -1)
   echo "### pass $i: $line"
   python $R/tools/pmc_summary.py "$db" "k_neighbor_force" | tail -n +2
