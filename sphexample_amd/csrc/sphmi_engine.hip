@@ -127,7 +127,19 @@ struct Engine final : EngineBase {
     unsigned long long* trace_d = nullptr;
     V4* kout_d = nullptr;              // StoreKernelOutput: { Σ∇W, ΣW } per particle
     MotionTable motions{};
-    StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control + its pinned mirror
+    StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control (two blocks) + its pinned mirror
+    // Which of the two control blocks / two sets of reduction slots is current.  Plain handles take the control inside the
+    // predictor (ForceParams::ctl_in): every queued step reads one block / set and writes the other, so both indices flip
+    // per step at queue time; after a batch the control index is the last one written and the slot index the one the last
+    // EXECUTED corrector filled.  Handles with mDBC, moving bodies or a slab keep index 0 (k_step_control works in place).
+    int cpar = 0, rpar = 0;
+    int fuse_ctrl = 1;                 // $SPHMI_FUSE_CTRL=0: a k_step_control launch per step for every handle (experiments)
+    StepCtrl* ctrl_cur() const { return ctrl_d + cpar; }
+    unsigned long long* red_cur() const { return red_d + 4 * rpar; }
+    // (decided once per queued batch: before the first rebuild there is no tile schedule and the predictor launch is skipped —
+    // nobody would take the decisions)
+    bool fused_control() const { return fuse_ctrl && cfg.mdbc == SPHMI_MDBC_NONE && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0; }
+    bool batch_fused = false;
     static constexpr int kBatch = 16;  // most steps queued between two looks at the control flags
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
@@ -201,7 +213,9 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&trace_d, nt * 32)); HC(hipMemset(trace_d, 0, nt * 32));
 #endif
         HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
-        HC(hipMalloc(&ctrl_d, sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
+        HC(hipMalloc(&ctrl_d, 2 * sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
+        HC(hipMemset(ctrl_d, 0, 2 * sizeof(StepCtrl)));
+        if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
     }
@@ -296,7 +310,7 @@ struct Engine final : EngineBase {
         P.out0 = pk0[out]; P.out1 = pk1[out];
         P.accbuf = acc[cur];
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
-        P.red = red_d; P.ctrl = nullptr;
+        P.red = red_cur(); P.stats = red_d + 8; P.ctrl = nullptr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
@@ -571,7 +585,7 @@ struct Engine final : EngineBase {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
         M.ctrl = ctrl;
-        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_d; M.N = N;
+        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_cur(); M.N = N;
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
         dim3 g((N + 3) / 4), b(256);               // one wave per particle, four per block
@@ -602,17 +616,27 @@ struct Engine final : EngineBase {
     }
     void enqueue_step() {
         serve_reschedules();
-        Ev ev = begin_phase(PH_TIMESTEP);
-        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, red_d, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
-        end_phase(ev);
-        progress_motion(0.0, ctrl_d);                                          // :765
-        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_d);                    // :772
-        ForceParams<T> P1 = force_params(iA, iA, iH, 0.0); P1.ctrl = ctrl_d;
+        const bool fused = batch_fused;
+        if (!fused) {
+            Ev ev = begin_phase(PH_TIMESTEP);
+            hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, red_cur(), ctrl_cur(), cfg.h, cfg.c0, cfg.CFL);
+            end_phase(ev);
+        }
+        progress_motion(0.0, ctrl_cur());                                      // :765
+        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());                // :772
+        ForceParams<T> P1 = force_params(iA, iA, iH, 0.0);
+        if (fused) {
+            // the predictor takes the decisions: reads control block / slots `cpar` / `rpar`, leaves the other ones to the corrector
+            P1.ctl_in = ctrl_d + cpar; P1.ctl_out = ctrl_d + (cpar ^ 1);
+            P1.red_in = red_d + 4 * rpar; P1.red_zero = red_d + 4 * (rpar ^ 1);
+            P1.ctl_h = cfg.h; P1.ctl_c0 = cfg.c0; P1.ctl_CFL = cfg.CFL;
+            cpar ^= 1; rpar ^= 1;
+        } else P1.ctrl = ctrl_cur();
         Ev e1 = begin_phase(PH_PASS1);
         launch_force<PASS_PREDICTOR>(P1);                                      // :774-781
         end_phase(e1);
-        progress_motion(0.0, ctrl_d);                                          // :787
-        ForceParams<T> P2 = force_params(iH, iA, iB, 0.0); P2.ctrl = ctrl_d;
+        progress_motion(0.0, ctrl_cur());                                      // :787
+        ForceParams<T> P2 = force_params(iH, iA, iB, 0.0); P2.ctrl = ctrl_cur();      // (force_params: P2.red = the current slots)
         Ev e2 = begin_phase(PH_PASS2);
         launch_force<PASS_CORRECTOR>(P2);                                      // :789-798
         end_phase(e2);
@@ -629,9 +653,11 @@ struct Engine final : EngineBase {
         c.max_steps = max_steps; c.last_dt = last_dt;
         try {
             *ctrl_h = c;
-            HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+            HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
             for (;;) {
                 const int a0 = iA, b0 = iB;
+                const int rpar0 = rpar;
+                batch_fused = fused_control();
                 const int64_t before = steps;
                 const double dx0 = delta_x;
                 // queue up to the step that is expected to ask for the rebuild (Δx grows by 4·max|Δx| a step, slowly
@@ -642,11 +668,14 @@ struct Engine final : EngineBase {
                 if (max_steps >= 0) batch = (int)std::min<int64_t>(batch, std::max<int64_t>(max_steps - steps, 1));
                 for (int k = 0; k < batch; ++k) { batch_step = k; enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
                 batch_step = -1;
-                HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
+                HC(hipMemcpyAsync(ctrl_h, ctrl_cur(), sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));      // the block the last queued step wrote
                 sync_and_collect(ctrl_h, before);
                 c = *ctrl_h;
                 steps = c.steps_done;
                 const int64_t executed = steps - before;
+                // (control inside the predictor: the slots flipped at queue time, once per queued step; what counts is where
+                // the last EXECUTED corrector left its maxima — cancelled steps consume nothing and zero nothing)
+                if (batch_fused) rpar = rpar0 ^ (int)(executed & 1);
                 iteration += executed - batch;                                    // what really ran
                 // the state sets rotate once per EXECUTED step
                 iA = (executed & 1) ? b0 : a0; iB = (executed & 1) ? a0 : b0;
@@ -667,7 +696,7 @@ struct Engine final : EngineBase {
                     rebuild();
                     c.delta_x = 0.0; c.need_rebuild = 0; delta_x = 0.0;           // resume stays set: the queued step re-uses its Δt
                     *ctrl_h = c;
-                    HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+                    HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
                     continue;
                 }
                 if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) break;
@@ -722,7 +751,8 @@ struct Engine final : EngineBase {
         if (groups) HC(hipMemcpyAsync(grp[cur], groups, n * 8, hipMemcpyHostToDevice, stream));
         else HC(hipMemsetAsync(grp[cur], 0, n * 8, stream));
         HC(hipMemsetAsync(key[cur], 0, n * 4, stream));
-        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+        HC(hipMemsetAsync(red_d, 0, 8 * 8, stream));
+        cpar = 0; rpar = 0;
         const int nb256 = (N + 255) / 256;
         // Pressure! (src/SPHCellList.jl:835) and the reductions Δt / update_delta_x! will read first
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
@@ -781,7 +811,7 @@ struct Engine final : EngineBase {
             hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur]);
             const size_t n = (size_t)N;
             HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
-            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
+            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); cpar = 0; rpar = 0;
             const int nb256 = (N + 255) / 256;
             hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
             hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d);

@@ -100,36 +100,47 @@ struct StepCtrl {
 
 // one thread: the per-step decisions of Δt (src/TimeStepping.jl:30-43) and update_delta_x! on the reduction slots the
 // previous corrector filled (bit patterns of non-negative values)
+// The decisions of one step on the four reduction slots the previous corrector filled (r0 … r3: bit patterns of
+// non-negative values) and the control block `c` (a copy; the caller stores it).  Returns true when the slots were consumed
+// (the step runs: they must be zero before its corrector fills them again), false when they must survive — a step that
+// ends the interval, asks for a rebuild or finds an error leaves them for the control that follows.
 template <class T>
-__global__ void k_step_control(unsigned long long* red, StepCtrl* cp, double h, double c0, double CFL) {
-    // everything the decision needs is requested at once (one round trip instead of a chain of dependent ones: the kernel
-    // is a single thread, and a step of a small case is three launches of which this is the shortest — 4.4 → ≈2.5 µs)
-    StepCtrl c = *cp;
-    const unsigned long long r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
-    if (c.stop || c.error || c.need_rebuild) { cp->active = 0; return; }
+__device__ __forceinline__ bool step_control_decide(unsigned long long r0, unsigned long long r1, unsigned long long r2,
+                                                    unsigned long long r3, StepCtrl& c, double h, double c0, double CFL) {
+    if (c.stop || c.error || c.need_rebuild) { c.active = 0; return false; }
     if (!c.resume) {
-        if (!(c.total_time <= c.t_target) || (c.max_steps >= 0 && c.steps_done >= c.max_steps)) { cp->stop = 1; cp->active = 0; return; }
+        if (!(c.total_time <= c.t_target) || (c.max_steps >= 0 && c.steps_done >= c.max_steps)) { c.stop = 1; c.active = 0; return false; }
         auto dec = [](unsigned long long b) -> double {
             if constexpr (sizeof(T) == 4) return (double)__uint_as_float((unsigned)b); else return __longlong_as_double((long long)b);
         };
-        if (r3) { cp->error = 2; cp->active = 0; return; }
+        if (r3) { c.error = 2; c.active = 0; return false; }
         const double maxdisp = sqrt(dec(r0)), visc = dec(r1), amax = sqrt(dec(r2));
         c.delta_x += 4.0 * maxdisp;
         const double dt1 = sqrt(h / amax), dt2 = h / (c0 + visc);
         const double dt = CFL * (dt1 < dt2 ? dt1 : dt2);
         c.last_visc = visc; c.last_amax = amax;
         c.dt = dt; c.dt2 = dt * 0.5;
-        if (!(dt > 0.0) || dt != dt || c.delta_x != c.delta_x) { c.error = 1; c.active = 0; *cp = c; return; }
-        if (c.delta_x >= h) { c.need_rebuild = 1; c.resume = 1; c.active = 0; *cp = c; return; }
+        if (!(dt > 0.0) || dt != dt || c.delta_x != c.delta_x) { c.error = 1; c.active = 0; return false; }
+        if (c.delta_x >= h) { c.need_rebuild = 1; c.resume = 1; c.active = 0; return false; }
     }
     c.resume = 0;
-    red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0;
     c.t_step_start = c.total_time;
     c.total_time += c.dt;                                   // UpdateMetaData!, :679-685 (nothing reads it before the
-    c.steps_done += 1;                                      // next control kernel except through t_step_start)
+    c.steps_done += 1;                                      // next control except through t_step_start)
     c.last_dt = c.dt;
     c.active = 1;
+    return true;
+}
+
+// one thread: the control as a launch of its own (handles with mDBC or moving bodies, whose kernels need the decisions before
+// the predictor; slab handles, whose slots are MAX-allreduced first).  State and slots are read in one burst.
+template <class T>
+__global__ void k_step_control(unsigned long long* red, StepCtrl* cp, double h, double c0, double CFL) {
+    StepCtrl c = *cp;
+    const unsigned long long r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+    const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, h, c0, CFL);
     *cp = c;
+    if (consumed) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0; }
 }
 
 template <class T>
@@ -146,7 +157,17 @@ struct ForceParams {
     const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
     const uint8_t* type;
     unsigned long long* red;   // [0] max |x⁺−x|², [1] max visc, [2] max |a|² (bit patterns), [3] bad-ρ flag
+    unsigned long long* stats; // loop counters of -DSPHMI_STATS builds
     const StepCtrl* ctrl;      // device-side step control (null: dt / dt2 below are used, the kernel always runs)
+    // Control taken INSIDE the predictor (plain handles: no mDBC, no moving body, no slab): every block takes the decisions
+    // of the step itself from the state the previous step left (`ctl_in`) and the slots its corrector filled (`red_in`) —
+    // the same few hundred instructions on the same inputs in every block, instead of a one-thread launch in front of every
+    // step (4.4 of the 32.5 µs of a 2-D dam-break step).  Block 0 stores the decided state to `ctl_out` — the OTHER
+    // control block: late blocks of this launch still read `ctl_in` — where this step's corrector and the next step's
+    // predictor read it, and zeroes `red_zero`, the OTHER set of slots, which this step's corrector fills.  Null: `ctrl`.
+    const StepCtrl* ctl_in; StepCtrl* ctl_out;
+    const unsigned long long* red_in; unsigned long long* red_zero;
+    double ctl_h, ctl_c0, ctl_CFL;
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (of its slowest wave × WPT), or null
@@ -340,8 +361,21 @@ k_neighbor_force(const ForceParams<T> P) {
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (P.ctrl && !P.ctrl->active) return;                 // a queued step that the control kernel cancelled
-    const T step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt, step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
+    T step_dt, step_dt2;
+    if (PASS == PASS_PREDICTOR && P.ctl_in != nullptr) {
+        StepCtrl c = *P.ctl_in;
+        const unsigned long long r0 = P.red_in[0], r1 = P.red_in[1], r2 = P.red_in[2], r3 = P.red_in[3];
+        const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, P.ctl_h, P.ctl_c0, P.ctl_CFL);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *P.ctl_out = c;
+            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; }
+        }
+        if (!c.active) return;
+        step_dt = (T)c.dt; step_dt2 = (T)c.dt2;
+    } else {
+        if (P.ctrl && !P.ctrl->active) return;             // a queued step that the control cancelled
+        step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt; step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
+    }
     const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;
     const int ddt = MODEL >= 0 ? ((MODEL >> 4) & 15) : P.ddt;
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
@@ -773,8 +807,8 @@ k_neighbor_force(const ForceParams<T> P) {
 #endif
 #ifdef SPHMI_STATS
     if (lane == 0) {
-        atomicAdd(&P.red[8], st_it); atomicAdd(&P.red[9], st_lane); atomicAdd(&P.red[10], st_ref);
-        atomicAdd(&P.red[11], st_emp); atomicAdd(&P.red[12], st_chunks); atomicAdd(&P.red[13], 1ull);
+        atomicAdd(&P.stats[0], st_it); atomicAdd(&P.stats[1], st_lane); atomicAdd(&P.stats[2], st_ref);
+        atomicAdd(&P.stats[3], st_emp); atomicAdd(&P.stats[4], st_chunks); atomicAdd(&P.stats[5], 1ull);
     }
 #endif
     if constexpr (WPT > 1) {
