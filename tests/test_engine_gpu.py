@@ -677,3 +677,28 @@ def test_device_side_case_generator(dp, fb):
     a, b = by_id(up.download()), by_id(gen.download())
     assert relmax(b["Density"], a["Density"]) < (1e-6 if fb == 4 else 1e-12)
     assert relmax(b["Position"], a["Position"]) < (1e-6 if fb == 4 else 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_control_inside_the_predictor_keeps_the_step_sequence(dam_break_2d, fuse, monkeypatch):
+    """Plain handles take the step control inside the predictor (two control blocks / two sets of reduction slots that flip
+    per queued step; cancelled steps of a batch consume nothing).  Short calls of odd and even length, by step count and by
+    time, each starting with a rebuild: Δt, the loop counters and the state must follow the oracle call by call — with the
+    one-thread control launch (SPHMI_FUSE_CTRL=0) and without."""
+    monkeypatch.setenv("SPHMI_FUSE_CTRL", fuse)
+    p, s = dam_break_2d
+    eng, orc = engines(p, s, 8)
+    now = 0.0
+    for k, n in enumerate([1, 2, 3, 1, 5, 8, 2, 17, 1, 4]):
+        if k % 3 == 2:                         # every third call ends by TIME: its last control returns with unconsumed maxima
+            pe, po = eng.advance(now + 2.7e-4 * n), orc.advance(now + 2.7e-4 * n)
+        else:
+            pe, po = eng.advance(1e9, max_steps=n), orc.advance(1e9, max_steps=n)
+        assert (pe.iteration, pe.steps_done, pe.n_rebuilds) == (po.iteration, po.steps_done, po.n_rebuilds)
+        assert pe.last_dt == pytest.approx(po.last_dt, rel=1e-10)
+        assert pe.total_time == pytest.approx(po.total_time, rel=1e-12)
+        now = po.total_time
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-9
+    assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < 1e-11
