@@ -192,6 +192,7 @@ struct Engine final : EngineBase {
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
         if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
+        if (const char* w = getenv("SPHMI_TPB2")) tpb2 = atoi(w);
         HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
         const size_t n = (size_t)N;
@@ -210,7 +211,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4)); HC(hipMalloc(&tile_work1_d, nt * 4));
         if (cfg.kernel_output == SPHMI_KOUT_STORE) { HC(hipMalloc(&kout_d, n * sizeof(V4))); HC(hipMemset(kout_d, 0, n * sizeof(V4))); }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
-        HC(hipMalloc(&trace_d, nt * 32)); HC(hipMemset(trace_d, 0, nt * 32));
+        HC(hipMalloc(&trace_d, nt * 32 * 9)); HC(hipMemset(trace_d, 0, nt * 32 * 9));     // per tile 4 stamps + (-DSPHMI_TRACE_WAVES) 8 waves × 4
 #endif
         HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
         HC(hipMalloc(&ctrl_d, 2 * sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
@@ -240,7 +241,7 @@ struct Engine final : EngineBase {
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         if (trace_d) {   // experiment build: start / end clock of every tile of the LAST launch → $SPHMI_TRACE_FILE
             const char* fn = getenv("SPHMI_TRACE_FILE");
-            std::vector<unsigned long long> tr((size_t)(cap / kWave + 2) * 4);
+            std::vector<unsigned long long> tr((size_t)(cap / kWave + 2) * 4 * 9);
             if (fn && hipMemcpy(tr.data(), trace_d, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                 FILE* f = fopen(fn, "wb");
                 if (f) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
@@ -346,6 +347,7 @@ struct Engine final : EngineBase {
     // 1.06 M particles (kernel ms per launch): 1 → 0.5601, 2 → 0.5591, 4 → 0.5558; it is what lets ONE tile segment per XCD
     // (the L2-friendly schedule) run as fast as sixteen: 0.5562 against 0.5585 / 0.5558
     int tpb = 4;
+    int tpb2 = 1;                      // two-wave tiles in pairs (workgroups of four waves); $SPHMI_TPB2=0 switches it off
     template <int PASS, int MODEL, int TPB> void launch_force_tpb(const ForceParams<T>& P, int list) {
         dim3 g(8 * ((part_max[list] + TPB - 1) / TPB)), b(kWave * TPB);
         hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, 1, TPB>), g, b, 0, stream, P);
@@ -355,6 +357,15 @@ struct Engine final : EngineBase {
         if constexpr (WPT == 1 && MODEL == kModelDefault && sizeof(T) == 4) {
             if (D == 3 && tpb == 4) { launch_force_tpb<PASS, MODEL, 4>(P, list); return; }
             if (D == 3 && tpb == 2) { launch_force_tpb<PASS, MODEL, 2>(P, list); return; }
+        }
+        if constexpr (WPT == 2) {
+            // two tiles of two waves per workgroup: four waves = one per SIMD of the compute unit ($SPHMI_TPB2=0: one tile per block)
+            if (D == 3 && tpb2) {
+                dim3 g2(8 * ((part_max[list] + 1) / 2)), b2(kWave * 4);
+                hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, 2, 2>), g2, b2, 0, stream, P);
+                HC(hipGetLastError());
+                return;
+            }
         }
         dim3 g(8 * part_max[list]), b(kWave * WPT);
         if (D == 3) hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, WPT>), g, b, 0, stream, P);

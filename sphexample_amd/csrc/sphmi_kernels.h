@@ -351,13 +351,13 @@ __device__ __forceinline__ void wave_sync() {
 // round-robin over ALL rows (chunk c of a row whose predecessors hold g chunks goes to wave (g + c) % WPT: the waves'
 // chunk counts differ by one at most); wave 0 adds the partial sums in wave order and runs the epilogue.  A wave's lifetime is the scheduling granule of a launch: with few tiles (small cases, and the
 // last round of a 1 M-particle launch) shorter-lived waves keep the SIMDs filled.
-// TPB: tiles per block (WPT = 1 only).  The TPB waves of a workgroup take TPB consecutive entries of the XCD's run —
+// TPB: tiles per block.  The TPB tiles of a workgroup are TPB consecutive entries of the XCD's run —
 // neighbouring tiles, whose candidate rows overlap by three quarters — and run on the four SIMDs of ONE compute unit,
 // so the rows are fetched into that unit's L1 once instead of by four units.
 template <class T, int D, int PASS, int MODEL, int WPT, int TPB = 1>
 __global__ void __launch_bounds__(kWave * WPT * TPB)
 k_neighbor_force(const ForceParams<T> P) {
-    static_assert(TPB == 1 || WPT == 1, "several tiles per block only with one wave per tile");
+    static_assert(TPB == 1 || WPT <= 2, "several tiles per block: one or two waves per tile");
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -388,7 +388,13 @@ k_neighbor_force(const ForceParams<T> P) {
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wvb = threadIdx.x >> 6;                      // wave of the block
-    const int wv = TPB == 1 ? wvb : 0;                     // wave of the tile
+    // wave of the tile, tile of the block.  Two tiles of two waves (the launches that fit the chip at once): a workgroup of
+    // FOUR waves puts one wave on each SIMD of its compute unit, so every SIMD of a unit holds the same number of waves —
+    // workgroups of two left the SIMDs with 4 … 9 waves and 35 % more work on the fullest than on average, and the launch
+    // lasts as long as its fullest SIMD (tools/trace_waves.py, 158 791 particles).  Odd blocks swap the roles of a tile's
+    // two waves, so that no SIMD always gets the wave that also runs the epilogue.
+    const int tib = TPB == 1 ? 0 : wvb / WPT;
+    const int wv = TPB == 1 ? wvb : (WPT == 1 ? 0 : ((wvb % WPT) ^ (int)((blockIdx.x >> 3) & 1)));
     // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
     // program order is all the synchronisation the queue needs
     uint2* const s_q = s_q_all + wvb * QCAP * kWave + lane;
@@ -397,7 +403,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
     int b;
     {
-        const int x = blockIdx.x & 7, r = TPB == 1 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * TPB + wvb;
+        const int x = blockIdx.x & 7, r = TPB == 1 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * TPB + tib;
         if (r >= P.part[8 + x]) return;
         b = P.order[P.part[x] + r];
     }
@@ -799,6 +805,16 @@ k_neighbor_force(const ForceParams<T> P) {
         atomicMin(&P.xcd_clock[8], xcd_t0);
     }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
+#ifdef SPHMI_TRACE_WAVES
+    // experiment: every wave of the tile leaves { start, end of its pair loop, hardware id, work } in a second table behind the
+    // first (4 × tiles entries further): which SIMD of which unit ran it, and how the tile's waves compare
+    if (lane == 0 && P.trace) {
+        unsigned long long* W = P.trace + 4ull * ((unsigned long long)P.N / kWave + 2) + 4ull * ((unsigned long long)b * 8 + wv);
+        W[0] = st_t0; W[1] = __builtin_amdgcn_s_memrealtime();
+        W[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(blockIdx.x & 7) << 32);   // HW_ID | XCD
+        W[3] = (unsigned long long)work_it | ((unsigned long long)work_ch << 32);
+    }
+#endif
     if (lane == 0 && wv == 0 && P.trace) {
         P.trace[4 * b] = st_entry;                                                                               // kernel entry of the wave
         P.trace[4 * b + 1] = st_t0;                                                                              // prologue done, scan starts
@@ -814,8 +830,10 @@ k_neighbor_force(const ForceParams<T> P) {
     if constexpr (WPT > 1) {
         // partial sums of waves 1 … WPT−1: { a, dρ/dt }, and for the run-time variant the shifting and kernel-output sums
         constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;
-        __shared__ V4 s_part[kPartArrays * (WPT - 1) * kWave];
-        __shared__ int s_work[WPT];
+        __shared__ V4 s_part_all[TPB * kPartArrays * (WPT - 1) * kWave];
+        __shared__ int s_work_all[TPB * WPT];
+        V4* const s_part = s_part_all + tib * kPartArrays * (WPT - 1) * kWave;
+        int* const s_work = s_work_all + tib * WPT;
         // fixed summation order (wave 0 + wave 1 + …): results do not depend on which wave finishes first
         if (lane == 0) s_work[wv] = tile_work;
         if (wv > 0) {
