@@ -157,8 +157,13 @@ struct Engine final : EngineBase {
     // measured (both with the order from measured work): 108 tiles 4 > 2 > 1; 2481 … 6344 tiles 2 > 1 (+6 … +2 %);
     // 10512 tiles 2 = 1; 14032 / 16528 / 24676 tiles 1 > 2 (+3 / +5 / +7 %)
     // cost classes of the tile order (sphmi_rebuild.h): fine where the launch fits the chip at once, coarse where it does not
-    int tile_classes(int ntile) const { return ntile < kWptMedium ? SPHMI_TILE_CLASSES_ONE_ROUND : SPHMI_TILE_CLASSES; }
-    static constexpr int kWptTiny = 512, kWptSmall = 1024, kWptMedium = 10000;
+    int tile_classes(int ntile) const { return ntile < classes_fine_below ? SPHMI_TILE_CLASSES_ONE_ROUND : SPHMI_TILE_CLASSES; }
+    // waves per tile by tile count (measured with the paired two-wave launches and sixteen classes, updates/s WPT 2 / WPT 1:
+    // 2 481 tiles 8.03 / 7.16e8, 3 454: 8.47 / 8.22, 5 050: 9.19 / 9.02, 6 985: 9.62 / 9.80, 9 428: 9.76e8 / 1.022e9,
+    // 11 689: 0.986 / 1.054e9, 16 527: 0.978 / 1.08e9)
+    static constexpr int kWptTiny = 512, kWptSmall = 1024;
+    int kWptMedium = 6000;             // $SPHMI_WPT2_BELOW
+    int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -193,6 +198,8 @@ struct Engine final : EngineBase {
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
         if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
         if (const char* w = getenv("SPHMI_TPB2")) tpb2 = atoi(w);
+        if (const char* w = getenv("SPHMI_WPT2_BELOW")) kWptMedium = atoi(w);
+        if (const char* w = getenv("SPHMI_CLASSES_FINE_BELOW")) classes_fine_below = atoi(w);
         HC(hipMalloc(&xcd_clock_d, 16 * 8)); HC(hipHostMalloc(&xcd_clock_h, 32 * 8));
         if (const char* w = getenv("SPHMI_XCD_SEGS")) { const int v = atoi(w); if (v >= 1 && v <= 4096) xcd_segs = v; }
         const size_t n = (size_t)N;
