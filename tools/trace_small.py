@@ -13,9 +13,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
-    from conftest import load_dam_break_2d
+    import conftest
     from sphexample_amd.engine import make_engine
-    p, s = load_dam_break_2d()
+    p, s = getattr(conftest, "load_" + os.environ.get("TRACE_CASE", "dam_break_2d"))()
     e = make_engine(p, s, device_float_bytes=int(sys.argv[2]))
     e.advance(1e9, max_steps=60)
     del e
@@ -26,7 +26,8 @@ lib, fn = "/tmp/libsphmi_trace.so", "/tmp/tiles_small.bin"
 build.build(force=True, extra_flags=["-DSPHMI_TRACE"] + [a for a in sys.argv[2:] if a.startswith("-D")], out=lib)
 fb = sys.argv[1] if len(sys.argv) > 1 else "4"
 subprocess.run([sys.executable, os.path.abspath(__file__), "--child", fb], env=dict(os.environ, SPHMI_LIB=lib, SPHMI_TRACE_FILE=fn), check=True)
-raw = np.fromfile(fn, dtype=np.uint64).reshape(-1, 4)     # per tile: kernel entry, scan start, pair loop end | XCD << 60, exit
+raw = np.fromfile(fn, dtype=np.uint64)
+raw = raw[: 4 * (len(raw) // 36)].reshape(-1, 4)           # per tile: kernel entry, scan start, pair loop end | XCD << 60, exit
 raw = raw[raw[:, 2] > 0]
 t = raw.astype(np.int64)
 t[:, 2] = (raw[:, 2] & np.uint64((1 << 60) - 1)).astype(np.int64)

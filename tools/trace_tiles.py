@@ -18,7 +18,7 @@ fn = "/tmp/tiles.bin"
 env = dict(os.environ, SPHMI_LIB=lib, SPHMI_TRACE_FILE=fn)
 subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--precondition-ms", "0"] + bench_extra, env=env,
                capture_output=True)
-raw = np.fromfile(fn, dtype=np.uint64).reshape(-1, 4)[:, 1:3]     # { kernel entry, scan start, pair loop end | XCD, exit }
+raw = np.fromfile(fn, dtype=np.uint64); raw = raw[: 4 * (len(raw) // 36)].reshape(-1, 4)[:, 1:3]     # { kernel entry, scan start, pair loop end | XCD, exit }
 raw = raw[raw[:, 1] > 0]
 xcd = (raw[:, 1] >> np.uint64(60)).astype(np.int64)                 # the block's XCD rides in the top bits of the end clock
 t = np.stack([raw[:, 0], raw[:, 1] & np.uint64((1 << 60) - 1)], axis=1).astype(np.int64)
@@ -42,7 +42,7 @@ life = (t[:, 1] - t[:, 0]) / 100.0
 print("start-time histogram (% of span):", np.histogram(st, bins=[0, 5, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100])[0])
 print("life (us) percentiles 5/50/95/max:", np.percentile(life, [5, 50, 95, 100]).round(1))
 idx = np.argsort(-en)[:15]
-ids = np.nonzero(np.fromfile(fn, dtype=np.uint64).reshape(-1, 4)[:, 2] > 0)[0]
+_r = np.fromfile(fn, dtype=np.uint64); ids = np.nonzero(_r[: 4 * (len(_r) // 36)].reshape(-1, 4)[:, 2] > 0)[0]
 for i in idx:
     print(f"  tile {ids[i]:6d}  start {st[i]:5.1f} %  end {en[i]:5.1f} %  life {life[i]:6.1f} us")
 for lo, hi in ((0, 30), (30, 60), (60, 80), (80, 100)):
