@@ -50,7 +50,14 @@ if nw.max() > 1:
           f"95 % {np.percentile(hi / np.maximum(lo, 1), 95):.2f}; end-time gap median {np.median(et[m, :k].max(1) - et[m, :k].min(1)):.1f} us")
     same = [(simd_key[(tile == t)][0] // 4 == simd_key[(tile == t)][1] // 4) for t in np.unique(tile)[:400]]
     print(f"both waves of a tile on the same compute unit: {100 * np.mean(same):.0f} % (first 400 tiles)")
+if nw.max() > 2:
+    k = int(nw.max())
+    print("by wave of the tile: mean pair-loop iterations / chunks / life (us):")
+    for w_ in range(k):
+        m_ = wv == w_
+        print(f"   wave {w_}: {it[m_].mean():6.1f} (max {it[m_].max():4d})  {ch[m_].mean():4.1f}  {np.mean(en[m_] - st[m_]):6.1f} (max {np.max(en[m_] - st[m_]):5.1f})")
+    print(f"   life vs iterations: corr {np.corrcoef(it, en - st)[0, 1]:.2f}; us per iteration (fit) {np.polyfit(it, en - st, 1)[0]:.3f}, intercept {np.polyfit(it, en - st, 1)[1]:.2f} us")
 # the stragglers
 o = np.argsort(-en)[:10]
 for i in o:
-    print(f"  tile {tile[i]:6d} wave {wv[i]}  end {en[i]:6.1f} us  life {en[i] - st[i]:6.1f}  work {work[i]:6d} (mean {work.mean():.0f})  waves on its SIMD {np.sum(simd_key == simd_key[i])}, their work {work[simd_key == simd_key[i]].sum()}")
+    print(f"  tile {tile[i]:6d} wave {wv[i]}  end {en[i]:6.1f} us  life {en[i] - st[i]:6.1f}  it {it[i]:4d} ch {ch[i]:2d} work {work[i]:6d} (mean {work.mean():.0f})  waves on its SIMD {np.sum(simd_key == simd_key[i])}, their work {work[simd_key == simd_key[i]].sum()}")
