@@ -702,3 +702,43 @@ def test_control_inside_the_predictor_keeps_the_step_sequence(dam_break_2d, fuse
     e, o = by_id(eng.download()), by_id(orc.download())
     assert relmax(e["Density"], o["Density"]) < 1e-9
     assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wpt", ["1", "2", "4", "8"])
+@pytest.mark.parametrize("case,steps", [("dam_break_3d_shipped", 12), ("dam_break_2d", 20)])
+def test_every_waves_per_tile_variant_matches_the_oracle(case, steps, wpt, request, monkeypatch):
+    """The number of waves per tile follows the tile count (8 / 4 / 2 / 1; two-wave tiles of 3-D handles go out in pairs, one-wave
+    tiles four per block): here every variant is forced on the same small cases — partial last blocks, tiles of ghosts of the
+    pairing included — and has to track the fp64 oracle like the default choice."""
+    monkeypatch.setenv("SPHMI_WPT", wpt)
+    p, s = request.getfixturevalue(case)
+    for fb, tol in ((8, 1e-9), (4, 1e-5)):
+        eng, orc = engines(p, s, fb)
+        pe, po = eng.advance(1e9, max_steps=steps), orc.advance(1e9, max_steps=steps)
+        assert (pe.iteration, pe.n_rebuilds) == (po.iteration, po.n_rebuilds)
+        assert pe.last_dt == pytest.approx(po.last_dt, rel=1e-9 if fb == 8 else 1e-5)
+        e, o = by_id(eng.download()), by_id(orc.download())
+        assert relmax(e["Density"], o["Density"]) < tol
+        assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < tol
+
+
+@pytest.mark.gpu
+def test_mid_size_launch_matches_the_oracle():
+    """≈85 k particles = 1.3 k tiles: the launches that fit the chip at once (two waves per tile, tiles in pairs, sixteen cost
+    classes, measured-work order) against the oracle on the generated lattice — no shipped layout has this size."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    from sphexample_amd.engine import make_engine
+    dp = 0.0105
+    p, s = perturbed(dam_break_3d(dp), seed=5), setup_dam_break_3d(dp)
+    orc = make_oracle(p, s)
+    po = orc.advance(1e9, max_steps=6)
+    o = by_id(orc.download())
+    for fb, tol in ((8, 1e-9), (4, 1e-5)):
+        eng = make_engine(p, s, device_float_bytes=fb)
+        pe = eng.advance(1e9, max_steps=6)
+        assert (pe.iteration, pe.n_rebuilds) == (po.iteration, po.n_rebuilds)
+        e = by_id(eng.download())
+        assert relmax(e["Density"], o["Density"]) < tol
+        assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < tol
