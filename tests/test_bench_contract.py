@@ -45,15 +45,21 @@ def test_bench_line_single_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_line_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("transport", [None, "rccl"])
+def test_bench_line_two_ranks_on_one_gpu(transport):
+    """transport = "rccl": RCCL is ASKED for and refuses (two ranks on one device) — every rank learns it, the run falls back to
+    the shared-memory transport and still produces its line (what a node whose RCCL cannot be set up would get)."""
     import torch
     if torch.cuda.device_count() > 1:
         pytest.skip("more than one GPU: the ranks would not share a device")
     env = dict(os.environ, SPHMI_SHM_TIMEOUT="60")
+    if transport:
+        env["SPHMI_TRANSPORT"] = transport
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dp", "0.02",
+                        "--master-port", "29547" if transport is None else "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dp", "0.02",
                         "--precondition-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
     assert KEYS <= set(j) and "cpu_baseline" not in j
     assert j["n_gpus"] == 2 and "SHARED-MEMORY" in j["config"]["parallelism"]
+    assert ("falling back" in r.stderr) == (transport == "rccl")
