@@ -171,6 +171,8 @@ int sphmi_download_end(sphmi_handle* h);
  * (to_3d!, src/ProduceHDFVTK.jl:251-325): the arrays handed to sphmi_download* then hold n×3 values and can be appended
  * to the `Points` / PointData datasets as they are.  Cells stay n×dims. */
 int sphmi_set_output_components(sphmi_handle* h, int components);
+/* (multi-device handles stage through page-locked buffers of their own and merge the slabs on the host: registering the
+ * caller's arrays is accepted and gains nothing there) */
 int sphmi_host_register(sphmi_handle* h, void* ptr, int64_t bytes);
 int sphmi_host_unregister(sphmi_handle* h, void* ptr);
 
@@ -179,6 +181,17 @@ int sphmi_host_unregister(sphmi_handle* h, void* ptr);
  * neighbour pass, host float type, n and n×dims values, current (cell-sorted) order.  Needs kernel_output = STORE.
  */
 int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient);
+
+/*
+ * The sort as a permutation.  The reference's sort! permutes ALL 17 fields of the SimParticles StructArray
+ * (src/SPHCellList.jl:142); the engine carries the ten the hot path touches and sphmi_download returns those in the
+ * current cell-sorted order.  prev_row (N Int64, 0-based) says where every row came from: row i of the arrays
+ * sphmi_download delivers NOW was row prev_row[i] at the previous call of sphmi_download_permutation (at sphmi_upload
+ * for the first call), so the caller brings the fields the engine does not carry (GhostNormals, ChunkID, user columns)
+ * along with ONE gather per field — no sort on the host.  The engine has the permutation from its own sort (a 4-byte
+ * column that travels with the particles); multi-device handles derive it from the ID column.  Not for rank-mode handles.
+ */
+int sphmi_download_permutation(sphmi_handle* h, int64_t* prev_row);
 
 /*
  * MotionDetails of the Geometry with this GroupMarker (src/SimulationGeometry.jl:17-22): particles of Type Moving
@@ -212,7 +225,8 @@ int sphmi_download(sphmi_handle* h,
  * NeighborLoop!+ReductionStep! (src/SPHCellList.jl:771,774-775) on the current state and return
  * dρdtI (N) and Acceleration (N*D, no gravity) in cell-sorted order; also sorts the particles
  * (as UpdateNeighbors! does) but does not advance time.  apply_mdbc != 0 additionally runs
- * ApplyMDBCBeforeHalf! (:772) between Pressure! and the pair loop.
+ * ApplyMDBCBeforeHalf! (:772) between Pressure! and the pair loop.  Multi-device handles: the rebuild is the collective
+ * one (migration, fresh ghost layers) and the rows come back merged, in the order one device would hold.
  */
 int sphmi_forces_once(sphmi_handle* h, int apply_mdbc, void* drhodt, void* acceleration);
 
@@ -262,94 +276,8 @@ typedef struct sphmi_multi_info {
     int64_t n_live[SPHMI_MAX_DEVICES];  /* particles incl. ghost copies currently held per local slab               */
 } sphmi_multi_info;
 int sphmi_multi_info_get(sphmi_handle* h, sphmi_multi_info* out);
-/* Test hook, no device needed: rank `rank` of `world` processes attaches to the shared-memory transport keyed by
- * `unique_id` (128 bytes, the same in every process), runs SUM / MAX reductions of known vectors and a neighbour
- * exchange of `n_bytes` per direction with known patterns, and checks what arrives.  0 = everything matched. */
-int sphmi_shm_selftest(const void* unique_id, int32_t rank, int32_t world, int64_t n_bytes);
-/* Test hook: start from these cuts (world-1 first columns) instead of the balanced ones; call before sphmi_upload. */
-int sphmi_multi_set_cuts(sphmi_handle* h, const int64_t* cuts, int32_t n);
-/* Host-only planning (no device needed; CPU tests): slab axis, cuts, halo width, owned particles and capacity per
- * slab for `world` slabs of the given particle set.  cuts_out: world-1, owned_out / capacity_out: world entries. */
-int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* ghost_points, int64_t n, int32_t world,
-                     int32_t* axis_out, int32_t* halo_width_out, int64_t* cuts_out, int64_t* owned_out,
-                     int64_t* capacity_out);
-
-/* ---- domain decomposition, verb by verb (test harness: sphexample_amd/distributed.py drives these from Python; the
- * product path is the slab driver inside the library, above): slabs along one axis, one-cell halo (wider with mDBC) --
- * The reference has no multi-process path; these entry points let a host driver
- * (sphexample_amd/distributed.py: torch.distributed over RCCL) run the SAME kernels on a slab of the
- * domain.  The handle is created with n_particles = the rank's CAPACITY; the live count changes at every
- * cell-list rebuild (migration + ghost layer).  Ghost copies carry type bit 0x80 (owned by the left
- * neighbour) or 0x40 (right neighbour): they act as neighbours only, their state arrives by halo exchange
- * before each neighbour pass.  `*_dev` pointers are DEVICE pointers (e.g. torch tensors' data_ptr()).
- * One step = reductions → (rebuild) → halo(A) → pass 1 → halo(H) → pass 2, all driven by the host.
- * With sphmi_dd_set_slab the engine also splits every pass into INTERIOR tiles (no ghost in reach: they may
- * run while the halo is still in flight) and slab-EDGE tiles (sphmi_dd_pass_part). */
-int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream);   /* run on the caller's HIP stream (torch's) */
-int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity,
-                    const void* acceleration, const void* density, const uint8_t* type, const int64_t* id,
-                    const uint64_t* group_marker, const void* ghost_points /* mDBC handles; else nullable */,
-                    const int64_t* upload_index /* index of each particle in the UNSPLIT particle set: the in-cell
-                                                   order after the first sort (and with it the "i" role of same-cell
-                                                   pairs) then equals the single-process one; nullable = 0 … n-1 */);
-int sphmi_dd_count(sphmi_handle* h, int64_t* n_out);                 /* live particles incl. ghosts      */
-/* Slab of this rank: cell columns col_lo … col_hi (inclusive) along `axis` (0 = x, 1 = y, 2 = z); has_* say
- * whether a neighbour rank exists on that side.  Takes effect at the next sphmi_dd_rebuild. */
-int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi, int has_lower_neighbour,
-                      int has_upper_neighbour);
-int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out);   /* host: global cell index along the slab axis, n ints */
-int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out);              /* host: type bytes incl. ghost bits */
-/* the same two arrays into DEVICE buffers (n entries, stream order): index lists by device-side compaction */
-int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev);
-int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev);
-/* Work per cell column for the load balance: cost_dev[c] += Σ over the OWNED particles of column col0 + c of the
- * candidates in their 3^D cells (cell list of the last rebuild) — what a particle costs in the neighbour kernel;
- * cost_dev: ncols zero-initialised uint64 on the device. */
-int sphmi_dd_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_dev);
-int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out);   /* migration buffer size    */
-int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev);
-int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n);
-int sphmi_dd_kill_ghosts(sphmi_handle* h);
-int sphmi_dd_append(sphmi_handle* h, const void* buf_dev, int64_t n, int flag);
-int sphmi_dd_rebuild(sphmi_handle* h);                               /* UpdateNeighbors! on the slab      */
-int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev);
-int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev);
-int sphmi_dd_reductions(sphmi_handle* h, double* out8);  /* [0] max|x⁺−x|², [1] visc, [2] max|a|², [3] bad ρ */
-/* Same four slots as raw bit patterns (float32 bits in the low word for 4-byte handles, float64 bits otherwise)
- * into a DEVICE buffer of 4 × int64: non-negative values order like integers, so an integer MAX-allreduce of
- * this buffer is the global maximum (NaN sorts on top).  Resets the slots. */
-int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev);
-int sphmi_dd_pass(sphmi_handle* h, int which, double dt);            /* 1: predictor pass, 2: corrector   */
-/* part 0 = whole pass (same as sphmi_dd_pass), 1 = interior tiles, 2 = slab-edge tiles (completes the pass) */
-int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part);
-/* Moving bodies and mDBC on a slab (both need the device-side step control below).
- * sphmi_dd_progress_motion: ProgressMotion (src/SPHCellList.jl:765,787) of the queued step on owned particles and
- * ghost copies alike; call it before packing the halo of either pass.
- * sphmi_dd_mdbc: the mDBC density of EVERY boundary particle held (src/SPHCellList.jl:772), ghost copies included,
- * after the halo of state A has been unpacked and before pass 1.  A ghost copy in the column next to the slab gets
- * the owner's value (up to summation order) when the halo is 2 + max |column(ghost node) − column(particle)|
- * columns wide — the driver's job (sphexample_amd/distributed.py: halo_width). */
-int sphmi_dd_progress_motion(sphmi_handle* h);
-int sphmi_dd_mdbc(sphmi_handle* h);
-/* Device-side step control for the slab driver (the k_step_control of sphmi_advance, fed with the MAX-allreduced
- * slots): init once per advance, then per step  reductions_dev → allreduce → step_control → passes (dt argument
- * ignored); sphmi_dd_ctrl_sync waits for everything queued and reports the flags; after a collective rebuild call
- * sphmi_dd_ctrl_resume (the pending step re-uses its Δt). */
-typedef struct sphmi_dd_control {
-    int64_t steps_done;       /* steps executed since sphmi_dd_ctrl_init                                  */
-    double  total_time, last_dt, delta_x;
-    int32_t need_rebuild;     /* Δx ≥ h: rebuild (collectively), resume, keep queueing                     */
-    int32_t stop;             /* loop bound reached                                                        */
-    int32_t error;            /* 1: non-positive / NaN Δt, 2: non-positive density                         */
-    int32_t reserved;
-} sphmi_dd_control;
-int sphmi_dd_ctrl_init(sphmi_handle* h, double delta_x, double t_target, int64_t max_steps);
-int sphmi_dd_step_control(sphmi_handle* h, void* red4_dev);
-int sphmi_dd_ctrl_sync(sphmi_handle* h, sphmi_dd_control* out);
-int sphmi_dd_ctrl_resume(sphmi_handle* h);
-int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id,
-                            int64_t* n_out);                          /* host fp64 arrays, owned only      */
-int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out);
+/* (Test hooks of the slab driver — the shared-memory transport's self-test, initial cuts, host-only planning, the work
+ * measure of the re-cut — are declared in include/sphmi_internal.h; they are not part of the drop-in boundary.) */
 
 #ifdef __cplusplus
 }

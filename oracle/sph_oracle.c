@@ -43,6 +43,7 @@ typedef struct orc_handle {
     double  *pos, *vel, *acc, *rho, *press, *gf, *ml, *ghost;
     uint8_t *type;
     int64_t *id;
+    int64_t *prow;   /* row of every particle at the last orc_download_permutation: one more column that sort! permutes */
     uint64_t *group;
     int64_t *cells;          /* N*D */
     /* support arrays (src/PreProcess.jl:121-158) — NOT permuted by the sort */
@@ -252,6 +253,7 @@ static void update_neighbors(orc_handle *o) {
         permute_f64(o, o->ml, 1);
         permute_f64(o, o->ghost, D);
         permute_i64(o, o->id, 1);
+        permute_i64(o, o->prow, 1);
         permute_i64(o, (int64_t *)o->group, 1);
         permute_u8(o, o->type);
     }
@@ -756,7 +758,7 @@ int orc_create(const sphmi_config *cfg, orc_handle **out) {
     const size_t N = (size_t)o->N, D = (size_t)o->D;
     o->pos = xcalloc(N * D, 8); o->vel = xcalloc(N * D, 8); o->acc = xcalloc(N * D, 8);
     o->rho = xcalloc(N, 8); o->press = xcalloc(N, 8); o->gf = xcalloc(N, 8); o->ml = xcalloc(N, 8);
-    o->ghost = xcalloc(N * D, 8); o->type = xcalloc(N, 1); o->id = xcalloc(N, 8); o->group = xcalloc(N, 8);
+    o->ghost = xcalloc(N * D, 8); o->type = xcalloc(N, 1); o->id = xcalloc(N, 8); o->prow = xcalloc(N, 8); o->group = xcalloc(N, 8);
     o->cells = xcalloc(N * D, 8);
     o->drhodt = xcalloc(N, 8); o->vel_np = xcalloc(N * D, 8); o->pos_np = xcalloc(N * D, 8); o->rho_np = xcalloc(N, 8);
     o->ranges = xcalloc(N + 2, 8); o->ucells = xcalloc((N + 1) * D, 8);
@@ -802,7 +804,7 @@ int orc_destroy(orc_handle *o) {
     free(o->drhodt_thr); free(o->acc_thr); free(o->gradC_thr); free(o->divr_thr); free(o->kern_thr); free(o->kgrad_thr);
     free(o->gradC); free(o->divr); free(o->kern); free(o->kgrad);
     free(o->pos); free(o->vel); free(o->acc); free(o->rho); free(o->press); free(o->gf); free(o->ml);
-    free(o->ghost); free(o->type); free(o->id); free(o->group); free(o->cells);
+    free(o->ghost); free(o->type); free(o->id); free(o->prow); free(o->group); free(o->cells);
     free(o->drhodt); free(o->vel_np); free(o->pos_np); free(o->rho_np);
     free(o->ranges); free(o->ucells); free(o->perm); free(o->perm_tmp); free(o->scratch);
     free(o->bgam); free(o->Agam);
@@ -821,6 +823,7 @@ int orc_upload(orc_handle *o, const double *position, const double *velocity, co
     memcpy(o->rho, density, N * 8);
     memcpy(o->type, type, N);
     memcpy(o->id, id, N * 8);
+    for (int64_t i = 0; i < (int64_t)N; ++i) o->prow[i] = i;
     if (group) memcpy(o->group, group, N * 8); else memset(o->group, 0, N * 8);
     if (ghost_points) memcpy(o->ghost, ghost_points, N * D * 8); else memset(o->ghost, 0, N * D * 8);
     /* src/PreProcess.jl:78-98 */
@@ -835,6 +838,14 @@ int orc_upload(orc_handle *o, const double *position, const double *velocity, co
     pressure(o, o->press, o->rho);         /* src/SPHCellList.jl:835 */
     o->index_counter = 0;
     o->uploaded = 1;
+    return SPHMI_OK;
+}
+
+/* The sort as a permutation (include/sphmi.h: sphmi_download_permutation): the reference's sort! (src/SPHCellList.jl:142)
+ * permutes every column of the StructArray; `prow` is a row-number column that rides along. */
+int orc_download_permutation(orc_handle *o, int64_t *prev_row) {
+    if (!o || !prev_row) return SPHMI_ERR_ARGUMENT;
+    for (int64_t i = 0; i < o->N; ++i) { prev_row[i] = o->prow[i]; o->prow[i] = i; }
     return SPHMI_OK;
 }
 

@@ -276,6 +276,15 @@ class Backend:
         self._check(self._fn("download_kernel_output")(self._h, _ptr(k), _ptr(g)))
         return k, g
 
+    def download_permutation(self) -> np.ndarray:
+        """prev_row: row i of what download() returns now was row prev_row[i] at the previous call (at the upload for the
+        first).  The reference's sort! permutes all 17 fields of the StructArray (src/SPHCellList.jl:142); this is what lets
+        the caller bring along the fields the engine does not carry (`permute_passive_fields`)."""
+        self._fn("download_permutation").argtypes = [C.c_void_p, C.c_void_p]
+        out = np.empty(self.N, dtype=np.int64)
+        self._check(self._fn("download_permutation")(self._h, _ptr(out)))
+        return out
+
     def forces_once(self, apply_mdbc: bool = False):
         drho = np.empty(self.N, dtype=self._ft)
         acc = np.empty((self.N, self.D), dtype=self._ft)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/sphmi.h"
+#include "../../include/sphmi_internal.h"
 #include "sphmi_kernels.h"
 #include "sphmi_rebuild.h"
 
@@ -39,6 +40,16 @@ static const char* kPhaseNames[PH_COUNT] = {
     "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
     "05 First NeighborLoop (+06/07 half step)", "08 Second NeighborLoop (+09/10/11 full step)"};
 
+// what the slab driver reads back after a batch of queued steps (Engine::dd_ctrl_sync)
+struct sphmi_dd_control {
+    int64_t steps_done;       // steps executed since dd_ctrl_init
+    double total_time, last_dt, delta_x;
+    int32_t need_rebuild;     // Δx ≥ h: rebuild (collectively), resume, keep queueing
+    int32_t stop;             // loop bound reached
+    int32_t error;            // 1: non-positive / NaN Δt, 2: non-positive density
+    int32_t reserved;
+};
+
 struct EngineBase {
     sphmi_config cfg{};
     std::string err;
@@ -57,6 +68,7 @@ struct EngineBase {
     virtual void host_unregister(void* p) = 0;
     virtual void forces_once(int apply_mdbc, void* drhodt, void* acc) = 0;
     virtual void download_kernel_output(void* kernel, void* kernel_gradient) = 0;
+    virtual void download_permutation(int64_t* prev_row) = 0;
     virtual void unique_cells(int64_t* out, int64_t cap, int64_t* n) = 0;
     virtual void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) = 0;
     virtual void force_stats(int reset, double* avg_ms, int64_t* launches) = 0;
@@ -64,37 +76,7 @@ struct EngineBase {
     virtual void reset_count() = 0;
     virtual int64_t owned_count() { return cfg.n_particles; }
     virtual void generate_dam_break_3d(double) { throw EngineError(SPHMI_ERR_STATE, "sphmi_generate_dam_break_3d: single-device handles only"); }
-    // domain decomposition, verb by verb (slab handles only)
-    [[noreturn]] static void not_a_slab() { throw EngineError(SPHMI_ERR_STATE, "not a slab handle: sphmi_dd_* verbs need a single-device handle"); }
     virtual void set_motion(uint64_t group, double vel, double start, double dur, const double* dir) = 0;
-    virtual void dd_set_stream(void* s) { not_a_slab(); }
-    virtual void dd_upload(int64_t, const void*, const void*, const void*, const void*, const uint8_t*,
-                           const int64_t*, const uint64_t*, const void*, const int64_t*) { not_a_slab(); }
-    virtual void dd_progress_motion() { not_a_slab(); }
-    virtual void dd_mdbc() { not_a_slab(); }
-    virtual int64_t dd_count() { not_a_slab(); return 0; }
-    virtual void dd_cell_x(int32_t* out_host) { not_a_slab(); }
-    virtual void dd_types(uint8_t* out_host) { not_a_slab(); }
-    virtual void dd_cell_x_dev(int32_t* out_dev) { not_a_slab(); }
-    virtual void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) { not_a_slab(); }
-    virtual void dd_types_dev(uint8_t* out_dev) { not_a_slab(); }
-    virtual size_t dd_record_bytes(int64_t n) { not_a_slab(); return 0; }
-    virtual void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) { not_a_slab(); }
-    virtual void dd_kill(const int32_t* idx_dev, int64_t n) { not_a_slab(); }
-    virtual void dd_kill_ghosts() { not_a_slab(); }
-    virtual void dd_append(const void* buf_dev, int64_t n, int flag) { not_a_slab(); }
-    virtual void dd_rebuild() { not_a_slab(); }
-    virtual void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { not_a_slab(); }
-    virtual void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { not_a_slab(); }
-    virtual void dd_reductions(double* out8) { not_a_slab(); }
-    virtual void dd_reductions_dev(void* out4_dev) { not_a_slab(); }
-    virtual void dd_pass(int which, double dt, int part) { not_a_slab(); }
-    virtual void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) { not_a_slab(); }
-    virtual void dd_ctrl_init(double delta_x, double t_target, int64_t max_steps) { not_a_slab(); }
-    virtual void dd_step_control(void* red4_dev) { not_a_slab(); }
-    virtual void dd_ctrl_sync(sphmi_dd_control* out) { not_a_slab(); }
-    virtual void dd_ctrl_resume() { not_a_slab(); }
-    virtual void dd_download_owned(void* pos, void* vel, void* rho, int64_t* id, int64_t* n_out) { not_a_slab(); }
 };
 
 template <class T>
@@ -115,6 +97,7 @@ struct Engine final : EngineBase {
     long long* id[2] = {};
     unsigned long long* grp[2] = {};
     unsigned long long* otag[2] = {};  // order tags (sphmi_rebuild.h, k_rankfix_tag): slab handles only
+    int* prow[2] = {};                 // row of every particle at the last sphmi_download_permutation (the sort permutes it along)
     int* key[2] = {};
     int cur = 0;                       // which of the [2] copies is live
     int *slot = nullptr, *tmp_idx = nullptr, *perm = nullptr;
@@ -211,6 +194,7 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&id[k], n * 8));
             HC(hipMalloc(&grp[k], n * 8));
             HC(hipMalloc(&key[k], n * 4));
+            HC(hipMalloc(&prow[k], n * 4));
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
         const size_t nt = n / kWave + 2;
@@ -235,7 +219,7 @@ struct Engine final : EngineBase {
         for (int k = 0; k < 3; ++k) (void)hipFree(rec[k]);
         for (int k = 0; k < 2; ++k) {
             (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]); (void)hipFree(otag[k]);
-            (void)hipFree(grp[k]); (void)hipFree(key[k]);
+            (void)hipFree(grp[k]); (void)hipFree(key[k]); (void)hipFree(prow[k]);
         }
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); (void)hipEventDestroy(ev_packed); }
         for (auto& e : host_pinned) (void)hipHostUnregister(e.first);
@@ -520,6 +504,7 @@ struct Engine final : EngineBase {
         A.grp_in = grp[cur]; A.grp_out = grp[nxt];
         A.key_in = key[cur]; A.key_out = key[nxt];
         A.tag_in = otag[cur]; A.tag_out = otag[nxt];
+        A.prow_in = prow[cur]; A.prow_out = prow[nxt];
         A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
         if (otag[0]) {
@@ -772,6 +757,7 @@ struct Engine final : EngineBase {
         HC(hipMemsetAsync(red_d, 0, 8 * 8, stream));
         cpar = 0; rpar = 0;
         const int nb256 = (N + 255) / 256;
+        hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
         // Pressure! (src/SPHCellList.jl:835) and the reductions Δt / update_delta_x! will read first
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
                            (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
@@ -831,6 +817,7 @@ struct Engine final : EngineBase {
             HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
             HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); cpar = 0; rpar = 0;
             const int nb256 = (N + 255) / 256;
+            hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
             hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
             hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d);
             HC(hipGetLastError());
@@ -867,6 +854,7 @@ struct Engine final : EngineBase {
         }
     }
     hipStream_t copy_stream = nullptr; hipEvent_t ev_packed = nullptr; bool download_pending = false;
+    unsigned long long* dl_tags_host = nullptr;    // slab engines: the order tags travel with a download (the multi-device handle merges by them)
     int out_comp = 0;          // components per output vector: D, or 3 (sphmi_set_output_components)
     void set_output_components(int c) override {
         if (c != D && c != 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_output_components: dims or 3");
@@ -880,7 +868,7 @@ struct Engine final : EngineBase {
         if (!copy_stream) { HC(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); HC(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)); }
         if (download_pending) { HC(hipStreamSynchronize(copy_stream)); download_pending = false; }
         const size_t n = (size_t)N, nd = n * (size_t)out_comp, ncell_d = n * (size_t)D;
-        const size_t need = (4 * nd + 2 * n) * sizeof(H) + ncell_d * 8 + n * 17 + 256 * 12;
+        const size_t need = (4 * nd + 2 * n) * sizeof(H) + ncell_d * 8 + n * 25 + 256 * 13;
         if (need > out_arena_bytes) {
             (void)hipFree(out_arena);
             out_arena = nullptr; out_arena_bytes = 0;
@@ -898,6 +886,7 @@ struct Engine final : EngineBase {
         o.press = (H*)take(pressure, n * sizeof(H)); o.ghost = (H*)take(ghost_points, nd * sizeof(H));
         o.cells = (long long*)take(cells, ncell_d * 8);
         char* a_id = take(ids, n * 8); char* a_ty = take(ty, n); char* a_grp = take(groups, n * 8);
+        char* a_tag = take(dl_tags_host != nullptr && otag[0], n * 8);
         hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
                            stepped ? Half<const V4>(pk0[iH]) : Half<const V4>(), acc[cur], ghost[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
                            (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
@@ -905,6 +894,7 @@ struct Engine final : EngineBase {
         if (a_id) HC(hipMemcpyAsync(a_id, id[cur], n * 8, hipMemcpyDeviceToDevice, stream));
         if (a_ty) HC(hipMemcpyAsync(a_ty, type[cur], n, hipMemcpyDeviceToDevice, stream));
         if (a_grp) HC(hipMemcpyAsync(a_grp, grp[cur], n * 8, hipMemcpyDeviceToDevice, stream));
+        if (a_tag) HC(hipMemcpyAsync(a_tag, otag[cur], n * 8, hipMemcpyDeviceToDevice, stream));
         HC(hipEventRecord(ev_packed, stream));
         HC(hipStreamWaitEvent(copy_stream, ev_packed, 0));
         auto copy = [&](void* dst, const void* src, size_t bytes) {
@@ -916,6 +906,7 @@ struct Engine final : EngineBase {
         copy(pressure, o.press, n * sizeof(H)); copy(ghost_points, o.ghost, nd * sizeof(H));
         copy(cells, o.cells, ncell_d * 8);
         copy(ids, a_id, n * 8); copy(ty, a_ty, n); copy(groups, a_grp, n * 8);
+        if (a_tag) copy(dl_tags_host, a_tag, n * 8);
         download_pending = true;
     }
     void download_begin(void* position, void* velocity, void* acceleration, void* density, void* pressure,
@@ -947,20 +938,44 @@ struct Engine final : EngineBase {
         if (kernel_gradient) { if (h8) unpack3(tmp, (double*)kernel_gradient, N, D); else unpack3(tmp, (float*)kernel_gradient, N, D); }
         if (kernel) for (int i = 0; i < N; ++i) { if (h8) ((double*)kernel)[i] = (double)tmp[i].w; else ((float*)kernel)[i] = (float)tmp[i].w; }
     }
-    void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {
-        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once before sphmi_upload");
+    // sphmi_download_permutation: the sort carried every particle's row at the previous call along (prow); hand it over and
+    // start counting from the present order.  The reference's sort! permutes all 17 fields of the StructArray
+    // (src/SPHCellList.jl:142); the engine carries ten of them, and this is what lets the caller permute the rest.
+    void download_permutation(int64_t* prev_row) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation before sphmi_upload");
+        if (!prev_row) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_download_permutation: null array");
         HC(hipSetDevice(cfg.device));
-        rebuild();
+        std::vector<int> tmp((size_t)N);
+        HC(hipMemcpyAsync(tmp.data(), prow[cur], (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_iota, dim3((N + 255) / 256), dim3(256), 0, stream, prow[cur], N);
+        HC(hipGetLastError());
+        HC(hipStreamSynchronize(stream));
+        for (int i = 0; i < N; ++i) prev_row[i] = tmp[(size_t)i];
+    }
+    // Pressure! + [mDBC] + ONE forces-only neighbour pass on the current cell list; {a, dρ/dt} of every particle held are left
+    // in the scratch record array rec[iB] (N contiguous packets), SimParticles.Acceleration survives.  all_lists: a slab
+    // engine runs its interior and its slab-edge tiles (the ghost layers must be current: the caller has just rebuilt).
+    void forces_local(int apply_mdbc, bool all_lists) {
         const int nb256 = (N + 255) / 256;
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
                            (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
         if (apply_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc();
-        // the forces-only pass writes {a, dρ/dt} into a scratch set so SimParticles.Acceleration survives
         ForceParams<T> P = force_params(iA, iA, iH, 0.0);
         P.accbuf = rec[iB];                       // (scratch: N contiguous packets at the start of the third record array)
         Ev e1 = begin_phase(PH_PASS1);
         launch_force<PASS_FORCES_ONLY>(P);
         end_phase(e1);
+        if (all_lists && part_max[1] > 0) {
+            Ev e2 = begin_phase(PH_PASS1_EDGE);
+            launch_force<PASS_FORCES_ONLY>(P, 1);
+            end_phase(e2);
+        }
+    }
+    void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once before sphmi_upload");
+        HC(hipSetDevice(cfg.device));
+        rebuild();
+        forces_local(apply_mdbc, false);
         sync_and_collect();
         std::vector<V4> tmp(N);
         HC(hipMemcpy(tmp.data(), rec[iB], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
@@ -1005,15 +1020,10 @@ struct Engine final : EngineBase {
     }
 
 
-    // ---- domain decomposition (driven per step by sphexample_amd/distributed.py) ---------------
-    void dd_set_stream(void* sp) override {
-        if (stream && own_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
-        stream = (hipStream_t)sp;
-        own_stream = false;
-    }
+    // ---- domain decomposition: what the slab driver (sphmi_multi.h, MultiEngine) asks of one slab engine ---------------
     void dd_upload(int64_t n, const void* position, const void* velocity, const void* acceleration,
                    const void* density, const uint8_t* ty, const int64_t* ids, const uint64_t* groups,
-                   const void* ghost_points, const int64_t* upload_index) override {
+                   const void* ghost_points, const int64_t* upload_index) {
         if (n < 1 || n > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: particle count exceeds the handle's capacity");
         if (cfg.mdbc != SPHMI_MDBC_NONE && !ghost_points)
             throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_upload: mDBC handle without ghost points");
@@ -1028,71 +1038,52 @@ struct Engine final : EngineBase {
     }
     // ProgressMotion of the queued step (src/SPHCellList.jl:765,787) on owned particles AND ghost copies — a prescribed
     // motion is the same function of time on every rank — before the halo of the pass is packed
-    void dd_progress_motion() override {
+    void dd_progress_motion() {
         if (!dd_ctrl_on) throw EngineError(SPHMI_ERR_STATE, "sphmi_dd_progress_motion needs sphmi_dd_ctrl_init");
         HC(hipSetDevice(cfg.device));
         progress_motion(0.0, ctrl_d);
     }
     // mDBC (:772) for every boundary particle held, ghost copies included: with a halo wide enough (distributed.py)
     // the copies a pass can see get the owner's value up to summation order, and nothing has to travel twice
-    void dd_mdbc() override {
+    void dd_mdbc() {
         if (cfg.mdbc != SPHMI_MDBC_SIMPLE) return;
         HC(hipSetDevice(cfg.device));
         run_mdbc(dd_ctrl_on ? ctrl_d : nullptr);
     }
-    int64_t dd_count() override { return N; }
     void reset_count() override { N = cap; }
-    void dd_cell_x(int32_t* out_host) override {
-        HC(hipSetDevice(cfg.device));
-        if (!cellx_d) HC(hipMalloc(&cellx_d, (size_t)cap * 4));
-        hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, dd_axis, cellx_d);
-        HC(hipGetLastError());
-        HC(hipMemcpyAsync(out_host, cellx_d, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
-        HC(hipStreamSynchronize(stream));
-    }
     // the same two arrays into DEVICE buffers of the caller, in stream order (no host round trip: the driver builds its
     // migration / ghost-layer / halo index lists with device-side compaction)
-    void dd_cell_x_dev(int32_t* out_dev) override {
+    void dd_cell_x_dev(int32_t* out_dev) {
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_cellx<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], N, (T)cfg.H_inv, dd_axis, (int*)out_dev);
         HC(hipGetLastError());
     }
-    void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) override {
+    void dd_column_cost(int64_t col0, int32_t ncols, uint64_t* out_dev) {
         if (!have_grid) throw EngineError(SPHMI_ERR_STATE, "sphmi_dd_column_cost before the first rebuild");
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_column_cost, dim3((N + 255) / 256), dim3(256), 0, stream, key[cur], type[cur], cstart, N, grid, D, dd_axis,
                            (long long)col0, (int)ncols, (unsigned long long*)out_dev);
         HC(hipGetLastError());
     }
-    void dd_types_dev(uint8_t* out_dev) override {
-        HC(hipSetDevice(cfg.device));
-        HC(hipMemcpyAsync(out_dev, type[cur], (size_t)N, hipMemcpyDeviceToDevice, stream));
-    }
-    void dd_types(uint8_t* out_host) override {
-        HC(hipSetDevice(cfg.device));
-        HC(hipMemcpyAsync(out_host, type[cur], (size_t)N, hipMemcpyDeviceToHost, stream));
-        HC(hipStreamSynchronize(stream));
-    }
-    size_t dd_record_bytes(int64_t n) override { return DdRecord<T>::bytes((size_t)n); }
-    void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) override {
+    void dd_gather(const int32_t* idx_dev, int64_t n, void* buf_dev) {
         if (n <= 0) return;
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
                            ghost[cur], id[cur], grp[cur], otag[cur], type[cur], idx_dev, (int)n, buf_dev);
         HC(hipGetLastError());
     }
-    void dd_kill(const int32_t* idx_dev, int64_t n) override {
+    void dd_kill(const int32_t* idx_dev, int64_t n) {
         if (n <= 0) return;
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_kill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, type[cur], idx_dev, (int)n);
         HC(hipGetLastError());
     }
-    void dd_kill_ghosts() override {
+    void dd_kill_ghosts() {
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_kill_ghosts, dim3((N + 255) / 256), dim3(256), 0, stream, type[cur], N);
         HC(hipGetLastError());
     }
-    void dd_append(const void* buf_dev, int64_t n, int flag) override {
+    void dd_append(const void* buf_dev, int64_t n, int flag) {
         if (n <= 0) return;
         if ((int64_t)N + n > cap) throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: rank capacity exceeded (too many arrivals)");
         HC(hipSetDevice(cfg.device));
@@ -1101,7 +1092,7 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
         N += (int)n;
     }
-    void dd_rebuild() override {
+    void dd_rebuild() {
         HC(hipSetDevice(cfg.device));
         rebuild();
         int live = 0;
@@ -1110,39 +1101,10 @@ struct Engine final : EngineBase {
         if (live < N) index_counter -= 1;      // the graveyard is not a cell
         N = live;
     }
-    void dd_halo_pack(int set, const int32_t* idx_dev, int64_t n, void* buf_dev) override {
-        if (n <= 0) return;
-        const int s_ = set == 0 ? iA : iH;
-        hipLaunchKernelGGL(k_halo_pack<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[s_], pk1[s_], idx_dev, (int)n, (V4*)buf_dev);
-        HC(hipGetLastError());
-    }
-    void dd_halo_unpack(int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) override {
-        if (n <= 0) return;
-        const int s_ = set == 0 ? iA : iH;
-        hipLaunchKernelGGL(k_halo_unpack<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[s_], pk1[s_], idx_dev, (int)n, (const V4*)buf_dev);
-        HC(hipGetLastError());
-    }
-    // local reductions of the previous corrector (or of the upload), decoded; resets the device slots
-    void dd_reductions(double* out8) override {
-        HC(hipSetDevice(cfg.device));
-        HC(hipMemcpyAsync(red_h, red_d, 4 * 8, hipMemcpyDeviceToHost, stream));
-        HC(hipMemsetAsync(red_d, 0, 4 * 8, stream));
-        sync_and_collect();
-        out8[0] = decode(red_h[0]); out8[1] = decode(red_h[1]); out8[2] = decode(red_h[2]); out8[3] = red_h[3] ? 1.0 : 0.0;
-        for (int k = 4; k < 8; ++k) out8[k] = 0.0;
-    }
-    // the four reduction slots as raw bit patterns (non-negative floats: integer MAX = float MAX, NaN on top)
-    // into a caller-owned device buffer of 4 × int64, then reset — no host round trip before the allreduce
-    void dd_reductions_dev(void* out4_dev) override {
-        HC(hipSetDevice(cfg.device));
-        serve_reschedules();                                                               // main stream, after the join
-        hipLaunchKernelGGL(k_take_reductions, dim3(1), dim3(64), 0, stream, red_d, (unsigned long long*)out4_dev);
-        HC(hipGetLastError());
-    }
     // ---- device-side step control for the slab driver: same k_step_control as Engine::advance, fed with the
     // MAX-allreduced reduction slots, so the host looks at the flags once per batch of queued steps --------------
     bool dd_ctrl_on = false; int dd_a0 = 0, dd_b0 = 0; int64_t dd_steps_at_sync = 0;
-    void dd_ctrl_init(double dx0, double t_target, int64_t max_steps) override {
+    void dd_ctrl_init(double dx0, double t_target, int64_t max_steps) {
         HC(hipSetDevice(cfg.device));
         StepCtrl c{};
         c.delta_x = dx0; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
@@ -1151,13 +1113,13 @@ struct Engine final : EngineBase {
         HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
         dd_ctrl_on = true; dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = 0; batch_step = -1;
     }
-    void dd_step_control(void* red4_dev) override {
+    void dd_step_control(void* red4_dev) {
         HC(hipSetDevice(cfg.device));
         batch_step += 1;
         hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, (unsigned long long*)red4_dev, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
         HC(hipGetLastError());
     }
-    void dd_ctrl_sync(sphmi_dd_control* out) override {
+    void dd_ctrl_sync(sphmi_dd_control* out) {
         HC(hipSetDevice(cfg.device));
         HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));
         sync_and_collect(ctrl_h, dd_steps_at_sync);
@@ -1174,18 +1136,18 @@ struct Engine final : EngineBase {
             out->need_rebuild = c.need_rebuild; out->stop = c.stop; out->error = c.error; out->reserved = 0;
         }
     }
-    void dd_ctrl_resume() override {
+    void dd_ctrl_resume() {
         HC(hipSetDevice(cfg.device));
         ctrl_h->delta_x = 0.0; ctrl_h->need_rebuild = 0;          // `resume` stays set: the queued step re-uses its Δt
         HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
         dd_a0 = iA; dd_b0 = iB;                                  // the rebuild may have swapped the sets
     }
-    void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) override {
+    void dd_set_slab(int axis, int64_t lo, int64_t hi, int has_lo, int has_hi) {
         if (axis < 0 || axis >= D) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_set_slab: axis out of range");
         dd_slab = true; dd_axis = axis; dd_col_lo = lo; dd_col_hi = hi; dd_has_lo = has_lo != 0; dd_has_hi = has_hi != 0;
     }
     // part: 0 = the whole pass, 1 = interior tiles only, 2 = slab-edge tiles only (after the halo has landed)
-    void dd_pass(int which, double dt, int part) override {
+    void dd_pass(int which, double dt, int part) {
         HC(hipSetDevice(cfg.device));
         if (which != 1 && which != 2) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_dd_pass: which must be 1 or 2");
         ForceParams<T> P = which == 1 ? force_params(iA, iA, iH, dt) : force_params(iH, iA, iB, dt);
@@ -1205,32 +1167,6 @@ struct Engine final : EngineBase {
             if (!dd_ctrl_on) { stepped = true; iteration += 1; last_dt = dt; total_time += dt; }   // else: dd_ctrl_sync
         }
     }
-    void dd_download_owned(void* pos, void* vel, void* rho, int64_t* ids, int64_t* n_out) override {
-        HC(hipSetDevice(cfg.device));
-        HC(hipStreamSynchronize(stream));
-        std::vector<V4> h0(N), h1(N);
-        std::vector<uint8_t> ty(N);
-        std::vector<long long> idv(N);
-        {
-            std::vector<V4> hrec(2 * (size_t)N);
-            HC(hipMemcpy(hrec.data(), rec[iA], 2 * (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
-            for (int i = 0; i < N; ++i) { h0[i] = hrec[2 * (size_t)i]; h1[i] = hrec[2 * (size_t)i + 1]; }
-        }
-        HC(hipMemcpy(ty.data(), type[cur], (size_t)N, hipMemcpyDeviceToHost));
-        HC(hipMemcpy(idv.data(), id[cur], (size_t)N * 8, hipMemcpyDeviceToHost));
-        int64_t m = 0;
-        double* P_ = (double*)pos; double* V_ = (double*)vel; double* R_ = (double*)rho;
-        for (int i = 0; i < N; ++i) {
-            if (ty[i] == 0 || (ty[i] & kGhostMask)) continue;
-            P_[m * D] = h0[i].x; P_[m * D + 1] = h0[i].y; if (D == 3) P_[m * D + 2] = h0[i].z;
-            V_[m * D] = h1[i].x; V_[m * D + 1] = h1[i].y; if (D == 3) V_[m * D + 2] = h1[i].z;
-            R_[m] = std::fabs((double)h0[i].w);
-            ids[m] = idv[i];
-            ++m;
-        }
-        *n_out = m;
-    }
-
     void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
         if (n) *n = PH_COUNT;
         for (int i = 0; i < PH_COUNT && i < cap; ++i) {
@@ -1279,14 +1215,15 @@ const char* sphmi_last_error(const sphmi_handle* h) {
     return h->e->err.c_str();
 }
 
-static int check_config(const sphmi_config* cfg, std::string& why);
+static int check_config(const sphmi_config* cfg, int slabs, std::string& why);
 
 static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out) {
     using namespace sphmi;
     auto fail = [&](int st, const std::string& m) { g_create_error = m; return st; };
     if (!cfg || !out) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: null argument");
     std::string why;
-    if (int st = check_config(cfg, why)) return fail(st, why);
+    // slabs the particle set is spread over: sphmi_create_rank's world, or the device list of sphmi_create
+    if (int st = check_config(cfg, rank >= 0 ? std::max(world, 1) : std::max(cfg->n_devices, 1), why)) return fail(st, why);
     try {
         sphmi_handle* h = new sphmi_handle{nullptr};
         try {
@@ -1318,10 +1255,11 @@ int sphmi_rccl_unique_id(void* id_out) {
     if (!id_out) return SPHMI_ERR_ARGUMENT;
     try {
         ncclUniqueId id;
-        NC(Rccl::get().GetUniqueId(&id));
+        NCX("ncclGetUniqueId", 0, -1, nullptr, Rccl::get().GetUniqueId(&id));
         memcpy(id_out, &id, sizeof id);
         return SPHMI_OK;
     } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
+    catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_DEVICE; }
 }
 int sphmi_shm_selftest(const void* unique_id, int32_t rank, int32_t world, int64_t n_bytes) {
     using namespace sphmi;
@@ -1392,6 +1330,14 @@ int sphmi_multi_set_cuts(sphmi_handle* h, const int64_t* cuts, int32_t n) {
         else throw sphmi::EngineError(SPHMI_ERR_STATE, "sphmi_multi_set_cuts: not a multi-device handle");
     }()));
 }
+int sphmi_multi_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_out) {
+    if (!cost_out || ncols < 1) return SPHMI_ERR_ARGUMENT;
+    SPHMI_GUARD(h, ([&] {
+        if (auto* m = dynamic_cast<sphmi::MultiEngine<float>*>(h->e)) m->column_cost(col0, ncols, cost_out);
+        else if (auto* d = dynamic_cast<sphmi::MultiEngine<double>*>(h->e)) d->column_cost(col0, ncols, cost_out);
+        else throw sphmi::EngineError(SPHMI_ERR_STATE, "sphmi_multi_column_cost: not a multi-device handle");
+    }()));
+}
 int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* ghost_points, int64_t n, int32_t world,
                      int32_t* axis_out, int32_t* halo_width_out, int64_t* cuts_out, int64_t* owned_out, int64_t* capacity_out) {
     using namespace sphmi;
@@ -1409,7 +1355,7 @@ int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* 
     catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_ARGUMENT; }
 }
 
-static int check_config(const sphmi_config* cfg, std::string& why) {
+static int check_config(const sphmi_config* cfg, int slabs, std::string& why) {
     auto fail = [&](int st, const std::string& m) { why = m; return st; };
     if (cfg->struct_size != (int32_t)sizeof(sphmi_config) || cfg->abi_version != SPHMI_ABI_VERSION)
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: struct_size / abi_version mismatch");
@@ -1420,7 +1366,7 @@ static int check_config(const sphmi_config* cfg, std::string& why) {
     // the neighbour gathers use 32-bit buffer offsets: n × sizeof(packet) must stay below 4 GB
     // (n × sizeof(packet) < 4 GB: 2^27 packets of 16 bytes, 2^26 of 32; a multi-device handle holds n / devices per slab)
     {
-        const int64_t per = (cfg->n_devices > 1) ? (cfg->n_particles + cfg->n_devices - 1) / cfg->n_devices : cfg->n_particles;
+        const int64_t per = slabs > 1 ? (cfg->n_particles + slabs - 1) / slabs : cfg->n_particles;
         const int64_t lim = (cfg->device_float_bytes == 8 ? (1ll << 26) : (1ll << 27)) - 1;     // N × record size (64 / 32 bytes) < 4 GB
         if (cfg->n_particles < 1 || per > lim)
             return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: n_particles out of range [1, 2^27) (fp32 kernels) / [1, 2^26) (fp64 kernels) per device");
@@ -1457,49 +1403,6 @@ int sphmi_upload(sphmi_handle* h, const void* position, const void* velocity, co
     SPHMI_GUARD(h, (h->e->reset_count(), h->e->upload(position, velocity, acceleration, density, type, id, group_marker, ghost_points)));
 }
 
-int sphmi_dd_set_stream(sphmi_handle* h, void* hip_stream) { SPHMI_GUARD(h, h->e->dd_set_stream(hip_stream)); }
-int sphmi_dd_upload(sphmi_handle* h, int64_t n, const void* position, const void* velocity, const void* acceleration,
-                    const void* density, const uint8_t* type, const int64_t* id, const uint64_t* group_marker,
-                    const void* ghost_points, const int64_t* upload_index) {
-    SPHMI_GUARD(h, h->e->dd_upload(n, position, velocity, acceleration, density, type, id, group_marker, ghost_points, upload_index));
-}
-int sphmi_dd_progress_motion(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_progress_motion()); }
-int sphmi_dd_mdbc(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_mdbc()); }
-int sphmi_dd_count(sphmi_handle* h, int64_t* n_out) { if (!n_out) return SPHMI_ERR_ARGUMENT; SPHMI_GUARD(h, *n_out = h->e->dd_count()); }
-int sphmi_dd_cell_x(sphmi_handle* h, int32_t* cell_x_out) { SPHMI_GUARD(h, h->e->dd_cell_x(cell_x_out)); }
-int sphmi_dd_types(sphmi_handle* h, uint8_t* type_out) { SPHMI_GUARD(h, h->e->dd_types(type_out)); }
-int sphmi_dd_cell_x_dev(sphmi_handle* h, int32_t* cell_x_dev) { SPHMI_GUARD(h, h->e->dd_cell_x_dev(cell_x_dev)); }
-int sphmi_dd_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_dev) { SPHMI_GUARD(h, h->e->dd_column_cost(col0, ncols, cost_dev)); }
-int sphmi_dd_types_dev(sphmi_handle* h, uint8_t* type_dev) { SPHMI_GUARD(h, h->e->dd_types_dev(type_dev)); }
-int sphmi_dd_record_bytes(sphmi_handle* h, int64_t n, int64_t* bytes_out) { if (!bytes_out) return SPHMI_ERR_ARGUMENT; SPHMI_GUARD(h, *bytes_out = (int64_t)h->e->dd_record_bytes(n)); }
-int sphmi_dd_gather(sphmi_handle* h, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_gather(idx_dev, n, buf_dev)); }
-int sphmi_dd_kill(sphmi_handle* h, const int32_t* idx_dev, int64_t n) { SPHMI_GUARD(h, h->e->dd_kill(idx_dev, n)); }
-int sphmi_dd_kill_ghosts(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_kill_ghosts()); }
-int sphmi_dd_append(sphmi_handle* h, const void* buf_dev, int64_t n, int flag) { SPHMI_GUARD(h, h->e->dd_append(buf_dev, n, flag)); }
-int sphmi_dd_rebuild(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_rebuild()); }
-int sphmi_dd_halo_pack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_pack(set, idx_dev, n, buf_dev)); }
-int sphmi_dd_halo_unpack(sphmi_handle* h, int set, const int32_t* idx_dev, int64_t n, const void* buf_dev) { SPHMI_GUARD(h, h->e->dd_halo_unpack(set, idx_dev, n, buf_dev)); }
-int sphmi_dd_reductions_dev(sphmi_handle* h, void* out4_dev) { SPHMI_GUARD(h, h->e->dd_reductions_dev(out4_dev)); }
-int sphmi_dd_reductions(sphmi_handle* h, double* out8) { SPHMI_GUARD(h, h->e->dd_reductions(out8)); }
-int sphmi_dd_pass(sphmi_handle* h, int which, double dt) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, 0)); }
-int sphmi_dd_pass_part(sphmi_handle* h, int which, double dt, int part) { SPHMI_GUARD(h, h->e->dd_pass(which, dt, part)); }
-int sphmi_dd_ctrl_init(sphmi_handle* h, double delta_x, double t_target, int64_t max_steps) { SPHMI_GUARD(h, h->e->dd_ctrl_init(delta_x, t_target, max_steps)); }
-int sphmi_dd_step_control(sphmi_handle* h, void* red4_dev) { SPHMI_GUARD(h, h->e->dd_step_control(red4_dev)); }
-int sphmi_dd_ctrl_sync(sphmi_handle* h, sphmi_dd_control* out) { SPHMI_GUARD(h, h->e->dd_ctrl_sync(out)); }
-int sphmi_dd_ctrl_resume(sphmi_handle* h) { SPHMI_GUARD(h, h->e->dd_ctrl_resume()); }
-int sphmi_dd_set_slab(sphmi_handle* h, int axis, int64_t col_lo, int64_t col_hi, int has_lower_neighbour, int has_upper_neighbour) {
-    SPHMI_GUARD(h, h->e->dd_set_slab(axis, col_lo, col_hi, has_lower_neighbour, has_upper_neighbour));
-}
-int sphmi_dd_download_owned(sphmi_handle* h, void* position, void* velocity, void* density, int64_t* id, int64_t* n_out) {
-    SPHMI_GUARD(h, h->e->dd_download_owned(position, velocity, density, id, n_out));
-}
-int sphmi_dd_progress(sphmi_handle* h, sphmi_progress* out) {
-    if (!out) return SPHMI_ERR_ARGUMENT;
-    SPHMI_GUARD(h, (out->iteration = h->e->iteration, out->steps_done = 0, out->n_rebuilds = h->e->n_rebuilds,
-                    out->index_counter = h->e->index_counter, out->total_time = h->e->total_time,
-                    out->last_dt = h->e->last_dt, out->delta_x = h->e->delta_x));
-}
-
 int sphmi_download_begin(sphmi_handle* h, void* position, void* velocity, void* acceleration, void* density,
                          void* pressure, int64_t* id, uint8_t* type, uint64_t* group_marker, void* ghost_points,
                          int64_t* cells) {
@@ -1513,6 +1416,7 @@ int sphmi_host_unregister(sphmi_handle* h, void* ptr) { SPHMI_GUARD(h, h->e->hos
 int sphmi_download_kernel_output(sphmi_handle* h, void* kernel, void* kernel_gradient) {
     SPHMI_GUARD(h, h->e->download_kernel_output(kernel, kernel_gradient));
 }
+int sphmi_download_permutation(sphmi_handle* h, int64_t* prev_row) { SPHMI_GUARD(h, h->e->download_permutation(prev_row)); }
 int sphmi_set_motion(sphmi_handle* h, uint64_t group_marker, double velocity, double start_time, double duration,
                      const double* direction) {
     SPHMI_GUARD(h, h->e->set_motion(group_marker, velocity, start_time, duration, direction));

@@ -21,10 +21,11 @@
 // share a GPU — RCCL refuses that — run the rank-mode driver unchanged; a bring-up / test transport, nothing overlaps).
 #pragma once
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
+#include <functional>
 #include <memory>
 #include <numeric>
+#include <unordered_map>
 
 #include "sphmi_shm.h"
 
@@ -323,25 +324,52 @@ inline void plan_slabs(const sphmi_config& cfg, const void* position, const void
 // ------------------------------------------------------------------------------------------------------------------
 // RCCL, bound at run time (librccl.so.1: the copy already in the process — torch ships one — or /opt/rocm/lib's)
 // ------------------------------------------------------------------------------------------------------------------
+// The handful of NCCL / RCCL declarations the driver binds (the NCCL 2.x C ABI; values as in <rccl/rccl.h>).  Declared here
+// so that libsphmi.so builds on a ROCm install without the RCCL development headers: RCCL is needed at RUN time only, and
+// only by handles that spread over several devices.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
 struct Rccl {
     void* so = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr;      // optional (newer RCCL): the text behind a bare "invalid usage"
+    // Bound once per process; a failed attempt leaves nothing behind (the table is published only when every symbol resolved),
+    // so the next call tries again and fails with the same clean error instead of handing out null function pointers.
     static Rccl& get() {
-        static Rccl r;
-        if (r.so) return r;
+        static Rccl ready;
+        if (ready.so) return ready;
+        Rccl r;
+        std::string tried;
         const char* names[] = {getenv("SPHMI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { if (n && *n && (r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
-        if (!r.so) throw EngineError(SPHMI_ERR_DEVICE, std::string("RCCL not found (librccl.so.1): ") + (dlerror() ? dlerror() : ""));
-        auto sym = [&](const char* s) { void* p = dlsym(r.so, s); if (!p) throw EngineError(SPHMI_ERR_DEVICE, std::string("RCCL symbol missing: ") + s); return p; };
+        // SPHMI_RCCL_LIB is an override, not one more candidate: a wrong path must fail, not fall through to another copy
+        const int n_names = (names[0] && *names[0]) ? 1 : 4;
+        for (int k = 0; k < n_names && !r.so; ++k) {
+            const char* n = names[k];
+            if (!n || !*n) continue;
+            r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.so) { const char* e = dlerror(); tried += std::string(tried.empty() ? "" : "; ") + (e ? e : n); }      // dlerror() clears itself: read ONCE
+        }
+        if (!r.so) throw EngineError(SPHMI_ERR_DEVICE, "RCCL not found (needed by multi-device handles): " + tried);
+        auto sym = [&](const char* s, bool required = true) {
+            void* p = dlsym(r.so, s);
+            if (!p && required) throw EngineError(SPHMI_ERR_DEVICE, std::string("RCCL symbol missing: ") + s);
+            return p;
+        };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
@@ -352,14 +380,30 @@ struct Rccl {
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-        return r;
+        r.GetLastError = (decltype(r.GetLastError))sym("ncclGetLastError", false);
+        ready = r;
+        return ready;
     }
 };
+// What the failing call was doing: which slab, which peer, which phase — RCCL's own text is often a bare "invalid usage".
+struct RcclCtx { int rank = -1, peer = -1; const char* what = ""; ncclComm_t comm = nullptr; };
+static thread_local RcclCtx g_rccl_ctx;
+inline std::string rccl_fail(const char* expr, ncclResult_t r_) {
+    Rccl& N = Rccl::get();
+    std::string m = std::string(expr) + ": " + N.GetErrorString(r_);
+    if (N.GetLastError && g_rccl_ctx.comm) { const char* d = N.GetLastError(g_rccl_ctx.comm); if (d && *d) m += std::string(" — ") + d; }
+    char buf[160];
+    snprintf(buf, sizeof buf, " [%s; slab %d%s", g_rccl_ctx.what, g_rccl_ctx.rank, g_rccl_ctx.peer >= 0 ? "" : "]");
+    m += buf;
+    if (g_rccl_ctx.peer >= 0) { snprintf(buf, sizeof buf, ", peer slab %d]", g_rccl_ctx.peer); m += buf; }
+    return m;
+}
 #define NC(expr)                                                                                                      \
     do {                                                                                                              \
         ncclResult_t r_ = (expr);                                                                                     \
-        if (r_ != ncclSuccess) throw EngineError(SPHMI_ERR_DEVICE, std::string(#expr) + ": " + Rccl::get().GetErrorString(r_)); \
+        if (r_ != ncclSuccess) throw EngineError(SPHMI_ERR_DEVICE, rccl_fail(#expr, r_));                              \
     } while (0)
+#define NCX(what_, rank_, peer_, comm_, expr) do { g_rccl_ctx = RcclCtx{rank_, peer_, what_, comm_}; NC(expr); } while (0)
 
 // a device buffer that only grows (rebuild-time lists and message buffers)
 struct DevBuf {
@@ -417,7 +461,12 @@ struct MultiEngine final : EngineBase {
         DevBuf cx, flag, pos, idx[4], rec_s[2], rec_r[2], cost;
         int* mm_d = nullptr; int* mm_h = nullptr;
         int64_t* cnt_h = nullptr;
-        ncclComm_t comm = nullptr;
+        // Two communicators per slab: `comm` carries the point-to-point traffic (halos on the side stream, migration records
+        // and counts on the main stream), `comm_red` the per-step allreduce on the main stream.  One communicator used from two
+        // streams is legal only while every rank issues its calls in the same order and RCCL serialises them; with two, the
+        // 32-byte allreduce of step n+1 never queues behind the halo of step n inside the library.  ($SPHMI_RCCL_ONE_COMM=1:
+        // comm_red = comm, the round-2 arrangement.)
+        ncclComm_t comm = nullptr, comm_red = nullptr;
         bool has_left = false, has_right = false;
     };
     int world = 1;                     // slabs in total
@@ -472,17 +521,39 @@ struct MultiEngine final : EngineBase {
         }
         if (use_rccl) {
             Rccl& N = Rccl::get();
+            const char* oc = getenv("SPHMI_RCCL_ONE_COMM");
+            const bool one_comm = oc && atoi(oc) != 0;
             if (rank_mode) {
                 if (!unique_id) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_create_rank: null unique id");
                 ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
                 HC(hipSetDevice(R[0].device));
-                NC(N.CommInitRank(&R[0].comm, world, id, my_rank));
+                NCX("ncclCommInitRank (point-to-point communicator)", my_rank, -1, nullptr, N.CommInitRank(&R[0].comm, world, id, my_rank));
+                R[0].comm_red = R[0].comm;
+                if (world > 1 && !one_comm) {
+                    // the id of the second communicator: made on rank 0, summed over the first one (the others add zeros)
+                    ncclUniqueId id2; memset(&id2, 0, sizeof id2);
+                    if (my_rank == 0) NCX("ncclGetUniqueId (allreduce communicator)", my_rank, -1, nullptr, N.GetUniqueId(&id2));
+                    void* d = nullptr;
+                    HC(hipMalloc(&d, sizeof id2));
+                    try {
+                        HC(hipMemcpy(d, &id2, sizeof id2, hipMemcpyHostToDevice));
+                        NCX("ncclAllReduce (handing the second communicator's id round)", my_rank, -1, R[0].comm, N.AllReduce(d, d, sizeof id2, ncclUint8, ncclSum, R[0].comm, nullptr));
+                        HC(hipStreamSynchronize(nullptr));
+                        HC(hipMemcpy(&id2, d, sizeof id2, hipMemcpyDeviceToHost));
+                    } catch (...) { (void)hipFree(d); throw; }
+                    (void)hipFree(d);
+                    NCX("ncclCommInitRank (allreduce communicator)", my_rank, -1, nullptr, N.CommInitRank(&R[0].comm_red, world, id2, my_rank));
+                }
             } else {
                 std::vector<ncclComm_t> comms(world);
                 std::vector<int> devs(world);
                 for (int r = 0; r < world; ++r) devs[r] = R[r].device;
-                NC(N.CommInitAll(comms.data(), world, devs.data()));
-                for (int r = 0; r < world; ++r) R[r].comm = comms[r];
+                NCX("ncclCommInitAll (point-to-point communicators)", 0, -1, nullptr, N.CommInitAll(comms.data(), world, devs.data()));
+                for (int r = 0; r < world; ++r) R[r].comm = R[r].comm_red = comms[r];
+                if (!one_comm) {
+                    NCX("ncclCommInitAll (allreduce communicators)", 0, -1, nullptr, N.CommInitAll(comms.data(), world, devs.data()));
+                    for (int r = 0; r < world; ++r) R[r].comm_red = comms[r];
+                }
             }
         }
         if (!use_rccl && !rank_mode) {
@@ -511,6 +582,7 @@ struct MultiEngine final : EngineBase {
             (void)hipSetDevice(r.device);
             if (r.e) (void)hipStreamSynchronize(r.e->stream);
             if (r.side) { (void)hipStreamSynchronize(r.side); }
+            if (r.comm_red && r.comm_red != r.comm) { try { Rccl::get().CommDestroy(r.comm_red); } catch (...) {} }
             if (r.comm) { try { Rccl::get().CommDestroy(r.comm); } catch (...) {} }
             for (auto& h : r.halo) for (DevBuf* b : {&h.send_l, &h.send_r, &h.slot_l, &h.slot_r, &h.sb_l, &h.sb_r, &h.rb_l, &h.rb_r}) b->release();
             stage_s.release(); stage_r.release();
@@ -543,7 +615,7 @@ struct MultiEngine final : EngineBase {
         HC(hipSetDevice(r.device));
         void* d = r.cost.need((size_t)n * 8);
         HC(hipMemcpyAsync(d, v.data(), (size_t)n * 8, hipMemcpyHostToDevice, r.main));
-        NC(Rccl::get().AllReduce(d, d, (size_t)n, ncclInt64, op == OP_SUM ? ncclSum : ncclMax, r.comm, r.main));
+        NCX("ncclAllReduce (rebuild-time host scalars)", r.rank, -1, r.comm_red, Rccl::get().AllReduce(d, d, (size_t)n, ncclInt64, op == OP_SUM ? ncclSum : ncclMax, r.comm_red, r.main));
         HC(hipMemcpyAsync(v.data(), d, (size_t)n * 8, hipMemcpyDeviceToHost, r.main));
         HC(hipStreamSynchronize(r.main));
     }
@@ -572,10 +644,10 @@ struct MultiEngine final : EngineBase {
         r.cnt_h[0] = to_l[0]; r.cnt_h[1] = to_r[0]; r.cnt_h[2] = 0; r.cnt_h[3] = 0;
         HC(hipMemcpyAsync(d, r.cnt_h, 4 * 8, hipMemcpyHostToDevice, r.main));
         Rccl& N = Rccl::get();
-        NC(N.GroupStart());
-        if (r.has_left) { NC(N.Send(d + 0, 1, ncclInt64, r.rank - 1, r.comm, r.main)); NC(N.Recv(d + 2, 1, ncclInt64, r.rank - 1, r.comm, r.main)); }
-        if (r.has_right) { NC(N.Send(d + 1, 1, ncclInt64, r.rank + 1, r.comm, r.main)); NC(N.Recv(d + 3, 1, ncclInt64, r.rank + 1, r.comm, r.main)); }
-        NC(N.GroupEnd());
+        NCX("ncclGroupStart (neighbour counts)", r.rank, -1, r.comm, N.GroupStart());
+        if (r.has_left) { NCX("ncclSend (neighbour counts)", r.rank, r.rank - 1, r.comm, N.Send(d + 0, 1, ncclInt64, r.rank - 1, r.comm, r.main)); NCX("ncclRecv (neighbour counts)", r.rank, r.rank - 1, r.comm, N.Recv(d + 2, 1, ncclInt64, r.rank - 1, r.comm, r.main)); }
+        if (r.has_right) { NCX("ncclSend (neighbour counts)", r.rank, r.rank + 1, r.comm, N.Send(d + 1, 1, ncclInt64, r.rank + 1, r.comm, r.main)); NCX("ncclRecv (neighbour counts)", r.rank, r.rank + 1, r.comm, N.Recv(d + 3, 1, ncclInt64, r.rank + 1, r.comm, r.main)); }
+        NCX("ncclGroupEnd (neighbour counts)", r.rank, -1, r.comm, N.GroupEnd());
         HC(hipMemcpyAsync(r.cnt_h, d, 4 * 8, hipMemcpyDeviceToHost, r.main));
         HC(hipStreamSynchronize(r.main));
         from_l[0] = r.cnt_h[2]; from_r[0] = r.cnt_h[3];
@@ -611,12 +683,13 @@ struct MultiEngine final : EngineBase {
         }
         if (use_rccl) {
             Rccl& N = Rccl::get();
-            NC(N.GroupStart());
+            const char* what = side ? "halo / records, side stream" : "halo / records, main stream";
+            NCX(what, R[0].rank, -1, R[0].comm, N.GroupStart());
             for (const Msg& m : msgs) {
-                if (Rank* s = local(m.src)) { HC(hipSetDevice(s->device)); NC(N.Send(m.sbuf, m.bytes, ncclUint8, m.dst, s->comm, side ? s->side : s->main)); }
-                if (Rank* d = local(m.dst)) { HC(hipSetDevice(d->device)); NC(N.Recv(m.rbuf, m.bytes, ncclUint8, m.src, d->comm, side ? d->side : d->main)); }
+                if (Rank* s = local(m.src)) { HC(hipSetDevice(s->device)); NCX(what, s->rank, m.dst, s->comm, N.Send(m.sbuf, m.bytes, ncclUint8, m.dst, s->comm, side ? s->side : s->main)); }
+                if (Rank* d = local(m.dst)) { HC(hipSetDevice(d->device)); NCX(what, d->rank, m.src, d->comm, N.Recv(m.rbuf, m.bytes, ncclUint8, m.src, d->comm, side ? d->side : d->main)); }
             }
-            NC(N.GroupEnd());
+            NCX(what, R[0].rank, -1, R[0].comm, N.GroupEnd());
             return;
         }
         for (const Msg& m : msgs) {
@@ -646,7 +719,23 @@ struct MultiEngine final : EngineBase {
         plan_slabs(cfg, position, ghost_points, N, world, cfg.slab_axis - 1, given_plan.world() == world ? &given_plan : nullptr, 1.6, S);
         axis = S.axis; halo_width = S.halo_width; plan = S.plan;
         const size_t hb = (size_t)cfg.host_float_bytes;
-        for (auto& r : R) {
+        // the whole set is checked, whichever slabs are local (Engine::upload's checks see the local slabs only)
+        for (int64_t i = 0; i < N; ++i) {
+            if (ty[i] < 1 || ty[i] > 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: ParticleType must be 1, 2 or 3");
+            const double rho = hb == 8 ? ((const double*)density)[i] : (double)((const float*)density)[i];
+            if (!(rho > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
+        }
+        // ONE pass over the owner column: the index lists of the LOCAL slabs (counting sort by owner; a rank-mode process
+        // keeps one list — the other slabs' particles are never copied)
+        std::vector<int> local_of(world, -1);
+        for (size_t q = 0; q < R.size(); ++q) local_of[R[q].rank] = (int)q;
+        std::vector<size_t> n_of(R.size(), 0);
+        for (int64_t i = 0; i < N; ++i) { const int q = local_of[S.owner[(size_t)i]]; if (q >= 0) n_of[q] += 1; }
+        std::vector<std::vector<int64_t>> mine_of(R.size());
+        for (size_t q = 0; q < R.size(); ++q) mine_of[q].reserve(n_of[q]);
+        for (int64_t i = 0; i < N; ++i) { const int q = local_of[S.owner[(size_t)i]]; if (q >= 0) mine_of[q].push_back(i); }
+        for (size_t q_ = 0; q_ < R.size(); ++q_) {
+            Rank& r = R[q_];
             HC(hipSetDevice(r.device));
             sphmi_config c = cfg;
             c.n_particles = S.capacity[r.rank]; c.device = r.device; c.n_devices = 0;
@@ -656,8 +745,7 @@ struct MultiEngine final : EngineBase {
             r.e->dd_set_slab(axis, std::max(plan.lo[r.rank], -SlabPlan::INF), std::min(plan.hi[r.rank], SlabPlan::INF), r.has_left, r.has_right);
             for (int m = 0; m < motions_n; ++m) r.e->set_motion(mot_group[m], mot_vel[m], mot_start[m], mot_dur[m], mot_dir[m]);
             r.e->iteration = iteration; r.e->total_time = total_time;
-            std::vector<int64_t> mine;
-            for (int64_t i = 0; i < N; ++i) if (S.owner[(size_t)i] == r.rank) mine.push_back(i);
+            const std::vector<int64_t>& mine = mine_of[q_];
             const size_t n = mine.size();
             if (n == 0) throw EngineError(SPHMI_ERR_ARGUMENT, "a slab owns no particle: too many devices for this case");
             auto take = [&](const void* src, size_t elem) {
@@ -672,6 +760,7 @@ struct MultiEngine final : EngineBase {
                            ghost_points ? ph.data() : nullptr, mine.data());
         }
         uploaded = true; have_halo = false; dx_rate = 0.0;
+        if (!rank_mode) perm_ids.assign(ids, ids + N);                   // row history for sphmi_download_permutation
     }
 
     SlabPlan given_plan;               // test hook (sphmi_multi_set_cuts): start from these cuts instead of the balanced ones
@@ -979,9 +1068,9 @@ struct MultiEngine final : EngineBase {
         }
         if (use_rccl) {
             Rccl& N = Rccl::get();
-            NC(N.GroupStart());
-            for (auto& r : R) { HC(hipSetDevice(r.device)); NC(N.AllReduce(r.T2 + 4 * p, r.T2 + 4 * p, 4, ncclUint64, ncclMax, r.comm, r.main)); }
-            NC(N.GroupEnd());
+            NCX("per-step allreduce", R[0].rank, -1, R[0].comm_red, N.GroupStart());
+            for (auto& r : R) { HC(hipSetDevice(r.device)); NCX("per-step allreduce (4 × uint64, max)", r.rank, -1, r.comm_red, N.AllReduce(r.T2 + 4 * p, r.T2 + 4 * p, 4, ncclUint64, ncclMax, r.comm_red, r.main)); }
+            NCX("per-step allreduce", R[0].rank, -1, R[0].comm_red, N.GroupEnd());
         }
         if (shm) {
             Rank& r = R[0];
@@ -1073,7 +1162,7 @@ struct MultiEngine final : EngineBase {
         out->total_time = total_time; out->last_dt = last_dt; out->delta_x = delta_x;
     }
 
-    // ---- download: owned particles of every local slab, merged into the order of the UNSPLIT sort -------------------
+    // ---- output side: owned particles of every local slab, merged into the order of the UNSPLIT sort ------------------
     int64_t owned_count_impl() {
         int64_t n = 0;
         for (auto& r : R) {
@@ -1086,62 +1175,167 @@ struct MultiEngine final : EngineBase {
         }
         return n;
     }
-    void download(void* position, void* velocity, void* acceleration, void* density, void* pressure, int64_t* ids,
-                  uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
-        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
-        const size_t hb = (size_t)cfg.host_float_bytes, C = (size_t)out_comp;
-        struct Part { std::vector<char> pos, vel, acc, rho, prs, gho; std::vector<int64_t> id, cel; std::vector<uint8_t> ty; std::vector<uint64_t> grp, tag; size_t n; };
-        std::vector<Part> parts(R.size());
-        for (size_t q = 0; q < R.size(); ++q) {
-            Rank& r = R[q]; Part& P = parts[q];
-            HC(hipSetDevice(r.device));
-            Engine<T>& e = *r.e;
-            const size_t n = (size_t)e.N; P.n = n;
-            e.set_output_components(out_comp);
-            if (position) P.pos.resize(n * C * hb); if (velocity) P.vel.resize(n * C * hb); if (acceleration) P.acc.resize(n * C * hb);
-            if (density) P.rho.resize(n * hb); if (pressure) P.prs.resize(n * hb); if (ghost_points) P.gho.resize(n * C * hb);
-            if (ids) P.id.resize(n); if (cells) P.cel.resize(n * (size_t)D); if (groups) P.grp.resize(n);
-            P.ty.resize(n); P.tag.resize(n);
-            e.download(position ? P.pos.data() : nullptr, velocity ? P.vel.data() : nullptr, acceleration ? P.acc.data() : nullptr,
-                       density ? P.rho.data() : nullptr, pressure ? P.prs.data() : nullptr, ids ? P.id.data() : nullptr, P.ty.data(),
-                       groups ? P.grp.data() : nullptr, ghost_points ? P.gho.data() : nullptr, cells ? P.cel.data() : nullptr);
-            HC(hipMemcpy(P.tag.data(), e.otag[e.cur], n * 8, hipMemcpyDeviceToHost));
-        }
-        // k-way merge by order tag = (cell z, y, x, rank in cell) of the last sort: the order one engine would hold
-        std::vector<size_t> at(R.size(), 0);
-        auto skip = [&](size_t q) { Part& P = parts[q]; while (at[q] < P.n && (P.ty[at[q]] == 0 || (P.ty[at[q]] & kGhostMask))) ++at[q]; };
-        for (size_t q = 0; q < R.size(); ++q) skip(q);
+    // Merged row o = row i of local slab q, for the rows the slabs OWN, in the order ONE engine would hold: a k-way merge by
+    // order tag = (cell z, y, x, rank in cell) of the last sort.  ty / tag: the slabs' type bytes and tags (n[q] entries).
+    template <class F>
+    size_t merged_rows(const std::vector<const uint8_t*>& ty, const std::vector<const unsigned long long*>& tag,
+                       const std::vector<size_t>& n, F&& put) {
+        const size_t L = R.size();
+        std::vector<size_t> at(L, 0);
+        auto skip = [&](size_t q) { while (at[q] < n[q] && (ty[q][at[q]] == 0 || (ty[q][at[q]] & kGhostMask))) ++at[q]; };
+        for (size_t q = 0; q < L; ++q) skip(q);
         size_t o = 0;
         const size_t cap = (size_t)cfg.n_particles;
         for (;;) {
             int best = -1;
-            for (size_t q = 0; q < R.size(); ++q) if (at[q] < parts[q].n && (best < 0 || parts[q].tag[at[q]] < parts[best].tag[at[best]])) best = (int)q;
+            for (size_t q = 0; q < L; ++q) if (at[q] < n[q] && (best < 0 || tag[q][at[q]] < tag[(size_t)best][at[(size_t)best]])) best = (int)q;
             if (best < 0) break;
             if (o >= cap) throw EngineError(SPHMI_ERR_STATE, "sphmi_download: more owned particles than the handle was created for");
-            Part& P = parts[best]; const size_t i = at[best];
-            auto put = [&](void* dst, std::vector<char>& src, size_t elem) { if (dst) memcpy((char*)dst + o * elem, &src[i * elem], elem); };
-            put(position, P.pos, C * hb); put(velocity, P.vel, C * hb); put(acceleration, P.acc, C * hb);
-            put(density, P.rho, hb); put(pressure, P.prs, hb); put(ghost_points, P.gho, C * hb);
-            if (ids) ids[o] = P.id[i];
-            if (ty) ty[o] = P.ty[i] & kTypeMask;
-            if (groups) groups[o] = P.grp[i];
-            if (cells) for (int d = 0; d < D; ++d) cells[o * D + d] = P.cel[i * D + d];
-            ++o; ++at[best]; skip(best);
+            put(o, (size_t)best, at[(size_t)best]);
+            ++o; ++at[(size_t)best]; skip((size_t)best);
         }
-        n_downloaded = (int64_t)o;
+        return o;
+    }
+    // Asynchronous like the one-device handle's: `begin` snapshots every slab on ITS device in stream order
+    // and starts the device → host copies on the slabs' copy streams, into page-locked staging the handle owns; the caller
+    // may advance at once; `end` waits for the copies and merges the slabs into the caller's arrays.  Registering the
+    // caller's arrays (sphmi_host_register) gains nothing here — they only ever see host copies — and is accepted as a no-op.
+    struct Stage { HostBuf pos, vel, acc, rho, prs, gho, id, cel, grp, ty, tag; size_t n = 0; };
+    std::vector<Stage> stage;
+    struct PendingDownload { void *pos, *vel, *acc, *rho, *prs, *gho; int64_t *ids, *cells; uint8_t* ty; uint64_t* grp; bool on = false; } pend{};
+    void download_begin(void* position, void* velocity, void* acceleration, void* density, void* pressure, int64_t* ids,
+                        uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download before sphmi_upload");
+        if (pend.on) download_end();
+        const size_t hb = (size_t)cfg.host_float_bytes, C = (size_t)out_comp;
+        stage.resize(R.size());
+        for (size_t q = 0; q < R.size(); ++q) {
+            Rank& r = R[q]; Stage& P = stage[q];
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            const size_t n = (size_t)e.N; P.n = n;
+            e.set_output_components(out_comp);
+            auto buf = [&](HostBuf& b, bool wanted, size_t bytes) -> void* { return wanted ? (void*)b.need(std::max<size_t>(bytes, 1)) : nullptr; };
+            e.dl_tags_host = (unsigned long long*)P.tag.need(std::max<size_t>(n * 8, 1));
+            try {
+                e.download_begin(buf(P.pos, position, n * C * hb), buf(P.vel, velocity, n * C * hb), buf(P.acc, acceleration, n * C * hb),
+                                 buf(P.rho, density, n * hb), buf(P.prs, pressure, n * hb), (int64_t*)buf(P.id, ids, n * 8),
+                                 (uint8_t*)buf(P.ty, true, n), (uint64_t*)buf(P.grp, groups, n * 8), buf(P.gho, ghost_points, n * C * hb),
+                                 (int64_t*)buf(P.cel, cells, n * (size_t)D * 8));
+            } catch (...) { e.dl_tags_host = nullptr; throw; }
+            e.dl_tags_host = nullptr;
+        }
+        pend = PendingDownload{position, velocity, acceleration, density, pressure, ghost_points, ids, cells, ty, groups, true};
+    }
+    void download_end() override {
+        if (!pend.on) return;
+        pend.on = false;
+        for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->download_end(); }
+        const size_t hb = (size_t)cfg.host_float_bytes, C = (size_t)out_comp, L = R.size();
+        std::vector<const uint8_t*> tys(L); std::vector<const unsigned long long*> tags(L); std::vector<size_t> ns(L);
+        for (size_t q = 0; q < L; ++q) { tys[q] = (const uint8_t*)stage[q].ty.p; tags[q] = (const unsigned long long*)stage[q].tag.p; ns[q] = stage[q].n; }
+        const PendingDownload d = pend;
+        n_downloaded = (int64_t)merged_rows(tys, tags, ns, [&](size_t o, size_t q, size_t i) {
+            Stage& P = stage[q];
+            auto put = [&](void* dst, HostBuf& src, size_t elem) { if (dst) memcpy((char*)dst + o * elem, src.p + i * elem, elem); };
+            put(d.pos, P.pos, C * hb); put(d.vel, P.vel, C * hb); put(d.acc, P.acc, C * hb);
+            put(d.rho, P.rho, hb); put(d.prs, P.prs, hb); put(d.gho, P.gho, C * hb);
+            put(d.ids, P.id, 8); put(d.grp, P.grp, 8); put(d.cells, P.cel, (size_t)D * 8);
+            if (d.ty) d.ty[o] = (uint8_t)(((const uint8_t*)P.ty.p)[i] & kTypeMask);
+        });
+    }
+    void download(void* position, void* velocity, void* acceleration, void* density, void* pressure, int64_t* ids,
+                  uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
+        download_begin(position, velocity, acceleration, density, pressure, ids, ty, groups, ghost_points, cells);
+        download_end();
     }
     int64_t n_downloaded = 0;
     int out_comp = 0;
-    void download_begin(void* a, void* b, void* c, void* d, void* e, int64_t* f, uint8_t* g, uint64_t* h, void* i, int64_t* j) override { download(a, b, c, d, e, f, g, h, i, j); }
-    void download_end() override {}
     void set_output_components(int c) override {
         if (c != D && c != 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_set_output_components: dims or 3");
         out_comp = c;
     }
-    void host_register(void*, size_t) override {}
+    void host_register(void* p, size_t bytes) override { if (!p && bytes) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_host_register: null pointer"); }
     void host_unregister(void*) override {}
-    void forces_once(int, void*, void*) override { throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once: single-device handles only (parity hook)"); }
-    void download_kernel_output(void*, void*) override { throw EngineError(SPHMI_ERR_STATE, "sphmi_download_kernel_output: single-device handles only"); }
+    // one per-particle device array of every local slab (elem bytes per row), merged like a download → out
+    template <class Src>
+    void merged_array(Src&& src, size_t elem, const std::function<void(size_t, const char*)>& put) {
+        const size_t L = R.size();
+        std::vector<std::vector<char>> data(L); std::vector<std::vector<uint8_t>> ty(L); std::vector<std::vector<unsigned long long>> tag(L);
+        std::vector<const uint8_t*> tys(L); std::vector<const unsigned long long*> tags(L); std::vector<size_t> ns(L);
+        for (size_t q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            HC(hipStreamSynchronize(r.main));
+            const size_t n = (size_t)e.N; ns[q] = n;
+            data[q].resize(std::max<size_t>(n * elem, 1)); ty[q].resize(std::max<size_t>(n, 1)); tag[q].resize(std::max<size_t>(n, 1));
+            if (n) {
+                HC(hipMemcpy(data[q].data(), src(e), n * elem, hipMemcpyDeviceToHost));
+                HC(hipMemcpy(ty[q].data(), e.type[e.cur], n, hipMemcpyDeviceToHost));
+                HC(hipMemcpy(tag[q].data(), e.otag[e.cur], n * 8, hipMemcpyDeviceToHost));
+            }
+            tys[q] = ty[q].data(); tags[q] = tag[q].data();
+        }
+        n_downloaded = (int64_t)merged_rows(tys, tags, ns, [&](size_t o, size_t q, size_t i) { put(o, data[q].data() + i * elem); });
+    }
+    void put_packets(void* vec_out, void* scalar_out) {      // helper of the two hooks below: rows of V4 { vector, scalar }
+        const bool h8 = cfg.host_float_bytes == 8;
+        const int Dd = D;
+        return merged_array([&](Engine<T>& e) -> const void* { return packet_src(e); }, sizeof(V4), [=](size_t o, const char* p) {
+            V4 v; memcpy(&v, p, sizeof v);
+            const T c[3] = {v.x, v.y, v.z};
+            if (vec_out) for (int d = 0; d < Dd; ++d) { if (h8) ((double*)vec_out)[o * Dd + d] = (double)c[d]; else ((float*)vec_out)[o * Dd + d] = (float)c[d]; }
+            if (scalar_out) { if (h8) ((double*)scalar_out)[o] = (double)v.w; else ((float*)scalar_out)[o] = (float)v.w; }
+        });
+    }
+    std::function<const void*(Engine<T>&)> packet_src;
+    // Parity hook (sphmi_forces_once) on slabs: the collective rebuild sorts every slab, migrates and refreshes the ghost
+    // layers from the owners' current state; Pressure! → [mDBC on everything held] → one forces-only pass over the interior
+    // AND the slab-edge tiles; rows come back in the order one engine would hold (rank mode: this process's slab).
+    void forces_once(int apply_mdbc, void* drhodt, void* acceleration) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_forces_once before sphmi_upload");
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
+        rebuild_collective();
+        for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->forces_local(apply_mdbc, true); }
+        for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->sync_and_collect(); }
+        packet_src = [](Engine<T>& e) -> const void* { return e.rec[e.iB]; };
+        put_packets(acceleration, drhodt);
+    }
+    // StoreKernelOutput (src/SPHCellList.jl:106-116): Σ∇W, ΣW of the last corrector pass, merged like a download
+    void download_kernel_output(void* kernel, void* kernel_gradient) override {
+        if (cfg.kernel_output != SPHMI_KOUT_STORE) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_kernel_output: the handle was not created with kernel_output = STORE");
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_kernel_output before sphmi_upload");
+        packet_src = [](Engine<T>& e) -> const void* { return e.kout_d; };
+        put_packets(kernel_gradient, kernel);
+    }
+    // sphmi_download_permutation: the slabs exchange particles, so the row history lives on the host here — the ID column of
+    // the previous call (the upload order at first) against the merged ID column of now; one hash-free table look-up per row
+    // when the IDs are compact (every shipped layout: 1 … N), a hash map otherwise.
+    std::vector<int64_t> perm_ids;
+    void download_permutation(int64_t* prev_row) override {
+        if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation before sphmi_upload");
+        if (!prev_row) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_download_permutation: null array");
+        if (rank_mode) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: one-process handles only (a rank-mode process holds one slab of the rows)");
+        const size_t N = (size_t)cfg.n_particles;
+        std::vector<int64_t> now(N);
+        download(nullptr, nullptr, nullptr, nullptr, nullptr, now.data(), nullptr, nullptr, nullptr, nullptr);
+        if ((size_t)n_downloaded != N || perm_ids.size() != N) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: the handle does not hold the uploaded particle set");
+        int64_t lo = perm_ids[0], hi = perm_ids[0];
+        for (auto v : perm_ids) { lo = std::min(lo, v); hi = std::max(hi, v); }
+        if ((uint64_t)(hi - lo) < 4 * (uint64_t)N + 1024) {
+            std::vector<int64_t> row((size_t)(hi - lo + 1), -1);
+            for (size_t i = 0; i < N; ++i) row[(size_t)(perm_ids[i] - lo)] = (int64_t)i;
+            for (size_t i = 0; i < N; ++i) {
+                const int64_t v = now[i];
+                prev_row[i] = (v >= lo && v <= hi) ? row[(size_t)(v - lo)] : -1;
+            }
+        } else {
+            std::unordered_map<int64_t, int64_t> row; row.reserve(N * 2);
+            for (size_t i = 0; i < N; ++i) row[perm_ids[i]] = (int64_t)i;
+            for (size_t i = 0; i < N; ++i) { auto it = row.find(now[i]); prev_row[i] = it == row.end() ? -1 : it->second; }
+        }
+        perm_ids.swap(now);
+    }
     void unique_cells(int64_t* out, int64_t cap, int64_t* n_out) override {
         // occupied cells of the owned particles in sort order, from the merged Cells column
         const size_t N = (size_t)cfg.n_particles;
@@ -1157,8 +1351,15 @@ struct MultiEngine final : EngineBase {
         }
         if (n_out) *n_out = n;
     }
+    // the slabs run side by side: a phase costs what its slowest slab spent in it (calls: slab 0's — the same on every slab)
     void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
         R[0].e->timers(cap, names, secs, calls, n);
+        if (!secs) return;
+        for (size_t q = 1; q < R.size(); ++q) {
+            double sq[PH_COUNT] = {}; int32_t nq = 0;
+            R[q].e->timers(PH_COUNT, nullptr, sq, nullptr, &nq);
+            for (int i = 0; i < PH_COUNT && i < cap; ++i) secs[i] = std::max(secs[i], sq[i]);
+        }
     }
     void force_stats(int reset, double* avg_ms, int64_t* launches) override {
         double ms = 0; int64_t ln = 0;
@@ -1166,7 +1367,21 @@ struct MultiEngine final : EngineBase {
         if (avg_ms) *avg_ms = ln ? ms / (double)ln : 0.0;
         if (launches) *launches = ln;
     }
-    void device_ptrs(void** p0, void** p1, int64_t* n) override { R[0].e->device_ptrs(p0, p1, n); }
+    void device_ptrs(void** p0, void** p1, int64_t* n) override { R[0].e->device_ptrs(p0, p1, n); }      // (slab 0 of this handle)
+    // test hook (sphmi_multi_column_cost): the work histogram the re-cut balances, summed over the local slabs
+    void column_cost(int64_t col0, int32_t ncols, uint64_t* out) {
+        for (int c = 0; c < ncols; ++c) out[c] = 0;
+        std::vector<unsigned long long> h((size_t)ncols);
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            unsigned long long* cd = (unsigned long long*)r.cost.need((size_t)ncols * 8);
+            HC(hipMemsetAsync(cd, 0, (size_t)ncols * 8, r.main));
+            r.e->dd_column_cost(col0, ncols, (uint64_t*)cd);
+            HC(hipMemcpyAsync(h.data(), cd, (size_t)ncols * 8, hipMemcpyDeviceToHost, r.main));
+            HC(hipStreamSynchronize(r.main));
+            for (int c = 0; c < ncols; ++c) out[c] += h[(size_t)c];
+        }
+    }
     void reset_count() override {}
     int64_t owned_count() override { return owned_count_impl(); }
     void multi_info(sphmi_multi_info* o) {

@@ -397,6 +397,7 @@ struct PermuteArgs {
     const unsigned long long* grp_in; unsigned long long* grp_out;
     const int* key_in; int* key_out;
     const unsigned long long* tag_in; unsigned long long* tag_out;     // order tags (domain decomposition only)
+    const int* prow_in; int* prow_out;                                 // row at the last sphmi_download_permutation (single-device handles)
     const int* perm;
     int N, has_ghost;
 };
@@ -415,6 +416,11 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     A.grp_out[p] = A.grp_in[i];
     A.key_out[p] = A.key_in[i];
     if (A.tag_in) A.tag_out[p] = A.tag_in[i];
+    if (A.prow_in) A.prow_out[p] = A.prow_in[i];
+}
+__global__ void __launch_bounds__(256) k_iota(int* out, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = i;
 }
 
 // Pressure! (src/SimulationEquations.jl:18-24) on a state set: pk1.w = EOS(|pk0.w|)

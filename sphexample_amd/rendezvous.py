@@ -1,0 +1,100 @@
+"""Launcher-side glue of a one-process-per-GPU run (`torchrun bench.py --gpus N`, sphmi_create_rank).
+
+torch.distributed is the RENDEZVOUS only — gloo over TCP: the 128-byte RCCL id travels from rank 0 to the others, the
+timed region is bracketed by barriers, the wall time is the max over ranks, and every rank learns whether ALL ranks got
+their slab engine.  Halos, migration and the per-step MAX-allreduce run inside libsphmi.so (csrc/sphmi_multi.h) on RCCL.
+The reference has no counterpart (one Julia process, src/SPHCellList.jl:883); this is what a multi-process host driver
+needs around the C ABI.  Works without a GPU (tests/test_distributed.py runs it with 2 and 3 CPU processes).
+"""
+from __future__ import annotations
+
+import os
+import socket
+from typing import Optional
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (single-node launches without a launcher-provided MASTER_PORT)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class Rendezvous:
+    def __init__(self, rank: int, world: int, master_addr: Optional[str] = None, master_port: Optional[int] = None):
+        import torch.distributed as dist
+        self.rank, self.world, self._dist = rank, world, dist
+        addr = master_addr or os.environ.get("MASTER_ADDR") or "127.0.0.1"
+        port = master_port or os.environ.get("MASTER_PORT")
+        if port is None:
+            if world > 1:
+                raise RuntimeError("MASTER_PORT is not set: launch with `python -m torch.distributed.run --master-addr 127.0.0.1 "
+                                   "--master-port P …` (every rank must name the same port)")
+            port = free_port()                       # a one-rank world: nobody else has to know the port
+        self._own = not dist.is_initialized()
+        if self._own:
+            dist.init_process_group("gloo", init_method=f"tcp://{addr}:{int(port)}", rank=rank, world_size=world)
+
+    def broadcast_bytes(self, payload: Optional[bytes], src: int = 0) -> bytes:
+        box = [payload if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def barrier(self) -> None:
+        self._dist.barrier()
+
+    def max(self, x: float) -> float:
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(self, ok: bool) -> bool:
+        """True on every rank iff every rank passed True."""
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def gather_strings(self, text: str):
+        """Every rank's string, on every rank (error texts of a failed set-up: the line names rank, peer and call)."""
+        out = [None] * self.world
+        self._dist.all_gather_object(out, text)
+        return out
+
+    def close(self) -> None:
+        if self._own and self._dist.is_initialized():
+            try:
+                self._dist.barrier()
+            finally:
+                self._dist.destroy_process_group()
+
+
+def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSPORT"):
+    """One slab engine per rank with the id handed round, COLLECTIVELY: every rank learns whether all ranks succeeded.
+    `make(unique_id)` builds this rank's engine (sphexample_amd.engine.make_engine(..., rank=, world=, unique_id=)).
+    Returns (engine | None, list of the ranks' error texts).  The id is RCCL's (sphmi_rccl_unique_id on rank 0) unless the
+    shared-memory transport is selected in the environment, where any 128 random bytes do."""
+    from .engine import rccl_unique_id
+    uid, err = None, ""
+    if rdv.rank == 0:
+        try:
+            uid = os.urandom(128) if os.environ.get(transport_env) == "shm" else rccl_unique_id()
+        except Exception as exc:                      # librccl missing or broken: every rank must learn it, not hang
+            err = f"rank 0: sphmi_rccl_unique_id: {exc}"
+    uid = rdv.broadcast_bytes(uid, src=0)
+    eng = None
+    if uid is not None:
+        try:
+            eng = make(uid)
+        except Exception as exc:
+            err = f"rank {rdv.rank}: {exc}"
+    texts = rdv.gather_strings(err)
+    if not rdv.all_ok(eng is not None):
+        if eng is not None:
+            eng.close()
+        return None, [t for t in texts if t]
+    return eng, []
+
+
+__all__ = ["Rendezvous", "create_rank_engine", "free_port"]

@@ -17,6 +17,20 @@ from .config import (SimulationConstants, SimulationMetaData, SPHDensityDiffusio
 from .engine import Engine
 from .preprocess import LoadMDBCNormals, SimParticles
 
+# Fields of the StructArray the engine does not carry (src/PreProcess.jl:114): the reference's sort! (src/SPHCellList.jl:142)
+# permutes them with everything else, so after a download they follow through the engine's own permutation
+# (sphmi_download_permutation) — one gather per field, no sort on the host.
+PASSIVE_FIELDS = ("ChunkID", "GravityFactor", "MotionLimiter", "BoundaryBool", "GhostNormals")
+
+
+def permute_passive_fields(particles: SimParticles, prev_row, kernel_output: bool = False) -> None:
+    """Row i of the downloaded arrays was row prev_row[i] at the previous call: bring the passive fields along.  Kernel /
+    KernelGradient are passive too unless the handle stores them (StoreKernelOutput: they are downloaded instead)."""
+    names = PASSIVE_FIELDS + (() if kernel_output else ("Kernel", "KernelGradient"))
+    for k in names:
+        a = getattr(particles, k)
+        a[...] = a[prev_row]
+
 
 def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConstants: SimulationConstants,
                   SimKernel: SPHKernelInstance, SimLogger=None, SimParticles: SimParticles,
@@ -44,6 +58,15 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
     SimMetaData.OutputIterationCounter = 1                                       # :849
     if on_output:
         on_output(SimMetaData, SimParticles)                                     # :850
+    kout = SimMetaData.KMode.__name__ == "StoreKernelOutput"
+
+    def finish_output():
+        """The fields the engine does not carry follow the sort; a StoreKernelOutput handle hands over Kernel / KernelGradient."""
+        if eng._has("download_permutation"):
+            permute_passive_fields(SimParticles, eng.download_permutation(), kernel_output=kout)
+        if kout:
+            SimParticles.Kernel[...], SimParticles.KernelGradient[...] = eng.kernel_output()
+
     pending = None       # async_output: metadata of the snapshot whose copies are in flight
     while True:                                                                  # :881
         prog = eng.advance(next_output_time(SimMetaData))                        # :883
@@ -61,6 +84,7 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
                 eng.download_end()
                 on_output(pending, SimParticles)
             eng.download_into_begin(SimParticles)
+            finish_output()                    # (host-side gathers on fields that are not in flight: they overlap the copies)
             pending = copy.copy(SimMetaData)
             if done:
                 eng.download_end()
@@ -69,9 +93,12 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
             continue
         if on_output:
             eng.download_into(SimParticles)
+            finish_output()
             on_output(SimMetaData, SimParticles)                                 # :891-894
         if done:
-            eng.download_into(SimParticles)
+            if not on_output:
+                eng.download_into(SimParticles)
+                finish_output()
             break
     eng.unpin()
     eng.close()

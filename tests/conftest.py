@@ -138,3 +138,24 @@ def perturbed(p, seed=0, vel_scale=0.3, rho_scale=2.0, pos_scale=0.0):
     if pos_scale:
         q.Position[fluid] += rng.uniform(-pos_scale, pos_scale, size=q.Position[fluid].shape)
     return q
+
+
+def flowing(p, seed=3, shear=1.0, base=0.4, noise=0.05, rho_scale=0.5):
+    """A moving, smooth state on top of a 3-D layout: the fluid streams along +x with a shear in z (base … base + shear
+    m/s) plus a little noise — fast enough that the Δx criterion (src/SPHCellList.jl:758-762) asks for a cell-list rebuild
+    every few dozen steps, which the lattice at rest does not within a test's horizon."""
+    rng = np.random.default_rng(seed)
+    q = p.copy()
+    fluid = q.Type == 1
+    z = q.Position[fluid, -1]
+    v = rng.uniform(-noise, noise, size=q.Velocity[fluid].shape)
+    v[:, 0] += base + shear * (z - z.min()) / max(z.max() - z.min(), 1e-300)
+    q.Velocity[fluid] = v
+    q.Density = q.Density + rng.uniform(0, rho_scale, size=q.Density.shape)
+    return q
+
+
+def load_dam_break_3d_c3_flowing():
+    """BASELINE config 3's lattice (dp = 0.00425, N = 1 057 738) in the `flowing` state (rank-mode workers build it themselves)."""
+    from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+    return flowing(dam_break_3d(0.00425)), setup_dam_break_3d(0.00425)

@@ -1,0 +1,244 @@
+"""Parity and decomposition AT THE SIZES THE METRIC IS QUOTED ON (BASELINE configs 3 and 4).
+
+* C3 (dp = 0.00425, N = 1 057 738), fp32 kernels against the fp64 oracle over 100 steps of a streaming state with
+  Δx-triggered cell-list rebuilds inside the window (src/SPHCellList.jl:742-802, rebuild criterion :758-762);
+* the DEVELOPED flow (the engine's own state at t ≈ 0.4 s: the front has hit the pillar, spray tiles spanning hundreds of
+  cells — the chunk-skip path of phase 1): re-uploaded into the oracle and into fresh handles, one force evaluation and
+  10 steps;
+* config 4's slab decomposition at its real size on the one GPU of the test box: 8 slabs in one handle at 7.7 M
+  particles, 2 and 4 slabs at C3, and the rank-mode driver with 4 PROCESSES at C3 (shared-memory transport), against the
+  one-device handle (ID-for-ID order) and the oracle.
+
+Tolerances: ρ and x < 1e-5 of the field maximum (north_star); x is also recorded in units of dp.  A force evaluation:
+2e-4 of the field maximum (fp32 kernels vs fp64 oracle).  Figures go to gpurun_out/parity_scale.json.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, flowing
+from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
+from sphexample_amd.preprocess import particles_from_arrays
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+TOL = 1e-5
+DP3, DP4 = 0.00425, 0.002125
+FIELDS = ("ID", "Density", "Position", "Velocity")
+
+
+def _by_id(st):
+    o = np.argsort(st["ID"], kind="stable")
+    return {k: v[o] for k, v in st.items()}
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _errors(e, o, dp):
+    return {"rho": _rel(e["Density"], o["Density"]), "x": _rel(e["Position"], o["Position"]),
+            "x_over_dp": float(np.abs(e["Position"] - o["Position"]).max() / dp),
+            "v": _rel(e["Velocity"], o["Velocity"])}
+
+
+def _record(name, fig):
+    path = os.path.join(ROOT, "gpurun_out", "parity_scale.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[name] = fig
+        json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[scale parity] {name}: {json.dumps(fig)}")
+
+
+def _threads():
+    from oracle.oracle import Oracle
+    return max(1, min(16, os.cpu_count() or 1, Oracle.max_threads()))
+
+
+def _same_loop(pa, pb, rel=1e-5):
+    assert (pa.iteration, pa.steps_done, pa.n_rebuilds, pa.index_counter) == (pb.iteration, pb.steps_done, pb.n_rebuilds, pb.index_counter)
+    assert pa.total_time == pytest.approx(pb.total_time, rel=rel)
+    assert pa.last_dt == pytest.approx(pb.last_dt, rel=rel)
+
+
+def _state_from_download(d):
+    p = particles_from_arrays(3, d["Position"], d["Density"], d["Type"], d["GroupMarker"], d["ID"], sort_by_id=False)
+    p.Velocity[:] = d["Velocity"]
+    p.Acceleration[:] = d["Acceleration"]
+    return p
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_c3_hundred_steps_with_rebuilds_fp32_vs_oracle():
+    """100 steps, ≥ 2 rebuilds asked for by the Δx criterion inside the window, fp32 engine vs fp64 oracle."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP3)
+    p = flowing(dam_break_3d(DP3))
+    t0 = time.perf_counter()
+    eng, orc = make_engine(p, s, device_float_bytes=4), make_oracle(p, s, threads=_threads())
+    fig = {"N": len(p), "dp": DP3, "checkpoints": {}}
+    done = 0
+    for upto in (25, 50, 100):
+        pe, po = eng.advance(1e9, max_steps=upto - done), orc.advance(1e9, max_steps=upto - done)
+        done = upto
+        assert pe.iteration == po.iteration == upto
+        assert (pe.n_rebuilds, pe.index_counter) == (po.n_rebuilds, po.index_counter)
+        e, o = _by_id(eng.download(FIELDS)), _by_id(orc.download(FIELDS))
+        np.testing.assert_array_equal(e["ID"], o["ID"])
+        r = _errors(e, o, DP3)
+        r.update(dt=abs(pe.last_dt - po.last_dt) / po.last_dt, t=abs(pe.total_time - po.total_time) / po.total_time,
+                 rebuilds=int(pe.n_rebuilds))
+        fig["checkpoints"][str(upto)] = r
+    fig["seconds"] = time.perf_counter() - t0
+    _record("C3_100_steps_flowing", fig)
+    assert pe.n_rebuilds >= 3, pe.n_rebuilds        # the one that opens the first advance + ≥ 2 from the Δx criterion
+    for r in fig["checkpoints"].values():
+        assert r["rho"] < TOL and r["x"] < TOL and r["dt"] < TOL and r["t"] < TOL, fig
+
+
+@pytest.fixture(scope="module")
+def developed_c3():
+    """The engine's own state of the 1.06 M dam break at t = 0.4 s (≈9 000 steps, ≈300 rebuilds; ≈10 s of GPU time)."""
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP3)
+    eng = make_engine(dam_break_3d(DP3), s, device_float_bytes=4)
+    pr = eng.advance(0.4)
+    assert pr.total_time > 0.4 and pr.n_rebuilds > 100
+    d = eng.download()
+    eng.close()
+    return _state_from_download(d), s, {"t": pr.total_time, "steps": int(pr.iteration), "rebuilds": int(pr.n_rebuilds)}
+
+
+def test_c3_developed_state_fp32_vs_oracle(developed_c3):
+    """Spray and splash-up: tiles whose 64 particles span many cells (phase 1 skips chunks no lane needs)."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    p, s, how = developed_c3
+    eng, orc = make_engine(p, s, device_float_bytes=4), make_oracle(p, s, threads=_threads())
+    d1, a1 = eng.forces_once()
+    d2, a2 = orc.forces_once()
+    ie = np.argsort(eng.download(("ID",))["ID"], kind="stable")
+    io = np.argsort(orc.download(("ID",))["ID"], kind="stable")
+    fig = dict(how, N=len(p), force_drho=_rel(d1[ie], d2[io]), force_acc=_rel(a1[ie], a2[io]),
+               span_cells=float((p.Position.max(0) - p.Position.min(0)).max() * s.SimKernel.H_inv))
+    pe, po = eng.advance(1e9, max_steps=10), orc.advance(1e9, max_steps=10)
+    assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter)
+    e, o = _by_id(eng.download(FIELDS)), _by_id(orc.download(FIELDS))
+    fig.update(_errors(e, o, DP3), dt=abs(pe.last_dt - po.last_dt) / po.last_dt)
+    _record("C3_developed_t0.4", fig)
+    assert fig["force_drho"] < 2e-4 and fig["force_acc"] < 2e-4, fig
+    assert fig["rho"] < TOL and fig["x"] < TOL and fig["dt"] < TOL, fig
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c3_developed_state_on_slabs(developed_c3, world):
+    """The same developed state on 2 / 4 / 8 slabs (one handle, the slabs sharing GPU 0) against the one-device handle:
+    40 steps with a collective rebuild inside, same order ID for ID."""
+    from sphexample_amd.engine import make_engine
+    p, s, how = developed_c3
+    ref, dd = make_engine(p, s, device_float_bytes=4), make_engine(p, s, device_float_bytes=4, devices=[0] * world)
+    pr, pd = ref.advance(1e9, max_steps=40), dd.advance(1e9, max_steps=40)
+    _same_loop(pd, pr)
+    assert pr.n_rebuilds >= 2
+    r, d = ref.download(FIELDS + ("Cells",)), dd.download(FIELDS + ("Cells",))
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    np.testing.assert_array_equal(d["Cells"], r["Cells"])
+    fig = dict(_errors(d, r, DP3), rebuilds=int(pr.n_rebuilds), recuts=int(dd.multi_info().n_recuts))
+    _record(f"C3_developed_{world}_slabs_vs_one_device", fig)
+    assert fig["rho"] < TOL and fig["x"] < TOL, fig
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c3_slabs_match_one_device(world):
+    """2 and 4 slabs at C3 from the streaming state, 70 steps (the streaming state asks for a rebuild every ≈33 steps:
+    collective rebuilds, migration across the cuts)."""
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP3)
+    p = flowing(dam_break_3d(DP3))
+    ref, dd = make_engine(p, s, device_float_bytes=4), make_engine(p, s, device_float_bytes=4, devices=[0] * world)
+    for k in range(2):
+        pr, pd = ref.advance(1e9, max_steps=35), dd.advance(1e9, max_steps=35)
+        _same_loop(pd, pr)
+    assert pr.n_rebuilds >= 3
+    r, d = ref.download(FIELDS + ("Cells",)), dd.download(FIELDS + ("Cells",))
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    np.testing.assert_array_equal(d["Cells"], r["Cells"])
+    np.testing.assert_array_equal(dd.unique_cells(), ref.unique_cells())
+    fig = dict(_errors(d, r, DP3), rebuilds=int(pr.n_rebuilds))
+    _record(f"C3_flowing_{world}_slabs_vs_one_device", fig)
+    assert fig["rho"] < TOL and fig["x"] < TOL, fig
+
+
+def test_c4_eight_slabs_vs_one_device_and_oracle():
+    """BASELINE config 4's decomposition at its size: 7.7 M particles on 8 slabs (sharing the one GPU here): 5 steps against
+    the fp64 oracle, then on to 40 steps against the one-device handle, with collective rebuilds inside the window."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP4)
+    p = flowing(dam_break_3d(DP4), shear=2.0, base=1.0)
+    assert 7.6e6 < len(p) < 7.8e6
+    t0 = time.perf_counter()
+    dd = make_engine(p, s, device_float_bytes=4, devices=[0] * 8)
+    info = dd.multi_info()
+    assert info.world == 8 and info.n_local == 8 and info.halo_width == 1
+    orc = make_oracle(p, s, threads=_threads())
+    pd, po = dd.advance(1e9, max_steps=5), orc.advance(1e9, max_steps=5)
+    assert (pd.iteration, pd.n_rebuilds, pd.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter)
+    d, o = _by_id(dd.download(FIELDS)), _by_id(orc.download(FIELDS))
+    np.testing.assert_array_equal(d["ID"], o["ID"])
+    fig = {"N": len(p), "dp": DP4, "vs_oracle_5_steps": dict(_errors(d, o, DP4), dt=abs(pd.last_dt - po.last_dt) / po.last_dt)}
+    orc.close()
+    del orc, d, o
+    ref = make_engine(p, s, device_float_bytes=4)
+    pr = ref.advance(1e9, max_steps=5)
+    _same_loop(pd, pr)
+    pr, pd = ref.advance(1e9, max_steps=35), dd.advance(1e9, max_steps=35)
+    _same_loop(pd, pr)
+    r, d = ref.download(FIELDS + ("Cells",)), dd.download(FIELDS + ("Cells",))
+    assert dd.owned_count() == len(p)
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    np.testing.assert_array_equal(d["Cells"], r["Cells"])
+    info = dd.multi_info()
+    fig["vs_one_device_40_steps"] = dict(_errors(d, r, DP4), rebuilds=int(pr.n_rebuilds), recuts=int(info.n_recuts),
+                                         slab_particles=[int(x) for x in info.n_live[:8]])
+    fig["seconds"] = time.perf_counter() - t0
+    _record("C4_8_slabs", fig)
+    assert pr.n_rebuilds >= 2
+    assert max(fig["vs_oracle_5_steps"][k] for k in ("rho", "x", "dt")) < TOL, fig
+    assert max(fig["vs_one_device_40_steps"][k] for k in ("rho", "x")) < TOL, fig
+
+
+def test_c3_rank_mode_four_processes(tmp_path):
+    """sphmi_create_rank in 4 processes at C3 (shm transport, the processes sharing GPU 0): the union of the ranks is the
+    one-device result — capacities, message sizes, migration and negotiation at 1 M particles."""
+    from test_rank_mode import _spawn
+    from conftest import load_dam_break_3d_c3_flowing
+    from sphexample_amd.engine import make_engine
+    world, steps = 4, 50
+    res = _spawn(world, lambda r: ("run", "dam_break_3d_c3_flowing", steps, 4, str(tmp_path), 1, -1), timeout=900)
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+    p, s = load_dam_break_3d_c3_flowing()
+    ref = make_engine(p, s, device_float_bytes=4)
+    pr = ref.advance(1e9, max_steps=steps)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for q in parts:
+        np.testing.assert_array_equal(q["prog"][0, :4], [pr.iteration, pr.steps_done, pr.n_rebuilds, pr.index_counter])
+        np.testing.assert_allclose(q["prog"][0, 4:], [pr.total_time, pr.last_dt], rtol=1e-5)
+        assert tuple(q["info"][:3]) == (world, 1, 2)
+    ids = np.concatenate([q["ID"] for q in parts])
+    assert len(ids) == len(p) and len(np.unique(ids)) == len(p)
+    got = _by_id({k: np.concatenate([q[k] for q in parts]) for k in FIELDS})
+    r = _by_id(ref.download(FIELDS))
+    fig = dict(_errors(got, r, DP3), rebuilds=int(pr.n_rebuilds), owned=[int(len(q["ID"])) for q in parts])
+    _record("C3_rank_mode_4_processes", fig)
+    assert pr.n_rebuilds >= 2
+    assert fig["rho"] < TOL and fig["x"] < TOL, fig

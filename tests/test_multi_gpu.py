@@ -198,12 +198,89 @@ def test_rccl_binds_and_a_one_rank_world_runs(dam_break_3d_shipped):
     assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-12
 
 
+# ---- the hooks single-device handles have, on multi-device handles --------------------------
 @pytest.mark.gpu
-def test_multi_handle_rejects_the_single_device_hooks(dam_break_2d):
-    from sphexample_amd._abi import ERR_STATE, SphmiError
+@pytest.mark.parametrize("case,world,mdbc", [("dam_break_3d_shipped", 2, False), ("dam_break_3d_shipped", 3, False),
+                                              ("dam_break_2d_mdbc", 2, True), ("duckling", 2, True)])
+def test_forces_once_on_slabs(case, world, mdbc, request):
+    """sphmi_forces_once of a multi-device handle: collective rebuild (fresh ghost layers), Pressure!, [mDBC], one forces-only
+    pass over interior + edge tiles, rows merged into the one-device order.  Then the run goes on as if nothing happened."""
+    from conftest import perturbed
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    q = perturbed(p, seed=9)
+    ref, dd = make_engine(q, s, device_float_bytes=8), make_engine(q, s, device_float_bytes=8, devices=[0] * world)
+    d1, a1 = ref.forces_once(apply_mdbc=mdbc)
+    d2, a2 = dd.forces_once(apply_mdbc=mdbc)
+    np.testing.assert_array_equal(dd.download(("ID",))["ID"], ref.download(("ID",))["ID"])
+    assert np.abs(d2 - d1).max() <= 1e-10 * np.abs(d1).max() and np.abs(a2 - a1).max() <= 1e-10 * np.abs(a1).max()
+    pr, pd = ref.advance(1e9, max_steps=12), dd.advance(1e9, max_steps=12)
+    assert (pd.iteration, pd.n_rebuilds, pd.index_counter) == (pr.iteration, pr.n_rebuilds, pr.index_counter)
+    r, d = ref.download(("ID", "Density")), dd.download(("ID", "Density"))
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_kernel_output_on_slabs(dam_break_2d, world):
+    """StoreKernelOutput (src/SPHCellList.jl:106-116) on a multi-device handle: ΣW, Σ∇W of the last corrector, merged."""
+    import dataclasses
+    from conftest import perturbed
+    from sphexample_amd import StoreKernelOutput
     from sphexample_amd.engine import make_engine
     p, s = dam_break_2d
-    dd = make_engine(p, s, device_float_bytes=8, devices=[0, 0])
-    with pytest.raises(SphmiError) as ei:
-        dd.forces_once()
-    assert ei.value.status == ERR_STATE
+    s = dataclasses.replace(s, SimMetaData=dataclasses.replace(s.SimMetaData, KMode=StoreKernelOutput))
+    q = perturbed(p, seed=3)
+    ref, dd = make_engine(q, s, device_float_bytes=8), make_engine(q, s, device_float_bytes=8, devices=[0] * world)
+    ref.advance(1e9, max_steps=20); dd.advance(1e9, max_steps=20)
+    (k1, g1), (k2, g2) = ref.kernel_output(), dd.kernel_output()
+    np.testing.assert_array_equal(dd.download(("ID",))["ID"], ref.download(("ID",))["ID"])
+    assert k1.max() > 0 and np.abs(k2 - k1).max() <= 1e-10 * np.abs(k1).max() and np.abs(g2 - g1).max() <= 1e-9 * np.abs(g1).max()
+
+
+@pytest.mark.gpu
+def test_async_download_on_slabs(dam_break_3d_shipped):
+    """sphmi_download_begin / _end of a multi-device handle: the snapshot is taken in stream order on every slab, the copies
+    run while the next interval is computed, `end` merges — the arrays hold the state AT THE BEGIN call."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_3d_shipped
+    ref, dd = make_engine(p, s, device_float_bytes=8), make_engine(p, s, device_float_bytes=8, devices=[0, 0, 0])
+    ref.advance(1e9, max_steps=25); dd.advance(1e9, max_steps=25)
+    want = ref.download()
+    snap = p.copy()
+    dd.pin(snap)                                            # accepted (a no-op for multi-device handles)
+    dd.download_into_begin(snap)
+    dd.advance(1e9, max_steps=25)                           # incl. a collective rebuild: the snapshot must not move
+    dd.download_end()
+    dd.unpin()
+    for k in ("ID", "Position", "Velocity", "Density", "Pressure", "Type", "GroupMarker", "Cells"):
+        got = getattr(snap, k)
+        if want[k].dtype.kind == "f":
+            assert np.abs(got - want[k]).max() <= 1e-9 * max(np.abs(want[k]).max(), 1e-300), k
+        else:
+            np.testing.assert_array_equal(got, want[k], err_msg=k)
+    ref.advance(1e9, max_steps=25)
+    r, d = ref.download(("ID", "Density")), dd.download(("ID", "Density"))
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    assert np.abs(d["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,axis", [("dam_break_3d_shipped", 1), ("dam_break_2d", 0)])
+def test_column_work_on_device_matches_host(case, axis, request):
+    """The re-cut balances what the first cut balanced: the slabs' device-side work histogram (owned particles of every
+    slab, cell list of the rebuild; test hook sphmi_multi_column_cost) = particle_work summed per column, exactly."""
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(p.Position.shape[1])]
+    w = particle_work(cols)
+    dd = make_engine(p, s, device_float_bytes=8, devices=[0, 0], slab_axis=axis)
+    dd.advance(1e9, max_steps=1)                            # the first rebuild: cell list, ghost layers
+    col0, ncols = int(cols[axis].min()), int(cols[axis].max() - cols[axis].min() + 1)
+    got = np.zeros(ncols, dtype=np.uint64)
+    dd._lib.sphmi_multi_column_cost.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    dd._check(dd._lib.sphmi_multi_column_cost(dd._h, col0, ncols, got.ctypes.data_as(C.c_void_p)))
+    want = np.bincount(cols[axis] - col0, weights=w, minlength=ncols).astype(np.uint64)
+    np.testing.assert_array_equal(got, want)
+    assert want.sum() > 0
