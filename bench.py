@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precondition-ms", type=float, default=60.0,
                     help="untimed device pre-conditioning on a scratch handle before the warm-up steps (0 = off)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (cold window, fp64, developed flow, parity)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the slab driver even for one rank (measures its host overhead)")
     args = ap.parse_args()

@@ -313,6 +313,7 @@ struct Engine final : EngineBase {
         P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
         P.eta2 = (T)cfg.eta2;
         P.Kv2 = (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h);
+        P.inv_Kv2 = P.Kv2 != T(0) ? (T)(1.0 / (2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h)) : T(1);
         P.visc = cfg.viscosity; P.ddt = cfg.density_diffusion; P.shift = cfg.shifting == SPHMI_SHIFT_PLANAR;
         P.exact_cut = !(cfg.H >= 2.0 * cfg.h);
         P.kernel = cfg.kernel; P.kout = kout_d;
@@ -408,7 +409,8 @@ struct Engine final : EngineBase {
         // the compiled-in variant: the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
         const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
                           cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h &&
-                          cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE;
+                          cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE &&
+                          cfg.alpha != 0.0;      // (the compiled-in variant accumulates accelerations in units of the viscosity constant)
         if (dflt) launch_force_model<PASS, kModelDefault>(P, list);
         else      launch_force_model<PASS, kModelGeneric>(P, list);
     }

@@ -73,6 +73,20 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
     return SPHMI_QUEUE > 0 ? SPHMI_QUEUE : (WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12));
 }
 
+// Round-3 switches of the pair loop (defaults = what was measured best; 0 restores the round-2 code for the ablation runs)
+#ifndef SPHMI_ROLE_ENTRIES
+#define SPHMI_ROLE_ENTRIES 1    // the i / j role of a pair (density-diffusion orientation, Q4) rides in the queue entry: no index compares per pair
+#endif
+#ifndef SPHMI_PROD_RCP
+#define SPHMI_PROD_RCP 1        // 1/(r²+η²) and 1/((r²+η²)(ρ̄ᵢ+ρ̄ⱼ)) from ONE v_rcp_f32 of the product (fp32 kernels)
+#endif
+#ifndef SPHMI_KV2_FOLD
+#define SPHMI_KV2_FOLD 1        // the viscosity constant folded into the lane constants: accelerations accumulated in units of Kv2
+#endif
+#ifndef SPHMI_SETPRIO
+#define SPHMI_SETPRIO 0         // s_setprio in the pair loop: 1 = raised while the address is formed and the gathers are issued, 2 = raised during the arithmetic
+#endif
+
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 // model tags (values of include/sphmi.h)
 enum { kViscZero = 0, kViscArtificial = 1, kViscLaminar = 2, kViscLaminarSPS = 3 };
@@ -181,6 +195,7 @@ struct ForceParams {
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
     T nhinv_half, Cfac, big;   // −1/(2h);  −8·Cgw: ∇W factor = Cfac·u³ with u = clamp(1 − q/2);  2⁴⁰ (step01)
+    T inv_Kv2;                 // 1 / Kv2 (SPHMI_KV2_FOLD; 1 when Kv2 = 0: such handles run the run-time variant)
     T alphaD, tens_eps, inv_Wdx;   // CubicSpline: αD, CubicSpline.eps, 1 / W(q := dx) (src/SPHKernels.jl:114-126)
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
@@ -439,7 +454,11 @@ k_neighbor_force(const ForceParams<T> P) {
     const T rm_a = rho_a * P.m0;
     // lane constants of the pair terms: −m₀/ρₐ (pressure), −2·δᵩhc₀m₀·MLₐ (density diffusion; ZeroGravityLinear has no
     // MotionLimiter factor), Pₐ − Cb/γ·… (corrector: Pₐ + P_b = Cbe·r_b⁷ + (Pₐ − Cbe))
-    const T c_a = -P.m0 * inv_rho_a;
+    // (SPHMI_KV2_FOLD: the compiled-in model accumulates a / (Kv2·Cfac) and the density sums / Cfac — the viscosity term loses its
+    // constant, the pressure term takes 1/Kv2 into its lane constant, ∇W's factor is the bare u³; the sums are scaled back once
+    // after the loop; the host routes α = 0 to the run-time variant)
+    constexpr bool kFoldKv2 = SPHMI_KV2_FOLD && MODEL >= 0 && (MODEL & 15) == kViscArtificial && sizeof(T) == 4;
+    const T c_a = kFoldKv2 ? -P.m0 * inv_rho_a * P.inv_Kv2 : -P.m0 * inv_rho_a;
     const T Kd_a = (ddt == kDdtZeroGravityLinear || fluid_a) ? T(-2) * P.Kddt : T(0);
     const T PaC = P_a - P.Cbe;
 
@@ -478,6 +497,17 @@ k_neighbor_force(const ForceParams<T> P) {
     T sum_c = 0, sum_d = 0;                             // Σ (1/ρ_b)·(∇W·vᵢⱼ) (continuity without ρₐm₀), Σ density diffusion
     constexpr int kRecShift = sizeof(T) == 4 ? 5 : 6;      // log2 of the record size
     const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
+    unsigned rmask = 0;              // role of the current queue entry: all ones = the target plays "i" (SPHMI_ROLE_ENTRIES, below)
+    // `if_i` when the target plays "i", `if_j` otherwise
+    auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T {
+        if constexpr (SPHMI_ROLE_ENTRIES != 0) {
+            if constexpr (sizeof(T) == 4) return __uint_as_float((rmask & __float_as_uint(if_i)) | (~rmask & __float_as_uint(if_j)));      // v_bfi_b32
+            else {
+                const unsigned long long m64 = ((unsigned long long)rmask << 32) | rmask;
+                return __longlong_as_double((long long)((m64 & (unsigned long long)__double_as_longlong(if_i)) | (~m64 & (unsigned long long)__double_as_longlong(if_j))));
+            }
+        } else return a_is_i ? if_i : if_j;
+    };
     auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
         // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
         const T dx = xa - n0.x, dy = ya - n0.y, dz = (D == 3) ? za - n0.z : T(0);
@@ -491,7 +521,7 @@ k_neighbor_force(const ForceParams<T> P) {
         // branch: beyond H the clamp makes u = 0 and every pair term below carries the factor `fac`.
         const T r = fast_sqrt(r2);
         const T u = fma1_clamp01(r, P.nhinv_half);
-        T fac = P.Cfac * (u * u * u);
+        T fac = kFoldKv2 ? (u * u) * u : P.Cfac * (u * u * u);       // (folded: every sum of the compiled-in model is linear in Cfac — applied after the loop)
         T Wq = T(0);                                            // W(q): tensile correction / kernel output
         const bool cubic = MODEL < 0 && P.kernel == 1;
         if (MODEL < 0 && (cubic || P.kout)) {
@@ -514,7 +544,13 @@ k_neighbor_force(const ForceParams<T> P) {
         const T inv_rho_b = fast_rcp(rho_b);
         // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term); ρₐm₀ after the loop
         sum_c += inv_rho_b * (fac * vdx);
-        const T inv_r2e = fast_rcp(r2 + P.eta2);
+        constexpr bool kProdRcp = SPHMI_PROD_RCP && sizeof(T) == 4 && MODEL >= 0 && (MODEL & 15) == kViscArtificial;
+        T inv_r2e, inv_r2e_rs = T(0);                          // 1/(r²+η²);  1/((r²+η²)(ρ̄ₐ+ρ̄_b)) (artificial viscosity)
+        if constexpr (kProdRcp) {
+            const T rs = rhon_a + rhon_b;
+            inv_r2e_rs = fast_rcp((r2 + P.eta2) * rs);
+            inv_r2e = inv_r2e_rs * rs;
+        } else inv_r2e = fast_rcp(r2 + P.eta2);
         if (ddt != kDdtNone) {
             // density diffusion, src/SPHDensityDiffusionModels.jl:56-87 (no hydrostatic part, no MLcond),
             // :100-136 (linear), :150-188 (inverse hydrostatic EOS); orientation rule of SURVEY §8(a)-Q4:
@@ -530,8 +566,8 @@ k_neighbor_force(const ForceParams<T> P) {
             }
             const T drn = (rhon_b - rhon_a) - rhoH;
             T inv_sel;
-            if constexpr (PASS == PASS_CORRECTOR) inv_sel = a_is_i ? fast_rcp(rhon_b) : inv_rhon_a;
-            else inv_sel = a_is_i ? inv_rho_b : inv_rho_a;
+            if constexpr (PASS == PASS_CORRECTOR) inv_sel = pick_i(fast_rcp(rhon_b), inv_rhon_a, a_is_i);
+            else inv_sel = pick_i(inv_rho_b, inv_rho_a, a_is_i);
             // Dᵢ = δᵩhc₀·(m₀/ρ_sel)·ψ·∇W·MLᵢMLⱼ with ψ·∇W = −2·Δρ·fac·r²/(r²+η²); MLᵢ sits in Kd_a, MLⱼ is a 0/1 factor
             const T Dv = (Kd_a * inv_sel) * (drn * (fac * (r2 * inv_r2e)));
             const T on = ddt == kDdtZeroGravityLinear ? T(1) : step01(s_b, P.big);
@@ -556,7 +592,8 @@ k_neighbor_force(const ForceParams<T> P) {
         if (visc == kViscArtificial) {
             // ArtificialViscosity, src/SPHViscosityModels.jl:56-74 (ρ̄ from SimParticles.Density)
             const T vneg = min_raw(vdx, T(0));
-            coef += (P.Kv2 * (vneg * inv_r2e)) * fast_rcp(rhon_a + rhon_b);
+            if constexpr (kProdRcp) coef += kFoldKv2 ? vneg * inv_r2e_rs : P.Kv2 * (vneg * inv_r2e_rs);
+            else coef += kFoldKv2 ? (vneg * inv_r2e) * fast_rcp(rhon_a + rhon_b) : (P.Kv2 * (vneg * inv_r2e)) * fast_rcp(rhon_a + rhon_b);
         }
         coef *= fac;
         ax += coef * dx; ay += coef * dy;
@@ -626,6 +663,12 @@ k_neighbor_force(const ForceParams<T> P) {
     int qn = 0;
     unsigned cbase = 0;              // record offset of the candidate at bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
+    // SPHMI_ROLE_ENTRIES: which lanes' CURRENT entry holds pairs whose target plays "i" (orientation rule of the density diffusion,
+    // the target plays "i" iff j sorts before its cell, or after it inside it).  The role is a property of the
+    // ENTRY — phase 1 pushes the candidates of the target's own row split by role — so a lane keeps it as an all-ones / all-zeros
+    // word set at the refill (one arithmetic shift of the entry's second word: (record offset of bit 0) >> 1 with the role in
+    // bit 31) and SELECTS with it through v_bfi_b32: no index compares and no condition code per pair (3 of ≈64 vector instructions).
+    constexpr bool kRoleEntries = SPHMI_ROLE_ENTRIES != 0;
     char* const s_qb = reinterpret_cast<char*>(s_q);
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
@@ -637,14 +680,22 @@ k_neighbor_force(const ForceParams<T> P) {
     // 49.4; the 3-D run-time-model kernel at four waves per tile — DucklingMDBC — loses, 147.6 → 157.8: its corrector has no
     // registers left for a second neighbour)
     constexpr bool kTwoPairs = WPT >= 2 * SPHMI_TWO_PAIRS_MIN_WPT || (WPT >= SPHMI_TWO_PAIRS_MIN_WPT && (MODEL >= 0 || D == 2));
+#ifndef SPHMI_QFLAG
+#define SPHMI_QFLAG 1
+#endif
     auto run_pairs = [&](const int keep, const bool drain) {
         // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
+        // SPHMI_QFLAG: "current mask used up AND something queued" is ONE unsigned compare, cm < min(qn, 1); the 0 / 1 flag is
+        // kept up to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration
+        unsigned qf = qn != 0 ? 1u : 0u;
         bool more = qn != 0, have = cm != 0;
         if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0) do {
             unsigned m = cm;
-            if (!have & more) {                                  // fetch the next non-empty mask of MY queue
+            if (SPHMI_QFLAG ? (cm < qf) : (!have & more)) {      // fetch the next non-empty mask of MY queue
                 const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
-                m = ne.x; cbase = ne.y; raddr = q_next(raddr); qn -= 1;
+                m = ne.x; raddr = q_next(raddr); qn -= 1;
+                if (SPHMI_QFLAG) qf = min((unsigned)qn, 1u);
+                if constexpr (kRoleEntries) { rmask = (unsigned)((int)ne.y >> 31); cbase = ne.y << 1; } else cbase = ne.y;
             }
             work_it += 1;
 #ifdef SPHMI_STATS
@@ -652,7 +703,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #endif
             // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
             // cell (j < cs_a) or after it inside it (a < j < ce_a)
-            auto plays_i = [&](const unsigned jr) { return (jr < cs_ar) | ((jr > a_r) & (jr < ce_ar)); };
+            auto plays_i = [&](const unsigned jr) { return kRoleEntries ? rmask != 0u : (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
             if constexpr (kTwoPairs) {
                 // Lone waves (a tile of four or eight waves = a launch too small to hide latency behind other waves): TWO
                 // neighbours per iteration, their four gathers in flight together; the pairs are still accumulated one after
@@ -673,13 +724,24 @@ k_neighbor_force(const ForceParams<T> P) {
             } else {
                 cm = m & (m - 1);                                    // (0 stays 0)
                 if (m != 0) {
+#if SPHMI_SETPRIO == 1
+                    __builtin_amdgcn_s_setprio(1);
+#endif
                     const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
                     const V4 n0 = gather_packet(rs0, jr, 0, T());
                     const V4 n1 = gather_packet(rs0, jr, 1, T());
+#if SPHMI_SETPRIO == 1
+                    __builtin_amdgcn_s_setprio(0);
+#elif SPHMI_SETPRIO == 2
+                    __builtin_amdgcn_s_setprio(1);
+#endif
                     pair(jr, n0, n1, plays_i(jr));
+#if SPHMI_SETPRIO == 2
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 }
             }
-            more = qn != 0; have = cm != 0;
+            if (SPHMI_QFLAG) { more = (qf | cm) != 0u; have = false; } else { more = qn != 0; have = cm != 0; }
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
     };
 
@@ -775,8 +837,11 @@ k_neighbor_force(const ForceParams<T> P) {
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
             if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;
-            // room for two more entries (the two 32-candidate halves of a chunk) in every lane's queue?
-            if (__builtin_amdgcn_ballot_w64(qn > QCAP - 2) != 0) run_pairs(QCAP - 1 - SPHMI_QUEUE_SLACK, false);
+            // room for the entries of a chunk in every lane's queue?  Two (its 32-candidate halves); four for a chunk of the
+            // target's own row when the entries carry the role (each half split into the "i" and the "j" candidates)
+            const bool split_row = kRoleEntries && ddt != kDdtNone && seg == NSEG / 2;
+            const int need = split_row ? 4 : 2;
+            if (__builtin_amdgcn_ballot_w64(qn > QCAP - need) != 0) run_pairs(min(QCAP - 1 - SPHMI_QUEUE_SLACK, QCAP - need), false);
             unsigned long long m = scan_chunk(cb, HI);
             work_ch += 1;
 #ifdef SPHMI_STATS
@@ -788,12 +853,29 @@ k_neighbor_force(const ForceParams<T> P) {
             const int w = b1 - b0;
             const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
             m = (w > 0) ? (m & rm) : 0ull;
-            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            if (mlo != 0) { *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(mlo, (unsigned)cb << kRecShift); waddr = q_next(waddr); qn += 1; }
-            if (mhi != 0) { *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(mhi, (unsigned)(cb + 32) << kRecShift); waddr = q_next(waddr); qn += 1; }
+            auto push = [&](const unsigned bits, const int c0, const unsigned role_bit) {
+                if (bits != 0) {
+                    const unsigned w1 = kRoleEntries ? (((unsigned)c0 << (kRecShift - 1)) | role_bit) : ((unsigned)c0 << kRecShift);
+                    *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, w1); waddr = q_next(waddr); qn += 1;
+                }
+            };
+            if (!split_row) {
+                // rows before the target's own row hold candidates that sort before its cell (the target plays "i"), rows after it
+                // candidates that sort after its cell (the target plays "j")
+                const unsigned rb = (kRoleEntries && seg < NSEG / 2) ? 0x80000000u : 0u;
+                push((unsigned)m, cb, rb); push((unsigned)(m >> 32), cb + 32, rb);
+            } else {
+                // own row: "i" candidates = [.., cs_a) ∪ (a, ce_a), "j" candidates = [cs_a, a) ∪ [ce_a, ..)   (bit b = candidate cb + b)
+                auto below = [](const int n) -> unsigned long long { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); };
+                const unsigned long long R = below(cs_a - cb) | (below(ce_a - cb) & ~below(a + 1 - cb));
+                const unsigned long long mi = m & R, mj = m & ~R;
+                push((unsigned)mi, cb, 0x80000000u); push((unsigned)(mi >> 32), cb + 32, 0x80000000u);
+                push((unsigned)mj, cb, 0u); push((unsigned)(mj >> 32), cb + 32, 0u);
+            }
         }
     }
     run_pairs(0, true);
+    if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
