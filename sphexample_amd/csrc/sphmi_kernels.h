@@ -75,13 +75,19 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
 
 // Round-3 switches of the pair loop (defaults = what was measured best; 0 restores the round-2 code for the ablation runs)
 #ifndef SPHMI_ROLE_ENTRIES
-#define SPHMI_ROLE_ENTRIES 1    // the i / j role of a pair (density-diffusion orientation, Q4) rides in the queue entry: no index compares per pair
+#define SPHMI_ROLE_ENTRIES 0    // the i / j role of a pair (density-diffusion orientation, Q4) rides in the queue entry: no index compares per pair.
+                                // MEASURED AND OFF: −3 vector instructions per pair, but the own-row chunks push up to four entries (earlier drains,
+                                // more refills): 1.058 → 1.020e9 updates/s alone, 1.067 → 1.036e9 on top of the other three (gpurun_out/r3_sweep1.txt)
 #endif
 #ifndef SPHMI_PROD_RCP
 #define SPHMI_PROD_RCP 1        // 1/(r²+η²) and 1/((r²+η²)(ρ̄ᵢ+ρ̄ⱼ)) from ONE v_rcp_f32 of the product (fp32 kernels)
 #endif
 #ifndef SPHMI_KV2_FOLD
 #define SPHMI_KV2_FOLD 1        // the viscosity constant folded into the lane constants: accelerations accumulated in units of Kv2
+#endif
+#ifndef SPHMI_LDS_STAGE
+#define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
+                                // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
 #endif
 #ifndef SPHMI_SETPRIO
 #define SPHMI_SETPRIO 0         // s_setprio in the pair loop: 1 = raised while the address is formed and the gathers are issued, 2 = raised during the arithmetic
@@ -399,7 +405,9 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr int QCAP = queue_entries<T, PASS, WPT>();         // per-lane queue of non-empty accept masks
     static_assert(QCAP >= 4 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
-    __shared__ uint2 s_q_all[WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
+    __shared__ uint2 s_q_all[SPHMI_LDS_STAGE ? 1 : WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
+    // SPHMI_LDS_STAGE: the two packets of the 64 candidates of the chunk being worked on, per wave (2 / 4 KB in fp32 / fp64)
+    __shared__ V4 s_stage_all[SPHMI_LDS_STAGE ? WPT * TPB * 2 * kWave : 1];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wvb = threadIdx.x >> 6;                      // wave of the block
@@ -412,7 +420,8 @@ k_neighbor_force(const ForceParams<T> P) {
     const int wv = TPB == 1 ? wvb : (WPT == 1 ? 0 : ((wvb % WPT) ^ (int)((blockIdx.x >> 3) & 1)));
     // every lane owns one column of the queue array: no lane ever reads another lane's entries, so
     // program order is all the synchronisation the queue needs
-    uint2* const s_q = s_q_all + wvb * QCAP * kWave + lane;
+    uint2* const s_q = s_q_all + (SPHMI_LDS_STAGE ? 0 : wvb * QCAP * kWave + lane);
+    [[maybe_unused]] V4* const s_stage = s_stage_all + (SPHMI_LDS_STAGE ? wvb * 2 * kWave : 0);
     // Tile schedule (sphmi_rebuild.h): the dispatcher places block b on XCD b % 8; every XCD works through
     // one contiguous, cost-balanced run of tiles, expensive tiles first.  Measured on the 1 M-particle dam
     // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
@@ -500,7 +509,7 @@ k_neighbor_force(const ForceParams<T> P) {
     unsigned rmask = 0;              // role of the current queue entry: all ones = the target plays "i" (SPHMI_ROLE_ENTRIES, below)
     // `if_i` when the target plays "i", `if_j` otherwise
     auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T {
-        if constexpr (SPHMI_ROLE_ENTRIES != 0) {
+        if constexpr (SPHMI_ROLE_ENTRIES != 0 && SPHMI_LDS_STAGE == 0) {
             if constexpr (sizeof(T) == 4) return __uint_as_float((rmask & __float_as_uint(if_i)) | (~rmask & __float_as_uint(if_j)));      // v_bfi_b32
             else {
                 const unsigned long long m64 = ((unsigned long long)rmask << 32) | rmask;
@@ -668,7 +677,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // ENTRY — phase 1 pushes the candidates of the target's own row split by role — so a lane keeps it as an all-ones / all-zeros
     // word set at the refill (one arithmetic shift of the entry's second word: (record offset of bit 0) >> 1 with the role in
     // bit 31) and SELECTS with it through v_bfi_b32: no index compares and no condition code per pair (3 of ≈64 vector instructions).
-    constexpr bool kRoleEntries = SPHMI_ROLE_ENTRIES != 0;
+    constexpr bool kRoleEntries = SPHMI_ROLE_ENTRIES != 0 && SPHMI_LDS_STAGE == 0;
     char* const s_qb = reinterpret_cast<char*>(s_q);
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
@@ -853,6 +862,35 @@ k_neighbor_force(const ForceParams<T> P) {
             const int w = b1 - b0;
             const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
             m = (w > 0) ? (m & rm) : 0ull;
+#if SPHMI_LDS_STAGE
+            {
+                // Chunk-synchronous LDS staging (the design BASELINE config 3 names; DESIGN.md §4.4 and profiles/r03_lds_stage_ablation.md
+                // for why it is not what ships): every lane loads the record of ONE candidate, coalesced, and parks it in LDS; then
+                // the wave walks the accept masks of THIS chunk — a lane reads its neighbour's two packets with two ds_read_b128 —
+                // until the lane with the most accepted candidates in the chunk is done; lanes with fewer idle.  No mask queues.
+                const int c = cb + lane;
+                const bool cvs = c < HI;
+                const V4 s0 = P.src0[cvs ? c : cb], s1 = P.src1[cvs ? c : cb];
+                wave_sync();                                     // the readers of the previous chunk are done (one wave: program order)
+                s_stage[2 * lane] = s0; s_stage[2 * lane + 1] = s1;
+                wave_sync();
+                unsigned long long mm = m;
+                while (__builtin_amdgcn_ballot_w64(mm != 0ull) != 0) {
+                    work_it += 1;
+#ifdef SPHMI_STATS
+                    st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mm != 0ull));
+#endif
+                    if (mm != 0ull) {
+                        const int b = __builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const V4 n0 = s_stage[2 * b], n1 = s_stage[2 * b + 1];
+                        const unsigned jr = (unsigned)(cb + b) << kRecShift;
+                        pair(jr, n0, n1, (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))));
+                    }
+                }
+                continue;
+            }
+#endif
             auto push = [&](const unsigned bits, const int c0, const unsigned role_bit) {
                 if (bits != 0) {
                     const unsigned w1 = kRoleEntries ? (((unsigned)c0 << (kRecShift - 1)) | role_bit) : ((unsigned)c0 << kRecShift);

@@ -24,16 +24,22 @@ class Rendezvous:
     def __init__(self, rank: int, world: int, master_addr: Optional[str] = None, master_port: Optional[int] = None):
         import torch.distributed as dist
         self.rank, self.world, self._dist = rank, world, dist
-        addr = master_addr or os.environ.get("MASTER_ADDR") or "127.0.0.1"
-        port = master_port or os.environ.get("MASTER_PORT")
-        if port is None:
+        self._own = not dist.is_initialized()
+        if not self._own:
+            return
+        if master_port is None and os.environ.get("MASTER_PORT"):
+            # under a launcher (torch.distributed.run exports MASTER_ADDR / MASTER_PORT and may host the store itself):
+            # the launcher's own rendezvous, untouched
+            os.environ.setdefault("MASTER_ADDR", master_addr or "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            return
+        if master_port is None:
             if world > 1:
                 raise RuntimeError("MASTER_PORT is not set: launch with `python -m torch.distributed.run --master-addr 127.0.0.1 "
                                    "--master-port P …` (every rank must name the same port)")
-            port = free_port()                       # a one-rank world: nobody else has to know the port
-        self._own = not dist.is_initialized()
-        if self._own:
-            dist.init_process_group("gloo", init_method=f"tcp://{addr}:{int(port)}", rank=rank, world_size=world)
+            master_port = free_port()                # a one-rank world: nobody else has to know the port
+        addr = master_addr or os.environ.get("MASTER_ADDR") or "127.0.0.1"
+        dist.init_process_group("gloo", init_method=f"tcp://{addr}:{int(master_port)}", rank=rank, world_size=world)
 
     def broadcast_bytes(self, payload: Optional[bytes], src: int = 0) -> bytes:
         box = [payload if self.rank == src else None]

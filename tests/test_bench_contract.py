@@ -37,7 +37,9 @@ def test_bench_line_single_gpu():
     assert (j["n_gpus"], j["steps"], j["warmup"], j["dtype"], j["scaling"], j["higher_is_better"]) == (1, 4, 2, "f32", "weak", True)
     assert j["vs_baseline"] is None and j["value"] > 0 and "workload" in j["config"]
     rf = j["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # `bound` names the binding resource; achieved / peak / frac stay the HBM figure the metric asks for
+    assert rf["bound"] == "valu_issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert j["value_excl_rebuild"] >= j["value"] and j["rebuild_ms_in_window"] >= 0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert rf["peak_measured"] > 1000.0 and rf["launches"] > 0 and rf["avg_launch_ms"] > 0
     cb = j["cpu_baseline"]
@@ -62,4 +64,49 @@ def test_bench_line_two_ranks_on_one_gpu(transport):
     j = _line(r.stdout)
     assert KEYS <= set(j) and "cpu_baseline" not in j
     assert j["n_gpus"] == 2 and "SHARED-MEMORY" in j["config"]["parallelism"]
-    assert ("falling back" in r.stderr) == (transport == "rccl")
+    assert ("RCCL set-up failed" in r.stderr) == (transport == "rccl")
+    if transport == "rccl":                                 # the text names the slab and the call, not a bare "invalid usage"
+        assert "slab" in r.stderr and "ncclCommInitRank" in r.stderr
+
+
+def _identity():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.loaded_kernel_identity()
+
+
+def test_counters_are_quoted_for_the_profiled_kernel_only(tmp_path, monkeypatch):
+    """the PMC counters under profiles/ carry the identity of the kernels they were taken on (symbol,
+    ISA hash, registers, LDS); bench.py refuses them — traffic / valu null, the reason on the line — for any other build."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ident = _identity()
+    assert "error" not in ident, ident
+    assert set(ident) == {"predictor", "corrector"} and all(len(v["isa_sha16"]) == 16 and v["vgprs"] > 0 for v in ident.values())
+    counters = {k: {"valu_insts": 2.0e8, "valu_busy_frac": 0.8, "waves_per_simd_mean": 5.0, "wave_time_parked_on_waitcnt": 0.3} for k in ident}
+    rec = {"n_particles": 1000000, "kernels": ident, "counters": counters, "traffic": {"bytes_per_particle_per_launch_corrected": 100.0}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    path = tmp_path / bench.COUNTER_RECORD
+    json.dump(rec, open(path, "w"))
+    traffic, valu, why = bench.counters_for(ident, 500000, 0.5)
+    assert why is None and traffic == 5.0e7 and valu["wave_insts_per_launch"] == 1.0e8 and valu["busy_frac_pmc"] == 0.8
+    other = json.loads(json.dumps(ident)); other["corrector"]["isa_sha16"] = "0" * 16
+    traffic, valu, why = bench.counters_for(other, 500000, 0.5)
+    assert traffic is None and valu is None and "another kernel" in why and "corrector isa_sha16" in why
+    other = json.loads(json.dumps(ident)); other["predictor"]["vgprs"] += 8
+    assert bench.counters_for(other, 500000, 0.5)[2].count("predictor vgprs") == 1
+    os.remove(path)
+    assert bench.counters_for(ident, 500000, 0.5)[:2] == (None, None)
+
+
+def test_the_committed_counter_record_matches_the_tree():
+    """profiles/r03_counters.json (when present) must describe the kernels of the library built from THIS tree — a kernel
+    change without new counters shows up here, not as silently stale figures on the bench line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    path = os.path.join(ROOT, bench.COUNTER_RECORD)
+    if not os.path.exists(path):
+        pytest.skip("no counter record committed yet")
+    ident = _identity()
+    assert bench.counters_for(ident, 1000, 0.5)[2] is None

@@ -14,6 +14,7 @@ BENCH = ["k_neighbor_force<float, 3, 1, 33, 1, 4>", "k_neighbor_force<float, 3, 
 
 
 def code_object(lib, workdir):
+    lib = os.path.abspath(lib)
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", lib], cwd=workdir, check=True, capture_output=True)
     for f in os.listdir(os.path.dirname(lib)):
         pass
@@ -97,16 +98,11 @@ def classify(mn):
     return "other"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--lib", default=os.path.join(ROOT, "sphexample_amd", "libsphmi.so"))
-    ap.add_argument("--match", action="append")
-    ap.add_argument("--loop", action="store_true")
-    ap.add_argument("--json")
-    a = ap.parse_args()
-    want = a.match or BENCH
+def report(lib, want, with_loop=False):
+    """{demangled name: {symbol, isa_sha16, vgprs, lds_bytes, …, pair_loop}} for the kernels whose demangled name contains one of `want`."""
+    import hashlib
     with tempfile.TemporaryDirectory() as d:
-        co = code_object(a.lib, d)
+        co = code_object(lib, d)
         meta, ks = metadata(co), kernels(co)
     dm = demangle(list(ks))
     rep = {}
@@ -115,20 +111,35 @@ def main():
         if not any(w in name for w in want):
             continue
         mix = collections.Counter(classify(mnemonic(l)) for l in lines)
-        r = {"symbol": mangled, **meta.get(mangled, {}), "instructions": len(lines), "mix": dict(mix)}
+        text = "\n".join(re.sub(r"\s*//.*$", "", l.strip()) for l in lines)
+        r = {"symbol": mangled, **meta.get(mangled, {}), "instructions": len(lines), "mix": dict(mix),
+             "isa_sha16": hashlib.sha256(text.encode()).hexdigest()[:16]}
         pl = pair_loop(lines)
         if pl:
             body = lines[pl[0]:pl[1]]
             bm = collections.Counter(classify(mnemonic(l)) for l in body)
             r["pair_loop"] = {"instructions": len(body), "mix": dict(bm), "vector_alu_incl_trans": bm["valu"] + bm["trans"]}
+            if with_loop:
+                r["pair_loop"]["text"] = [re.sub(r"\s*//.*$", "", l.strip()) for l in body]
         rep[name] = r
-        print(f"{name}\n  vgprs {r.get('vgprs')} agprs {r.get('agprs')} sgprs {r.get('sgprs')} lds {r.get('lds_bytes')} scratch {r.get('scratch_bytes')}"
-              f" | {len(lines)} instructions {dict(mix)}")
-        if pl:
-            print(f"  pair loop: {r['pair_loop']}")
-            if a.loop:
-                for l in body:
-                    print("    " + re.sub(r"\s*//.*$", "", l.strip()))
+    return rep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "sphexample_amd", "libsphmi.so"))
+    ap.add_argument("--match", action="append")
+    ap.add_argument("--loop", action="store_true")
+    ap.add_argument("--json")
+    a = ap.parse_args()
+    rep = report(a.lib, a.match or BENCH, with_loop=a.loop)
+    for name, r in rep.items():
+        print(f"{name}\n  isa {r['isa_sha16']} vgprs {r.get('vgprs')} agprs {r.get('agprs')} sgprs {r.get('sgprs')} lds {r.get('lds_bytes')} "
+              f"scratch {r.get('scratch_bytes')} | {r['instructions']} instructions {r['mix']}")
+        if "pair_loop" in r:
+            print(f"  pair loop: {{k: v for k, v in r['pair_loop'].items() if k != 'text'}}".replace("{k: v for k, v in r['pair_loop'].items() if k != 'text'}", str({k: v for k, v in r['pair_loop'].items() if k != 'text'})))
+            for l in r["pair_loop"].get("text", []):
+                print("    " + l)
     if a.json:
         json.dump(rep, open(a.json, "w"), indent=1)
 
