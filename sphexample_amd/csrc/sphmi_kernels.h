@@ -89,6 +89,10 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
 #define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
 #endif
+#ifndef SPHMI_PREFETCH
+#define SPHMI_PREFETCH 0        // packet 0 of the NEXT neighbour is gathered before the arithmetic of the current one (its registers are free by
+                                // then: the four values taken from packet 0 are the first thing a pair computes); packet 1 follows from the same line
+#endif
 #ifndef SPHMI_SETPRIO
 #define SPHMI_SETPRIO 0         // s_setprio in the pair loop: 1 = raised while the address is formed and the gathers are issued, 2 = raised during the arithmetic
 #endif
@@ -375,8 +379,12 @@ __device__ __forceinline__ void wave_sync() {
 // TPB: tiles per block.  The TPB tiles of a workgroup are TPB consecutive entries of the XCD's run —
 // neighbouring tiles, whose candidate rows overlap by three quarters — and run on the four SIMDs of ONE compute unit,
 // so the rows are fetched into that unit's L1 once instead of by four units.
+#ifndef SPHMI_MIN_WAVES
+#define SPHMI_MIN_WAVES 0       // fp32 compiled-in-model kernels: waves per SIMD the register allocator must leave room for (0 = its own choice)
+#endif
 template <class T, int D, int PASS, int MODEL, int WPT, int TPB = 1>
 __global__ void __launch_bounds__(kWave * WPT * TPB)
+__attribute__((amdgpu_waves_per_eu((SPHMI_MIN_WAVES > 0 && sizeof(T) == 4 && MODEL >= 0 && D == 3) ? SPHMI_MIN_WAVES : 1, 8)))
 k_neighbor_force(const ForceParams<T> P) {
     static_assert(TPB == 1 || WPT <= 2, "several tiles per block: one or two waves per tile");
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
@@ -517,13 +525,13 @@ k_neighbor_force(const ForceParams<T> P) {
             }
         } else return a_is_i ? if_i : if_j;
     };
-    auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
-        // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
-        const T dx = xa - n0.x, dy = ya - n0.y, dz = (D == 3) ? za - n0.z : T(0);
+    // (the pair physics takes xᵢⱼ and the fourth word of packet 0 instead of the packet: with SPHMI_PREFETCH the registers of packet 0
+    // are re-used by the gather of the NEXT neighbour as soon as those four values have been taken from them)
+    auto pair_core = [&](const unsigned jr, const T dx, const T dy, const T dz, const T n0w, const V4& n1, const bool a_is_i) {
         const T r2 = (D == 3) ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
         T rho_b, rhon_b, s_b;
-        if constexpr (PASS == PASS_CORRECTOR) { rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w; }
-        else { rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; }
+        if constexpr (PASS == PASS_CORRECTOR) { rho_b = n0w; rhon_b = absT(n1.w); s_b = n1.w; }
+        else { rho_b = absT(n0w); rhon_b = rho_b; s_b = n0w; }
         // ∇W factor, src/SPHKernels.jl:80-87 with q = clamp(r/h, 0, 2) (src/SPHCellList.jl:280): (q − 2)³ = −8u³,
         // u = clamp(1 − q/2, 0, 1) — one fused multiply-add with the clamp output modifier.
         // The phase-1 mask is slightly generous; with H = 2h (the default k = 2) the r² ≤ H² cut of :275 needs no
@@ -651,6 +659,10 @@ k_neighbor_force(const ForceParams<T> P) {
             divr += (fluid_a && s_b > T(0)) ? dv : T(0);
         }
     };
+    // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
+    auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
+        pair_core(jr, xa - n0.x, ya - n0.y, (D == 3) ? za - n0.z : T(0), n0.w, n1, a_is_i);
+    };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
     // ONE descriptor over the neighbour records (2 packets each): 32-bit byte offsets, N·2·sizeof(packet) < 4 GB
@@ -692,7 +704,47 @@ k_neighbor_force(const ForceParams<T> P) {
 #ifndef SPHMI_QFLAG
 #define SPHMI_QFLAG 1
 #endif
-    auto run_pairs = [&](const int keep, const bool drain) {
+    // SPHMI_PREFETCH state (persists between the bursts of the pair loop): the neighbour whose packet 0 is already on its way
+    constexpr bool kPrefetch = SPHMI_PREFETCH != 0 && !kTwoPairs && !kRoleEntries && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
+    [[maybe_unused]] bool pf_ok = false;
+    [[maybe_unused]] unsigned pf_jr = (unsigned)ac << kRecShift;      // nothing requested yet: the lane's own record (a pair that adds nothing)
+    [[maybe_unused]] V4 pf_n0 = q0;
+    // A lane with nothing to do pairs its target with ITSELF: xᵢⱼ = 0 and vᵢⱼ = 0 make every term of the compiled-in model exactly
+    // zero, so the loop needs no execution mask around the gathers — and with the two gathers of an iteration issued
+    // unconditionally the compiler knows how many are outstanding and waits for packet 1 with vmcnt(1), leaving the next
+    // neighbour's packet 0 in flight through the arithmetic.
+    const unsigned self_r = (unsigned)ac << kRecShift;
+    auto run_pairs_prefetch = [&](const int keep, const bool drain) {
+        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+        unsigned qf = qn != 0 ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0) do {
+            work_it += 1;
+#ifdef SPHMI_STATS
+            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pf_ok));
+#endif
+            // 1. the pair of this iteration: its packet 0 was requested an iteration (or a burst) ago; packet 1 is in the same line
+            const unsigned jr = pf_jr;
+            const V4 n1 = gather_packet(rs0, jr, 1, T());
+            const T dx = xa - pf_n0.x, dy = ya - pf_n0.y, dz = (D == 3) ? za - pf_n0.z : T(0), n0w = pf_n0.w;
+            __builtin_amdgcn_sched_barrier(0);
+            // 2. the next neighbour of this lane (its own record when it has none): refill when the mask is used up, request packet 0
+            unsigned m = cm;
+            if (cm < qf) {
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
+                m = ne.x; raddr = q_next(raddr); qn -= 1;
+                qf = min((unsigned)qn, 1u);
+                cbase = ne.y;
+            }
+            cm = m & (m - 1);
+            pf_ok = m != 0;
+            pf_jr = pf_ok ? ((unsigned)__builtin_ctz(m) << kRecShift) + cbase : self_r;
+            pf_n0 = gather_packet(rs0, pf_jr, 0, T());
+            __builtin_amdgcn_sched_barrier(0);
+            // 3. the arithmetic of the current pair, while the next packet 0 is in flight
+            pair_core(jr, dx, dy, dz, n0w, n1, plays_i(jr));
+        } while (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0);
+    };
+    auto run_pairs_plain = [&](const int keep, const bool drain) {
         // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
         // SPHMI_QFLAG: "current mask used up AND something queued" is ONE unsigned compare, cm < min(qn, 1); the 0 / 1 flag is
         // kept up to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration
@@ -752,6 +804,9 @@ k_neighbor_force(const ForceParams<T> P) {
             }
             if (SPHMI_QFLAG) { more = (qf | cm) != 0u; have = false; } else { more = qn != 0; have = cm != 0; }
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
+    };
+    auto run_pairs = [&](const int keep, const bool drain) {
+        if constexpr (kPrefetch) run_pairs_prefetch(keep, drain); else run_pairs_plain(keep, drain);
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
