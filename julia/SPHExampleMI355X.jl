@@ -11,6 +11,13 @@
 # ZeroGravityLinear / Linear / Complex density diffusion and leaves user-defined SPHViscosity / SPHDensityDiffusion
 # subtypes (example/Dambreak2dMDBC.jl:46-66) on the CPU path — no method is overwritten.
 #
+# What one call costs on the host (round 3): the device → host copies of the fields the engine carries
+# (sphmi_download_begin … _end, straight into the columns of the StructArray, which are page-locked once), ONE gather per
+# passive column with the permutation the engine hands over (sphmi_download_permutation: the reference's sort! permutes all
+# 17 columns, src/SPHCellList.jl:142; the engine carries ten) — no sortperm, no per-particle loop: Type, GravityFactor,
+# MotionLimiter and BoundaryBool are per-particle constants and follow the same gather, Cells are written in place
+# (a CartesianIndex{D} is D Int64s).  The gathers run while the copies are in flight.
+#
 # Environment: SPHMI_LIB (path of libsphmi.so), SPHMI_DEVICE_FLOAT_BYTES (4 = fp32 kernels, default; 8 = fp64),
 # SPHMI_DEVICES ("0" default; "0,1,2,3,4,5,6,7" = one slab per GPU, halos over RCCL — same calls, see sphmi.h).
 #
@@ -46,18 +53,30 @@ const BuiltinDDT = Union{ZeroGravityLinearDensityDiffusion,LinearDensityDiffusio
 tag(::ZeroViscosity) = Int32(0); tag(::ArtificialViscosity) = Int32(1); tag(::Laminar) = Int32(2); tag(::LaminarSPS) = Int32(3)
 tag(::ZeroGravityLinearDensityDiffusion) = Int32(1); tag(::LinearDensityDiffusion) = Int32(2); tag(::ComplexDensityDiffusion) = Int32(3)
 
-const HANDLES = IdDict{Any,Ptr{Cvoid}}()          # SimParticles (identity) → engine handle
-atexit(() -> foreach(h -> ccall((:sphmi_destroy, LIB), Cint, (Ptr{Cvoid},), h), values(HANDLES)))
+# per simulation: the engine handle and the host scratch that lives as long as it (page-locked once, reused every interval)
+mutable struct Session
+    h::Ptr{Cvoid}
+    prev_row::Vector{Int64}              # sphmi_download_permutation: row i now was row prev_row[i] (0-based) at the previous call
+    perm::Vector{Int}                    # the same, 1-based
+    ucells::Vector{Int64}
+end
+const SESSIONS = IdDict{Any,Session}()            # SimParticles (identity) → session
+atexit(() -> foreach(s -> ccall((:sphmi_destroy, LIB), Cint, (Ptr{Cvoid},), s.h), values(SESSIONS)))
 
 function check(h, rc)
     rc == 0 || error("libsphmi status $rc: " * unsafe_string(ccall((:sphmi_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
 end
 
-function open_handle(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData::SimulationMetaData{D,T,S,K,B,L}, SimConstants, P, MotionDefinition) where {D,T,S,K,B,L}
+# the columns sphmi_download writes every interval: page-locked once (the arrays of the StructArray live for the whole run;
+# a multi-device handle accepts the call and stages through its own buffers)
+pin(h, a::Array) = isempty(a) || check(h, ccall((:sphmi_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), h, pointer(a), sizeof(a)))
+
+function open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData::SimulationMetaData{D,T,S,K,B,L}, SimConstants, P, MotionDefinition) where {D,T,S,K,B,L}
     devs = parse.(Int32, split(get(ENV, "SPHMI_DEVICES", "0"), ","))
+    N = length(P)
     cfg = SphmiConfig(sizeof(SphmiConfig), ABI_VERSION, D, sizeof(T), parse(Int32, get(ENV, "SPHMI_DEVICE_FLOAT_BYTES", "4")),
                       SimKernel.kernel isa CubicSpline ? 1 : 0, tag(SimViscosity), tag(SimDensityDiffusion), B <: SimpleMDBC ? 1 : 0,
-                      devs[1], S <: PlanarShifting ? 1 : 0, K <: StoreKernelOutput ? 1 : 0, length(P), 0,
+                      devs[1], S <: PlanarShifting ? 1 : 0, K <: StoreKernelOutput ? 1 : 0, N, 0,
                       SimConstants.ρ₀, SimConstants.dx, SimConstants.m₀, SimConstants.α, SimConstants.g, SimConstants.c₀,
                       SimConstants.γ, SimConstants.δᵩ, SimConstants.CFL, SimConstants.Cb, SimConstants.ν₀,
                       SimKernel.k, SimKernel.h, SimKernel.h⁻¹, SimKernel.H, SimKernel.H⁻¹, SimKernel.H², SimKernel.αD, SimKernel.η²,
@@ -79,8 +98,15 @@ function open_handle(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData::
         h, pointer(P.Position), pointer(P.Velocity), pointer(P.Acceleration), pointer(P.Density), pointer(typ), pointer(P.ID),
         pointer(P.GroupMarker), B <: SimpleMDBC ? pointer(P.GhostPoints) : C_NULL))
     check(h, ccall((:sphmi_set_clock, LIB), Cint, (Ptr{Cvoid}, Int64, Float64), h, SimMetaData.Iteration, SimMetaData.TotalTime))
-    return h
+    for a in (P.Position, P.Velocity, P.Acceleration, P.Density, P.Pressure, P.ID, P.GroupMarker, P.Cells)
+        pin(h, a)
+    end
+    B <: SimpleMDBC && pin(h, P.GhostPoints)
+    return Session(h, Vector{Int64}(undef, N), Vector{Int}(undef, N), Vector{Int64}(undef, SimMetaData.ExportGridCells ? N * D : 0))
 end
+
+# the reference's sort! permutes every column (src/SPHCellList.jl:142): the ones the engine does not carry follow by gather
+permute_column!(a::AbstractVector, perm) = (a .= a[perm]; nothing)
 
 # One output interval on the device: the contract of src/SPHCellList.jl:727-805 — advance until TotalTime > next output
 # time, leave the state in SimParticles (cell-sorted, every field permuted alike) and the counters in SimMetaData.
@@ -89,42 +115,42 @@ function SimulationLoop(SimDensityDiffusion::BuiltinDDT, SimViscosity::BuiltinVi
                         UniqueCells, CellDict, SortingScratchSpace, SimThreadedArrays, dρdtI, Velocityₙ⁺, Positionₙ⁺, ρₙ⁺,
                         ∇Cᵢ, ∇◌rᵢ, MotionDefinition) where {D,T,S,K,B,L}
     P = SimParticles
-    N = length(P)
-    h = get!(() -> open_handle(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData, SimConstants, P, MotionDefinition), HANDLES, P)
+    s = get!(() -> open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData, SimConstants, P, MotionDefinition), SESSIONS, P)
+    h = s.h
     prog = SphmiProgress()
     check(h, ccall((:sphmi_advance, LIB), Cint, (Ptr{Cvoid}, Float64, Int64, Ref{SphmiProgress}), h, Float64(next_output_time(SimMetaData)), -1, prog))
     SimMetaData.Iteration, SimMetaData.CurrentTimeStep, SimMetaData.TotalTime = prog.iteration, T(prog.last_dt), T(prog.total_time)
-    old_id = copy(P.ID)
-    typ = Vector{UInt8}(undef, N); cells = Vector{Int64}(undef, N * D)
-    GC.@preserve P typ cells begin
-        check(h, ccall((:sphmi_download, LIB), Cint,
+    SimMetaData.IndexCounter = prog.index_counter
+    GC.@preserve P s begin
+        # the carried fields: snapshot on the device, copies on a second stream, straight into the StructArray's columns
+        # (Cells: a Vector{CartesianIndex{D}} is N·D Int64; Type is a per-particle constant and follows the gather below)
+        check(h, ccall((:sphmi_download_begin, LIB), Cint,
             (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}, Ptr{UInt64}, Ptr{Cvoid}, Ptr{Int64}),
             h, pointer(P.Position), pointer(P.Velocity), pointer(P.Acceleration), pointer(P.Density), pointer(P.Pressure),
-            pointer(P.ID), pointer(typ), pointer(P.GroupMarker), B <: SimpleMDBC ? pointer(P.GhostPoints) : C_NULL, pointer(cells)))
-        K <: StoreKernelOutput && check(h, ccall((:sphmi_download_kernel_output, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, pointer(P.Kernel), pointer(P.KernelGradient)))
-    end
-    # fields the engine does not carry follow the particles through the sort by ID (the reference's sort! permutes all 17)
-    perm = Vector{Int}(undef, N); perm[sortperm(P.ID)] = sortperm(old_id)             # new row i was old row perm[i]
-    P.GhostNormals .= P.GhostNormals[perm]; P.ChunkID .= P.ChunkID[perm]
-    K <: StoreKernelOutput || (P.Kernel .= P.Kernel[perm]; P.KernelGradient .= P.KernelGradient[perm])
-    @inbounds for i in 1:N
-        P.Type[i] = ParticleType(typ[i])
-        P.Cells[i] = CartesianIndex(ntuple(d -> Int(cells[(i - 1) * D + d]), D))
-        P.GravityFactor[i] = typ[i] == 1 ? -one(T) : (typ[i] == 3 ? one(T) : zero(T))   # src/PreProcess.jl:78-100
-        P.MotionLimiter[i] = typ[i] == 1 ? one(T) : zero(T)
-        P.BoundaryBool[i] = typ[i] == 1 ? 0x00 : 0x01
-    end
-    SimMetaData.IndexCounter = prog.index_counter
-    if SimMetaData.ExportGridCells     # UniqueCells[2:IndexCounter] for save_grid (:890-893); slot 1 is the reference's dummy entry (:145-147)
-        nref = Ref{Int64}(0)
-        ucells = Vector{Int64}(undef, N * D)
-        GC.@preserve ucells check(h, ccall((:sphmi_unique_cells, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Int64}), h, pointer(ucells), N, nref))
-        @inbounds for k in 1:min(Int(nref[]), length(UniqueCells) - 1)
-            UniqueCells[k + 1] = CartesianIndex(ntuple(d -> Int(ucells[(k - 1) * D + d]), D))
+            pointer(P.ID), C_NULL, pointer(P.GroupMarker), B <: SimpleMDBC ? pointer(P.GhostPoints) : C_NULL,
+            Ptr{Int64}(pointer(P.Cells))))
+        # while they are in flight: the sort as a permutation, and one gather per passive column
+        check(h, ccall((:sphmi_download_permutation, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), h, pointer(s.prev_row)))
+        s.perm .= s.prev_row .+ 1
+        for col in (P.Type, P.GravityFactor, P.MotionLimiter, P.BoundaryBool, P.GhostNormals, P.ChunkID)
+            permute_column!(col, s.perm)
         end
+        if K <: StoreKernelOutput
+            check(h, ccall((:sphmi_download_kernel_output, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h, pointer(P.Kernel), pointer(P.KernelGradient)))
+        else
+            permute_column!(P.Kernel, s.perm); permute_column!(P.KernelGradient, s.perm)
+        end
+        if SimMetaData.ExportGridCells     # UniqueCells[2:IndexCounter] for save_grid (:890-893); slot 1 is the reference's dummy entry (:145-147)
+            nref = Ref{Int64}(0)
+            check(h, ccall((:sphmi_unique_cells, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Int64}), h, pointer(s.ucells), length(P), nref))
+            @inbounds for k in 1:min(Int(nref[]), length(UniqueCells) - 1)
+                UniqueCells[k + 1] = CartesianIndex(ntuple(d -> Int(s.ucells[(k - 1) * D + d]), D))
+            end
+        end
+        check(h, ccall((:sphmi_download_end, LIB), Cint, (Ptr{Cvoid},), h))
     end
     if SimMetaData.TotalTime > SimMetaData.SimulationTime                              # last interval (:909): release the GPUs
-        ccall((:sphmi_destroy, LIB), Cint, (Ptr{Cvoid},), h); delete!(HANDLES, P)
+        ccall((:sphmi_destroy, LIB), Cint, (Ptr{Cvoid},), h); delete!(SESSIONS, P)
     end
     return nothing
 end

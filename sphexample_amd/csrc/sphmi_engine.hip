@@ -1209,7 +1209,8 @@ extern "C" {
 static_assert(SPHMI_ABI_VERSION == 3, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
     return "sphmi abi 3 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
-           "counting-sort cell list, mDBC, moving bodies, shifting | multi-GPU slabs over RCCL | no CPU fallback";
+           "counting-sort cell list, mDBC, moving bodies, shifting | multi-device handles: slabs over device copies / RCCL "
+           "(RCCL transport not yet run with more than one rank) | no CPU fallback";
 }
 
 const char* sphmi_last_error(const sphmi_handle* h) {
