@@ -343,7 +343,19 @@ def main():
         rdv = Rendezvous(rank, env_world)
         barrier, reduce_max = rdv.barrier, rdv.max
         make = lambda uid: make_engine(particles, setup, device_float_bytes=4, device=device, rank=rank, world=world, unique_id=uid)  # noqa: E731
+        # a communicator set-up that cannot reach its peers does not fail, it waits: give up loudly instead of sitting in the
+        # driver's time limit ($SPHMI_BENCH_SETUP_TIMEOUT seconds, default 300)
+        import threading
+
+        def give_up():
+            print(f"[bench] rank {rank}: the slab engines were not set up within the time limit (RCCL communicator set-up hanging?) — "
+                  f"try `bench.py --gpus {world} --single-process` or SPHMI_TRANSPORT=local", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(float(os.environ.get("SPHMI_BENCH_SETUP_TIMEOUT", "300")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         eng, errs = create_rank_engine(rdv, make)
+        watchdog.cancel()
         how = "one process per GPU (sphmi_create_rank)"
         if eng is None and os.environ.get("SPHMI_TRANSPORT") != "shm":
             if rank == 0:

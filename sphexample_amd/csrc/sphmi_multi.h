@@ -1356,7 +1356,7 @@ struct MultiEngine final : EngineBase {
         R[0].e->timers(cap, names, secs, calls, n);
         if (!secs) return;
         for (size_t q = 1; q < R.size(); ++q) {
-            double sq[PH_COUNT] = {}; int32_t nq = 0;
+            double sq[PH_COUNT + 1] = {}; int32_t nq = 0;
             R[q].e->timers(PH_COUNT, nullptr, sq, nullptr, &nq);
             for (int i = 0; i < PH_COUNT && i < cap; ++i) secs[i] = std::max(secs[i], sq[i]);
         }

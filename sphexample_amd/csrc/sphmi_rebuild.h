@@ -38,12 +38,22 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // 0x80 / 0x40 = ghost copy of a particle owned by the left / right neighbour rank.
 constexpr uint8_t kGhostLeft = 0x80, kGhostRight = 0x40, kGhostMask = 0xC0, kTypeMask = 0x3F;
 
+struct GridDesc {
+    int gmin[3];      // cell coordinate of padded index 1
+    int np[3];        // padded dims (n + 2)
+    int ncell;        // np[0]*np[1]*np[2]
+};
+
+// bbox[0..5]: min / max cell coordinate per axis.  With `old_key` (the keys of the last sort, on the grid `og`): bbox[6] is set when
+// some particle is no longer in the cell it was sorted into — if none is, the stable sort the reference runs here
+// (src/SPHCellList.jl:142) is the identity permutation and the rebuild has nothing to do (Engine::rebuild).
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
-                                                   T inv_cutoff, int* bbox) {
+                                                   T inv_cutoff, int* bbox, const int* old_key, GridDesc og) {
     // grid-stride: a few hundred blocks, so that the six atomics per WAVE are a few thousand in total — one wave per
     // 64 particles (16 k waves at 1 M) spent 228 µs queueing on the one cache line, for 16 MB of streaming reads
     int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    bool moved = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         if (type[i] == 0) continue;
         const auto p = pk0[i];
@@ -51,7 +61,13 @@ __global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::
                           D == 3 ? map_floor<T>(p.z, inv_cutoff) : 0};
 #pragma unroll
         for (int d = 0; d < 3; ++d) { mn[d] = c[d] < mn[d] ? c[d] : mn[d]; mx[d] = c[d] > mx[d] ? c[d] : mx[d]; }
+        if (old_key) {
+            const int cx = c[0] - og.gmin[0] + 1, cy = c[1] - og.gmin[1] + 1, cz = D == 3 ? c[2] - og.gmin[2] + 1 : 0;
+            const bool inside = cx >= 1 && cx <= og.np[0] - 2 && cy >= 1 && cy <= og.np[1] - 2 && (D < 3 || (cz >= 1 && cz <= og.np[2] - 2));
+            moved |= !inside || (cx + og.np[0] * (cy + og.np[1] * cz)) != old_key[i];
+        }
     }
+    if (old_key && __builtin_amdgcn_ballot_w64(moved) != 0 && (threadIdx.x & 63) == 0) atomicOr(&bbox[6], 1);
     __shared__ int s_box[4][6];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -66,12 +82,6 @@ __global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::
         if (d < 3) atomicMin(&bbox[d], v); else atomicMax(&bbox[d], v);
     }
 }
-
-struct GridDesc {
-    int gmin[3];      // cell coordinate of padded index 1
-    int np[3];        // padded dims (n + 2)
-    int ncell;        // np[0]*np[1]*np[2]
-};
 
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_count(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
@@ -800,15 +810,6 @@ __global__ void __launch_bounds__(256) k_cells_out(const int* key, const int* fl
     if (D == 3) o[2] = (long long)cz - 1 + g.gmin[2];
 }
 
-// the four reduction slots → a caller-owned buffer, slots reset (one launch instead of a copy and a fill).
-// MAX-merged into what the buffer holds: k_step_control zeroes the buffer when a step consumes it, so whatever is
-// still there belongs to a control that returned early (loop bound reached, rebuild pending) and must survive until
-// the next executed step — the first step of the next output interval would otherwise run with Δt from empty maxima.
-__global__ void k_take_reductions(unsigned long long* red, unsigned long long* out) {
-    const int i = threadIdx.x;
-    if (i < 4) { const unsigned long long a = out[i], b = red[i]; out[i] = a > b ? a : b; red[i] = 0; }
-}
-
 // ProgressMotion, src/SPHCellList.jl:575-596: particles of Type Moving whose GroupMarker has a MotionDetails get
 // Velocity = v·dir·ShouldMove and Position += Velocity·dt/2 (state set A, in place).
 struct MotionTable {
@@ -928,26 +929,6 @@ __global__ void __launch_bounds__(256) k_dd_kill(uint8_t* type, const int* idx, 
 __global__ void __launch_bounds__(256) k_dd_kill_ghosts(uint8_t* type, int N) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N && (type[i] & kGhostMask)) type[i] = 0;
-}
-
-// per-step halo: packets of the listed particles → contiguous [n×V4 pk0][n×V4 pk1] and back
-template <class T>
-__global__ void __launch_bounds__(256) k_halo_pack(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
-                                                   const int* idx, int n, typename Vec4<T>::type* buf) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int i = idx[k];
-    buf[k] = pk0[i];
-    buf[n + k] = pk1[i];
-}
-template <class T>
-__global__ void __launch_bounds__(256) k_halo_unpack(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
-                                                     const int* idx, int n, const typename Vec4<T>::type* buf) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int i = idx[k];
-    pk0[i] = buf[k];
-    pk1[i] = buf[n + k];
 }
 
 }  // namespace sphmi

@@ -742,3 +742,32 @@ def test_mid_size_launch_matches_the_oracle():
         e = by_id(eng.download())
         assert relmax(e["Density"], o["Density"]) < tol
         assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < tol
+
+
+@pytest.mark.parametrize("case,fb", [("dam_break_3d_shipped", 4), ("dam_break_2d", 8), ("dam_break_2d_mdbc", 8)])
+def test_identity_rebuilds_change_nothing(case, fb, request, monkeypatch):
+    """Every sphmi_advance opens with UpdateNeighbors! (Δx re-armed, src/SPHCellList.jl:739).  When no particle has left the cell
+    it was sorted into, the reference's stable sort (:142) is the identity and the engine stops after the test that says so
+    (k_cell_bbox compares every particle's cell with the key of the last sort).  Step-by-step driving from rest — every call a
+    rebuild, almost all of them identities — must give bit for bit what the always-sorting engine gives, the same counters
+    as the oracle, and must actually take the short cut."""
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SPHMI_SAME_CELLS", flag)
+        eng = make_engine(p, s, device_float_bytes=fb)
+        prog = [eng.advance(1e9, max_steps=2) for _ in range(12)]
+        out[flag] = (eng.download(), [(q.iteration, q.n_rebuilds, q.index_counter, q.total_time, q.last_dt) for q in prog],
+                     eng.timers()["02b UpdateNeighbors calls that were the identity (no sort)"][1], eng.unique_cells())
+    for k, v in out["1"][0].items():
+        np.testing.assert_array_equal(v, out["0"][0][k], err_msg=k)
+    assert out["1"][1] == out["0"][1]
+    np.testing.assert_array_equal(out["1"][3], out["0"][3])
+    assert out["0"][2] == 0 and out["1"][2] >= 6, (out["0"][2], out["1"][2])
+    orc = engines(p, s, fb)[1]
+    po = [orc.advance(1e9, max_steps=2) for _ in range(12)]
+    assert [(q.iteration, q.n_rebuilds, q.index_counter) for q in po] == [t[:3] for t in out["1"][1]]
+    e, o = by_id(out["1"][0]), by_id(orc.download())
+    np.testing.assert_array_equal(out["1"][0]["ID"], orc.download(("ID",))["ID"]) if fb == 8 else None
+    assert relmax(e["Density"], o["Density"]) < (1e-9 if fb == 8 else 1e-5)
