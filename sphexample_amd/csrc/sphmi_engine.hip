@@ -116,6 +116,7 @@ struct Engine final : EngineBase {
     // per step at queue time; after a batch the control index is the last one written and the slot index the one the last
     // EXECUTED corrector filled.  Handles with mDBC, moving bodies or a slab keep index 0 (k_step_control works in place).
     int cpar = 0, rpar = 0;
+    bool ghost_given = false;          // sphmi_upload handed in GhostPoints (they are permuted at every rebuild then)
     int fuse_ctrl = 1;                 // $SPHMI_FUSE_CTRL=0: a k_step_control launch per step for every handle (experiments)
     int same_cells = 1;                // $SPHMI_SAME_CELLS=0: every rebuild sorts, also when no particle changed its cell
     int64_t n_identity_rebuilds = 0;   // rebuilds that ended at the "nobody moved" test
@@ -191,7 +192,7 @@ struct Engine final : EngineBase {
         for (int k = 0; k < 3; ++k) { HC(hipMalloc(&rec[k], 2 * n * sizeof(V4))); pk0[k] = Half<V4>(rec[k]); pk1[k] = Half<V4>(rec[k] + 1); }
         for (int k = 0; k < 2; ++k) {
             HC(hipMalloc(&acc[k], n * sizeof(V4)));
-            HC(hipMalloc(&ghost[k], n * sizeof(V4)));
+            HC(hipMalloc(&ghost[k], n * sizeof(V4))); HC(hipMemset(ghost[k], 0, n * sizeof(V4)));
             HC(hipMalloc(&type[k], n));
             HC(hipMalloc(&id[k], n * 8));
             HC(hipMalloc(&grp[k], n * 8));
@@ -212,7 +213,7 @@ struct Engine final : EngineBase {
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
-        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 4 * 8));
+        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 8 * 8));
     }
     ~Engine() override {
         (void)hipSetDevice(cfg.device);
@@ -520,7 +521,9 @@ struct Engine final : EngineBase {
         A.key_in = key[cur]; A.key_out = key[nxt];
         A.tag_in = otag[cur]; A.tag_out = otag[nxt];
         A.prow_in = prow[cur]; A.prow_out = prow[nxt];
-        A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE;
+        // (GhostPoints travel with the sort whenever the caller uploaded some — the reference permutes the column with every other,
+        // :142 — not only for mDBC handles: found as uninitialised GhostPoints in a download after an odd number of rebuilds)
+        A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
         if (otag[0]) {
             for (int d = 0; d < D; ++d)
@@ -687,6 +690,7 @@ struct Engine final : EngineBase {
                 for (int k = 0; k < batch; ++k) { batch_step = k; enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
                 batch_step = -1;
                 HC(hipMemcpyAsync(ctrl_h, ctrl_cur(), sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));      // the block the last queued step wrote
+                HC(hipMemcpyAsync(red_h, red_d, 8 * 8, hipMemcpyDeviceToHost, stream));                        // both sets of slots (below: the bad-ρ flag)
                 sync_and_collect(ctrl_h, before);
                 c = *ctrl_h;
                 steps = c.steps_done;
@@ -717,7 +721,14 @@ struct Engine final : EngineBase {
                     HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
                     continue;
                 }
-                if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) break;
+                if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) {
+                    // The corrector of the LAST executed step may have produced a non-positive density: no control runs after it in
+                    // this call, so its flag (slot 3 of the set that corrector filled) is looked at here — the state must not be
+                    // handed out as if it were good (tests/test_fuzz_gpu.py).
+                    if (red_h[4 * rpar + 3] != 0)
+                        throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
+                    break;
+                }
             }
         } catch (...) { fill(out, steps); throw; }
         fill(out, steps);
@@ -758,6 +769,7 @@ struct Engine final : EngineBase {
         for (int i = 0; i < N; ++i)
             if (!(std::fabs((double)h0[i].w) > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
         iA = 0; iH = 1; iB = 2; cur = 0;
+        ghost_given = ghost_points != nullptr;
         const size_t n = (size_t)N;
         std::vector<V4> hrec(2 * n);                                     // the two packets of a particle side by side
         for (size_t i = 0; i < n; ++i) { hrec[2 * i] = h0[i]; hrec[2 * i + 1] = h1[i]; }
@@ -807,7 +819,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&flag, (size_t)M * 4)); HC(hipMalloc(&pos, (size_t)M * 4)); HC(hipMalloc(&tsum, (size_t)(ntiles + 2) * 4)); HC(hipMalloc(&tot_d, 16));
         auto release = [&]() { (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(tsum); (void)hipFree(tot_d); };
         try {
-            iA = 0; iH = 1; iB = 2; cur = 0;
+            iA = 0; iH = 1; iB = 2; cur = 0; ghost_given = false;
             int base = 0;
             const unsigned nbM = (unsigned)((M + 255) / 256);
             for (int which = 1; which <= 2; ++which) {              // the tank first, then the pillar object

@@ -133,11 +133,14 @@ __device__ __forceinline__ bool step_control_decide(unsigned long long r0, unsig
                                                     unsigned long long r3, StepCtrl& c, double h, double c0, double CFL) {
     if (c.stop || c.error || c.need_rebuild) { c.active = 0; return false; }
     if (!c.resume) {
+        // a non-positive density of the LAST corrector is an error of this call even when the loop bound ends it here: the state
+        // set it went into must not be handed out as if it were good (found by tests/test_fuzz_gpu.py: the flag used to be
+        // looked at after the loop bound, so a bad last step of an interval surfaced one sphmi_advance late)
+        if (r3) { c.error = 2; c.active = 0; return false; }
         if (!(c.total_time <= c.t_target) || (c.max_steps >= 0 && c.steps_done >= c.max_steps)) { c.stop = 1; c.active = 0; return false; }
         auto dec = [](unsigned long long b) -> double {
             if constexpr (sizeof(T) == 4) return (double)__uint_as_float((unsigned)b); else return __longlong_as_double((long long)b);
         };
-        if (r3) { c.error = 2; c.active = 0; return false; }
         const double maxdisp = sqrt(dec(r0)), visc = dec(r1), amax = sqrt(dec(r2));
         c.delta_x += 4.0 * maxdisp;
         const double dt1 = sqrt(h / amax), dt2 = h / (c0 + visc);

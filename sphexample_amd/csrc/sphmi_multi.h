@@ -1142,6 +1142,17 @@ struct MultiEngine final : EngineBase {
         } catch (...) { iteration += steps; delta_x = dxl; fill(out, steps); throw; }
         iteration += steps; delta_x = dxl;
         for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
+        {   // the bad-ρ flag of the LAST corrector: no control looks at it in this call (Engine::advance does the same)
+            std::vector<long long> bad(R.size(), 0);
+            for (size_t q = 0; q < R.size(); ++q) {
+                Rank& r = R[q]; HC(hipSetDevice(r.device));
+                unsigned long long f = 0;
+                HC(hipMemcpy(&f, r.e->red_d + 3, 8, hipMemcpyDeviceToHost));
+                bad[q] = f != 0;
+            }
+            host_allreduce(bad, 1, OP_MAX);
+            if (bad[0]) { fill(out, steps); throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced on some slab"); }
+        }
         index_counter = 1;                                               // SimMetaData.IndexCounter = 1 + occupied cells (:145-157)
         for (auto& r : R) {
             HC(hipSetDevice(r.device));

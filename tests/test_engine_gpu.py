@@ -772,3 +772,20 @@ def test_identity_rebuilds_change_nothing(case, fb, request, monkeypatch):
     e, o = by_id(out["1"][0]), by_id(orc.download())
     np.testing.assert_array_equal(out["1"][0]["ID"], orc.download(("ID",))["ID"]) if fb == 8 else None
     assert relmax(e["Density"], o["Density"]) < (1e-9 if fb == 8 else 1e-5)
+
+
+def test_ghost_points_follow_the_sort_without_mdbc(dam_break_2d):
+    """GhostPoints is one of the 17 columns the reference's sort! permutes (src/SPHCellList.jl:142) whether or not mDBC reads
+    it.  A NoMDBC handle that was given ghost points hands them back row-aligned after any number of rebuilds (the column used
+    to travel for mDBC handles only: a download after an odd number of rebuilds showed the other, never-written buffer)."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d
+    q = perturbed(p, seed=4, vel_scale=3.0)
+    q.GhostPoints[:] = np.stack([q.ID * 1.5, -q.ID * 0.25], axis=1)
+    eng = make_engine(q, s, device_float_bytes=8)
+    eng.upload(q.Position, q.Velocity, q.Acceleration, q.Density, q.Type, q.ID, q.GroupMarker, q.GhostPoints)
+    for calls in range(1, 6):
+        pr = eng.advance(1e9, max_steps=9)
+        d = eng.download(("ID", "GhostPoints"))
+        np.testing.assert_array_equal(d["GhostPoints"], np.stack([d["ID"] * 1.5, -d["ID"] * 0.25], axis=1), err_msg=f"after {pr.n_rebuilds} rebuilds")
+    assert pr.n_rebuilds >= 5
