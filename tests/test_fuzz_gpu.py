@@ -103,3 +103,90 @@ def test_fuzzed_cloud_matches_the_oracle(seed):
         np.testing.assert_array_equal(d["ID"], eng.download(("ID",))["ID"])
         dd_ = _by_id(d)
         assert np.abs(dd_["Density"] - o["Density"]).max() < 1e-8 * np.abs(o["Density"]).max(), shape
+
+
+# ---- second generation: every switch behind the ABI at once ------------------------------------------------------------
+def _case2(seed):
+    """As _case, plus: CubicSpline kernel, PlanarShifting, StoreKernelOutput, mDBC with random ghost nodes, a Moving group with a
+    MotionDetails, k = √2, particles sitting EXACTLY on cell faces, and fp32 or fp64 kernels."""
+    from sphexample_amd import CubicSpline, Geometry, Moving, SPHKernelInstance, StoreKernelOutput, WendlandC2
+    from sphexample_amd.config import MotionDetails, PlanarShifting, SimpleMDBC
+    p, s, shape = _case(seed)
+    rng = np.random.default_rng(5000 + seed)
+    dims, n = s.SimMetaData.Dimensions, len(p)
+    meta = s.SimMetaData
+    kern = s.SimKernel
+    if rng.random() < 0.3:
+        kern = SPHKernelInstance(dims, CubicSpline(0.2), h=kern.h, k=kern.k)
+    elif rng.random() < 0.3:
+        kern = SPHKernelInstance(dims, WendlandC2(), h=kern.h, k=float(np.sqrt(2)))
+    if rng.random() < 0.3:
+        meta = dataclasses.replace(meta, SMode=PlanarShifting)
+    if rng.random() < 0.3:
+        meta = dataclasses.replace(meta, KMode=StoreKernelOutput)
+    if rng.random() < 0.35 and shape != "blob":
+        meta = dataclasses.replace(meta, BMode=SimpleMDBC)
+        bnd = p.Type != 1
+        p.GhostPoints[bnd] = p.Position[bnd] + rng.normal(0, 1.0, size=(int(bnd.sum()), dims)) * kern.h
+    if rng.random() < 0.5:                                   # some particles exactly on cell faces (map_floor's tie rule)
+        pick = rng.random(n) < 0.2
+        H = kern.H
+        p.Position[pick, 0] = np.round(p.Position[pick, 0] / H) * H + 0.5 * H * rng.choice([1.0, -1.0])
+    if rng.random() < 0.4 and (p.Type == 3).any():
+        p.GroupMarker[p.Type == 3] = 3
+        d = np.zeros(dims); d[int(rng.integers(0, dims))] = 1.0
+        p.geometries = [Geometry(CSVFile="", GroupMarker=3, Type=Moving, Motion=MotionDetails(Velocity=float(rng.uniform(0.5, 3)), StartTime=0.0,
+                                                                                              Duration=float(rng.choice([1e-4, 10.0])), Direction=tuple(d)))]
+    s = dataclasses.replace(s, SimKernel=kern, SimMetaData=meta)
+    return p, s, shape, int(rng.choice([8, 8, 4]))
+
+
+@pytest.mark.parametrize("seed", range(100, 160))
+def test_fuzzed_switches_match_the_oracle(seed):
+    from oracle.oracle import make_oracle
+    from sphexample_amd._abi import ERR_NUMERIC, SphmiError
+    from sphexample_amd.config import SimpleMDBC, StoreKernelOutput
+    from sphexample_amd.engine import make_engine
+    p, s, shape, fb = _case2(seed)
+    mdbc = s.SimMetaData.BMode is SimpleMDBC
+    tol_f = 1e-10 if fb == 8 else 1e-3
+    what = f"{shape} fb{fb} {type(s.SimViscosity).__name__} {type(s.SimDensityDiffusion).__name__} {type(s.SimKernel.kernel).__name__} k{s.SimKernel.k:.2f} " \
+           f"{s.SimMetaData.SMode.__name__} {s.SimMetaData.KMode.__name__} {s.SimMetaData.BMode.__name__} motion={getattr(p, 'geometries', None) is not None}"
+
+    def both():
+        e, o = make_engine(p, s, device_float_bytes=fb), make_oracle(p, s)
+        if getattr(p, "geometries", None) is not None:
+            o.set_motions(p.geometries)
+        return e, o
+    eng, orc = both()
+    d1, a1 = eng.forces_once(apply_mdbc=mdbc); d2, a2 = orc.forces_once(apply_mdbc=mdbc)
+    ie, io = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
+    if fb == 8:
+        np.testing.assert_array_equal(eng.download(("ID",))["ID"], orc.download(("ID",))["ID"], err_msg=what)
+    np.testing.assert_allclose(d1[ie], d2[io], rtol=0, atol=tol_f * max(np.abs(d2).max(), 1e-300), err_msg="drho " + what)
+    np.testing.assert_allclose(a1[ie], a2[io], rtol=0, atol=tol_f * max(np.abs(a2).max(), 1e-300), err_msg="acc " + what)
+    if fb == 4:
+        return                                            # (K steps of a violent cloud in fp32: chaos, not parity)
+    eng, orc = both()
+    prog = []
+    for steps in (2, 3):                                  # two calls: the rebuild that opens the second, the carried reductions
+        po = orc.advance(1e9, max_steps=steps)
+        bad = bool((orc.download(("Density",))["Density"] <= 0).any()) or not np.isfinite(po.last_dt) or not np.isfinite(orc.download(("Position",))["Position"]).all()
+        if bad:
+            with pytest.raises(SphmiError) as ei:
+                eng.advance(1e9, max_steps=steps)
+            assert ei.value.status == ERR_NUMERIC, what
+            return
+        pe = eng.advance(1e9, max_steps=steps)
+        assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter), what
+        assert pe.total_time == pytest.approx(po.total_time, rel=1e-9), what
+    e, o = _by_id(eng.download()), _by_id(orc.download())
+    scale = max(np.abs(o["Position"] - o["Position"].mean(0)).max(), s.SimKernel.h)
+    assert np.abs(e["Density"] - o["Density"]).max() < 1e-8 * np.abs(o["Density"]).max(), what
+    assert np.abs(e["Position"] - o["Position"]).max() < 1e-9 * scale + 1e-15 * np.abs(o["Position"]).max(), what
+    assert np.abs(e["Velocity"] - o["Velocity"]).max() < 1e-8 * max(np.abs(o["Velocity"]).max(), 1e-300), what
+    if s.SimMetaData.KMode is StoreKernelOutput:
+        (k1, g1), (k2, g2) = eng.kernel_output(), orc.kernel_output()
+        i1, i2 = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
+        assert np.abs(k1[i1] - k2[i2]).max() <= 1e-9 * max(np.abs(k2).max(), 1e-300), what
+        assert np.abs(g1[i1] - g2[i2]).max() <= 1e-8 * max(np.abs(g2).max(), 1e-300), what
