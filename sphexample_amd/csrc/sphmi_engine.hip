@@ -1140,12 +1140,8 @@ struct Engine final : EngineBase {
         HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
         dd_ctrl_on = true; dd_a0 = iA; dd_b0 = iB; dd_steps_at_sync = 0; batch_step = -1;
     }
-    void dd_step_control(void* red4_dev) {
-        HC(hipSetDevice(cfg.device));
-        batch_step += 1;
-        hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, (unsigned long long*)red4_dev, ctrl_d, cfg.h, cfg.c0, cfg.CFL);
-        HC(hipGetLastError());
-    }
+    // the slab driver has queued this step's control (k_dd_merge_control on ctrl_d): the coming corrector fills slot set `fill`
+    void dd_control_queued(int fill) { batch_step += 1; rpar = fill; }
     void dd_ctrl_sync(sphmi_dd_control* out) {
         HC(hipSetDevice(cfg.device));
         HC(hipMemcpyAsync(ctrl_h, ctrl_d, sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));

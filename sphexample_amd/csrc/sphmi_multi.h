@@ -67,19 +67,29 @@ __global__ void __launch_bounds__(256) k_dd_count_owned_cells(const int* key, co
     const unsigned long long b = __ballot(head);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
 }
-// M = max(M, T_0, …, T_{n-1}) over four uint64 bit patterns (non-negative floats order like integers)
 struct RedPtrs { const unsigned long long* p[16]; int n; };
-__global__ void k_dd_merge_max(unsigned long long* M, RedPtrs T) {
+// The per-step decisions of a slab (one wave): M = max(M, T_0, …) over four uint64 bit patterns — T_0 this slab's slots after the
+// allreduce (or, between the slabs of one process, every slab's own slots) — then the SAME step_control_decide as the
+// one-device engine on M; M is zeroed when the step consumed it, and `zero_set`, the OTHER of the slab engine's two sets of
+// reduction slots, is zeroed for the corrector of the coming step.  One launch where round 2 had three (take, merge, control):
+// the chain corrector → [allreduce] → control → predictor is the critical path of every step on every GPU.
+template <class T>
+__global__ void k_dd_merge_control(unsigned long long* M, RedPtrs Tp, unsigned long long* zero_set, StepCtrl* cp, double h, double c0, double CFL) {
     const int i = threadIdx.x;
-    if (i >= 4) return;
-    unsigned long long v = M[i];
-    for (int k = 0; k < T.n; ++k) { const unsigned long long u = T.p[k][i]; v = u > v ? u : v; }
-    M[i] = v;
-}
-// the reduction slots of the last corrector → T (slots reset); T is what travels
-__global__ void k_dd_take(unsigned long long* red, unsigned long long* T) {
-    const int i = threadIdx.x;
-    if (i < 4) { T[i] = red[i]; red[i] = 0; }
+    unsigned long long v = 0;
+    if (i < 4) {
+        v = M[i];
+        for (int k = 0; k < Tp.n; ++k) { const unsigned long long u = Tp.p[k][i]; v = u > v ? u : v; }
+    }
+    const unsigned long long r0 = __shfl(v, 0, 64), r1 = __shfl(v, 1, 64), r2 = __shfl(v, 2, 64), r3 = __shfl(v, 3, 64);
+    int consumed = 0;
+    if (i == 0) {
+        StepCtrl c = *cp;
+        consumed = step_control_decide<T>(r0, r1, r2, r3, c, h, c0, CFL) ? 1 : 0;
+        *cp = c;
+    }
+    consumed = __shfl(consumed, 0, 64);
+    if (i < 4) { M[i] = consumed ? 0ull : v; zero_set[i] = 0ull; }
 }
 // both halo lists of a side in one launch: [0, nl) → buf_l, [nl, nl + nr) → buf_r
 template <class T>
@@ -457,7 +467,9 @@ struct MultiEngine final : EngineBase {
         hipEvent_t ev_pack = nullptr, ev_edge = nullptr, ev_red = nullptr, ev_consumed[8] = {};
         bool consumed_valid[8] = {};
         Halo halo[2];
-        unsigned long long *T2 = nullptr, *M = nullptr, *stage = nullptr;   // T2: 2 × 4 travelling slots (step parity), M: merged, stage: peers' T (other devices)
+        // The travelling slots are the slab engine's own two sets of reduction slots (Engine::red_d, alternating by step parity: the
+        // corrector of step n fills one, the control of step n+1 reads it — after the allreduce in place — and zeroes the other).
+        unsigned long long *M = nullptr, *stage = nullptr;   // M: merged maxima not yet consumed by a step, stage: peers' slots (other devices)
         DevBuf cx, flag, pos, idx[4], rec_s[2], rec_r[2], cost;
         int* mm_d = nullptr; int* mm_h = nullptr;
         int64_t* cnt_h = nullptr;
@@ -572,8 +584,8 @@ struct MultiEngine final : EngineBase {
             HC(hipEventCreateWithFlags(&r.ev_edge, hipEventDisableTiming));
             HC(hipEventCreateWithFlags(&r.ev_red, hipEventDisableTiming));
             for (auto& e : r.ev_consumed) HC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HC(hipMalloc(&r.T2, 8 * 8)); HC(hipMalloc(&r.M, 4 * 8)); HC(hipMalloc(&r.stage, 16 * 4 * 8));
-            HC(hipMemset(r.T2, 0, 8 * 8)); HC(hipMemset(r.M, 0, 4 * 8));
+            HC(hipMalloc(&r.M, 4 * 8)); HC(hipMalloc(&r.stage, 16 * 4 * 8));
+            HC(hipMemset(r.M, 0, 4 * 8));
             HC(hipMalloc(&r.mm_d, 2 * 4)); HC(hipHostMalloc(&r.mm_h, 2 * 4)); HC(hipHostMalloc(&r.cnt_h, 8 * 8));
         }
     }
@@ -588,7 +600,7 @@ struct MultiEngine final : EngineBase {
             stage_s.release(); stage_r.release();
             if (red_h) { (void)hipHostFree(red_h); red_h = nullptr; }
             for (DevBuf* b : {&r.cx, &r.flag, &r.pos, &r.idx[0], &r.idx[1], &r.idx[2], &r.idx[3], &r.rec_s[0], &r.rec_s[1], &r.rec_r[0], &r.rec_r[1], &r.cost}) b->release();
-            (void)hipFree(r.T2); (void)hipFree(r.M); (void)hipFree(r.stage); (void)hipFree(r.mm_d); (void)hipHostFree(r.mm_h); (void)hipHostFree(r.cnt_h);
+            (void)hipFree(r.M); (void)hipFree(r.stage); (void)hipFree(r.mm_d); (void)hipHostFree(r.mm_h); (void)hipHostFree(r.cnt_h);
             if (r.ev_pack) { (void)hipEventDestroy(r.ev_pack); (void)hipEventDestroy(r.ev_edge); (void)hipEventDestroy(r.ev_red); }
             for (auto& e : r.ev_consumed) if (e) (void)hipEventDestroy(e);
             r.e.reset();
@@ -759,7 +771,7 @@ struct MultiEngine final : EngineBase {
                            (const int64_t*)pi.data(), groups ? (const uint64_t*)pg.data() : nullptr,
                            ghost_points ? ph.data() : nullptr, mine.data());
         }
-        uploaded = true; have_halo = false; dx_rate = 0.0;
+        uploaded = true; have_halo = false; dx_rate = 0.0; parity = 0;
         if (!rank_mode) perm_ids.assign(ids, ids + N);                   // row history for sphmi_download_permutation
     }
 
@@ -1058,48 +1070,51 @@ struct MultiEngine final : EngineBase {
 
     // local maxima → global maxima → decisions, without leaving the device
     void reductions_and_control() {
-        const int p = parity; parity ^= 1;
+        const int p = parity; parity ^= 1;          // the set of slots the LAST corrector filled; the coming one fills the other
         for (auto& r : R) {
             HC(hipSetDevice(r.device));
             r.e->serve_reschedules();
-            hipLaunchKernelGGL(k_dd_take, dim3(1), dim3(64), 0, r.main, r.e->red_d, r.T2 + 4 * p);
-            HC(hipGetLastError());
-            if (!use_rccl) HC(hipEventRecord(r.ev_red, r.main));
+            if (!use_rccl) HC(hipEventRecord(r.ev_red, r.main));         // behind the last corrector (its edge tiles joined `main`)
         }
-        if (use_rccl) {
+        if (use_rccl && world > 1) {
             Rccl& N = Rccl::get();
             NCX("per-step allreduce", R[0].rank, -1, R[0].comm_red, N.GroupStart());
-            for (auto& r : R) { HC(hipSetDevice(r.device)); NCX("per-step allreduce (4 × uint64, max)", r.rank, -1, r.comm_red, N.AllReduce(r.T2 + 4 * p, r.T2 + 4 * p, 4, ncclUint64, ncclMax, r.comm_red, r.main)); }
+            for (auto& r : R) {
+                HC(hipSetDevice(r.device));
+                unsigned long long* t = r.e->red_d + 4 * p;
+                NCX("per-step allreduce (4 × uint64, max)", r.rank, -1, r.comm_red, N.AllReduce(t, t, 4, ncclUint64, ncclMax, r.comm_red, r.main));
+            }
             NCX("per-step allreduce", R[0].rank, -1, R[0].comm_red, N.GroupEnd());
         }
         if (shm) {
             Rank& r = R[0];
-            HC(hipMemcpyAsync(red_h, r.T2 + 4 * p, 32, hipMemcpyDeviceToHost, r.main));
+            unsigned long long* t = r.e->red_d + 4 * p;
+            HC(hipMemcpyAsync(red_h, t, 32, hipMemcpyDeviceToHost, r.main));
             HC(hipStreamSynchronize(r.main));
             shm->allreduce((int64_t*)red_h, 4, ShmWorld::MAXU);
-            HC(hipMemcpyAsync(r.T2 + 4 * p, red_h, 32, hipMemcpyHostToDevice, r.main));
+            HC(hipMemcpyAsync(t, red_h, 32, hipMemcpyHostToDevice, r.main));
             HC(hipStreamSynchronize(r.main));
         }
         for (auto& r : R) {
             HC(hipSetDevice(r.device));
             RedPtrs P{}; P.n = 0;
-            P.p[P.n++] = r.T2 + 4 * p;
+            P.p[P.n++] = r.e->red_d + 4 * p;
             if (!use_rccl) {
-                // Double-buffered by step parity: rank q overwrites T2[p] again two steps from now, after its own merge of
-                // the NEXT step — which waited for every rank's take of that step, queued behind that rank's merge of this one.
+                // Double-buffered by step parity: slab q's set p is zeroed again by ITS control two steps from now, which waits for
+                // every slab's corrector of the step in between — queued behind that slab's control of this step, the reader.
                 for (auto& o : R) {
                     if (&o == &r) continue;
                     HC(hipStreamWaitEvent(r.main, o.ev_red, 0));
-                    if (o.device == r.device) P.p[P.n++] = o.T2 + 4 * p;
+                    if (o.device == r.device) P.p[P.n++] = o.e->red_d + 4 * p;
                     else {
-                        HC(hipMemcpyAsync(r.stage + 4 * o.rank, o.T2 + 4 * p, 32, hipMemcpyDeviceToDevice, r.main));
+                        HC(hipMemcpyAsync(r.stage + 4 * o.rank, o.e->red_d + 4 * p, 32, hipMemcpyDeviceToDevice, r.main));
                         P.p[P.n++] = r.stage + 4 * o.rank;
                     }
                 }
             }
-            hipLaunchKernelGGL(k_dd_merge_max, dim3(1), dim3(64), 0, r.main, r.M, P);
+            hipLaunchKernelGGL(k_dd_merge_control<T>, dim3(1), dim3(64), 0, r.main, r.M, P, r.e->red_d + 4 * (p ^ 1), r.e->ctrl_d, cfg.h, cfg.c0, cfg.CFL);
             HC(hipGetLastError());
-            r.e->dd_step_control(r.M);
+            r.e->dd_control_queued(p ^ 1);
         }
     }
 
@@ -1147,7 +1162,7 @@ struct MultiEngine final : EngineBase {
             for (size_t q = 0; q < R.size(); ++q) {
                 Rank& r = R[q]; HC(hipSetDevice(r.device));
                 unsigned long long f = 0;
-                HC(hipMemcpy(&f, r.e->red_d + 3, 8, hipMemcpyDeviceToHost));
+                HC(hipMemcpy(&f, r.e->red_cur() + 3, 8, hipMemcpyDeviceToHost));
                 bad[q] = f != 0;
             }
             host_allreduce(bad, 1, OP_MAX);
