@@ -93,6 +93,19 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
 #define SPHMI_PREFETCH 0        // packet 0 of the NEXT neighbour is gathered before the arithmetic of the current one (its registers are free by
                                 // then: the four values taken from packet 0 are the first thing a pair computes); packet 1 follows from the same line
 #endif
+#ifndef SPHMI_PIPE
+#define SPHMI_PIPE 1            // the pair loop is software-pipelined by ONE address: the queue refill (LDS read), the bit walk and the record offset
+                                // of the NEXT neighbour are worked out while the two gathers of the current one are in flight (no further load in
+                                // flight, one more register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links
+#endif
+#ifndef SPHMI_SCAN_PF
+#define SPHMI_SCAN_PF 0         // phase 1 software-pipelined (one wave per tile): bit 0 = the candidate coordinates of the NEXT chunk of a row are
+                                // requested before the current chunk is worked on (3 registers), bit 1 = the index ranges of the NEXT row are
+                                // requested before the current row is scanned (2 registers)
+#endif
+#ifndef SPHMI_SCAN_PF_C
+#define SPHMI_SCAN_PF_C SPHMI_SCAN_PF   // the same switch for the corrector pass (its kernel has fewer registers to spare)
+#endif
 #ifndef SPHMI_SETPRIO
 #define SPHMI_SETPRIO 0         // s_setprio in the pair loop: 1 = raised while the address is formed and the gathers are issued, 2 = raised during the arithmetic
 #endif
@@ -808,8 +821,43 @@ k_neighbor_force(const ForceParams<T> P) {
             if (SPHMI_QFLAG) { more = (qf | cm) != 0u; have = false; } else { more = qn != 0; have = cm != 0; }
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
     };
+    // SPHMI_PIPE: (pv, pjr) = the pair this lane takes NEXT (valid flag, record offset), worked out one iteration early; the state
+    // survives between the bursts of the pair loop like the queue itself
+    constexpr bool kPipe = SPHMI_PIPE != 0 && !kTwoPairs && !kRoleEntries && !kPrefetch && SPHMI_LDS_STAGE == 0;
+    [[maybe_unused]] bool pv = false;
+    [[maybe_unused]] unsigned pjr = 0;
+    auto run_pairs_piped = [&](const int keep, const bool drain) {
+        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+        unsigned qf = qn != 0 ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
+            work_it += 1;
+#ifdef SPHMI_STATS
+            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pv));
+#endif
+            // 1. the gathers of the pair worked out an iteration (or a burst) ago
+            const unsigned jr = pjr;
+            const bool v = pv;
+            V4 n0, n1;
+            if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); }
+            // 2. while they fly: the next pair of this lane — refill when the mask is used up, lowest set bit, record offset
+            unsigned m = cm;
+            if (cm < qf) {
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
+                m = ne.x; raddr = q_next(raddr); qn -= 1;
+                qf = min((unsigned)qn, 1u);
+                cbase = ne.y;
+            }
+            cm = m & (m - 1);
+            pv = m != 0;
+            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // (meaningless without pv: v_ffbl of 0 is all ones)
+            // 3. the arithmetic
+            if (v) pair(jr, n0, n1, plays_i(jr));
+        } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
+    };
     auto run_pairs = [&](const int keep, const bool drain) {
-        if constexpr (kPrefetch) run_pairs_prefetch(keep, drain); else run_pairs_plain(keep, drain);
+        if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);
+        else if constexpr (kPipe) run_pairs_piped(keep, drain);
+        else run_pairs_plain(keep, drain);
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -825,10 +873,10 @@ k_neighbor_force(const ForceParams<T> P) {
     B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
-    auto scan_chunk = [&](const int cb, const int HI) -> unsigned long long {
+    auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
+    auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
         const int c = cb + bperm;
         const bool cv = c < HI;
-        const V4 cpk = P.src0[cv ? c : cb];
         float A0[2], A1[2];
         A0[0] = (float)(cpk.x - ox); A0[1] = (float)(cpk.y - oy); A1[0] = (float)(cpk.z - oz);
         A1[1] = cv ? A0[0] * A0[0] + A0[1] * A0[1] + A1[0] * A1[0] : 1e30f;
@@ -879,12 +927,28 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
     }
+    constexpr int kPfMask = PASS == PASS_CORRECTOR ? (SPHMI_SCAN_PF_C) : (SPHMI_SCAN_PF);
+    constexpr bool kPfChunks = (kPfMask & 1) != 0 && WPT == 1 && SPHMI_LDS_STAGE == 0;
+    constexpr bool kPfRows = (kPfMask & 2) != 0 && WPT == 1 && !kShareRanges;
+    [[maybe_unused]] int lo_n = 0, hi_n = 0;
+    if constexpr (kPfRows) {
+        const int off = row_offset(0);
+        lo_n = valid ? P.cstart[key_a + off - 1] : 0;
+        hi_n = valid ? P.cstart[key_a + off + 2] : 0;
+    }
 #pragma unroll 1
     for (int seg = 0; seg < NSEG; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
         int lo_l, hi_l;
         if constexpr (kShareRanges) { const int2 rg = s_rng[seg * kWave + lane]; lo_l = rg.x; hi_l = rg.y; }
-        else {
+        else if constexpr (kPfRows) {
+            lo_l = lo_n; hi_l = hi_n;
+            if (seg + 1 < NSEG) {
+                const int off = row_offset(seg + 1);
+                lo_n = valid ? P.cstart[key_a + off - 1] : 0;
+                hi_n = valid ? P.cstart[key_a + off + 2] : 0;
+            }
+        } else {
             const int off = row_offset(seg);
             lo_l = valid ? P.cstart[key_a + off - 1] : 0;
             hi_l = valid ? P.cstart[key_a + off + 2] : 0;
@@ -898,8 +962,15 @@ k_neighbor_force(const ForceParams<T> P) {
             else first = (wv + WPT - seg % WPT) % WPT;
             g0 = (g0 + (HI > LO ? (HI - LO + kWave - 1) / kWave : 0)) & (WPT - 1);
         }
+        [[maybe_unused]] V4 pre;
+        if constexpr (kPfChunks) { if (LO < HI) pre = chunk_packet(LO, HI); }
 #pragma unroll 1
         for (int cb = LO + first * kWave; cb < HI; cb += kWave * WPT) {
+            V4 cpk;
+            if constexpr (kPfChunks) {
+                cpk = pre;
+                if (cb + kWave < HI) pre = chunk_packet(cb + kWave, HI);
+            }
             // A tile of a sparse region (spray, a thin sheet) spans many cells: the union range of a row is then
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
@@ -909,7 +980,8 @@ k_neighbor_force(const ForceParams<T> P) {
             const bool split_row = kRoleEntries && ddt != kDdtNone && seg == NSEG / 2;
             const int need = split_row ? 4 : 2;
             if (__builtin_amdgcn_ballot_w64(qn > QCAP - need) != 0) run_pairs(min(QCAP - 1 - SPHMI_QUEUE_SLACK, QCAP - need), false);
-            unsigned long long m = scan_chunk(cb, HI);
+            if constexpr (!kPfChunks) cpk = chunk_packet(cb, HI);
+            unsigned long long m = scan_chunk(cb, HI, cpk);
             work_ch += 1;
 #ifdef SPHMI_STATS
             st_chunks += 1;
