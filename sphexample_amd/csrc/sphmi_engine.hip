@@ -34,6 +34,44 @@ struct EngineError : std::runtime_error {
 
 static thread_local std::string g_create_error;
 
+// Copies between device memory and PAGEABLE host memory — the caller's arrays, std::vector storage, stack variables — go
+// through a page-locked bounce buffer that belongs to the engine.  Handed a pageable pointer, the runtime page-locks the
+// caller's pages itself and remembers such pins by address; when the C library trims its heap and later hands the same
+// addresses out again (or an array is unmapped and a new one lands on the same range) the next transfer into them runs on
+// the stale mapping and the process dies with "Memory access fault by GPU … Write access to a read-only page" — seen about
+// once per two runs of the GPU test suite (≈2 000 handle life cycles, host arrays allocated and freed all the time), in a
+// download or an upload that had nothing wrong with it.  Memory the CALLER page-locked (sphmi_host_register) is copied
+// directly, and so is everything the engine allocates with hipHostMalloc.
+struct HostBounce {
+    static constexpr size_t kBytes = size_t(16) << 20;
+    char* p = nullptr;
+    HostBounce() = default;
+    HostBounce(const HostBounce&) = delete;
+    HostBounce& operator=(const HostBounce&) = delete;
+    ~HostBounce() { if (p) (void)hipHostFree(p); }
+    void ensure() { if (!p) HC(hipHostMalloc((void**)&p, kBytes)); }
+    // device → pageable host; the data are in `dst` on return (the stream has been synchronised)
+    void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
+        ensure();
+        for (size_t off = 0; off < bytes; off += kBytes) {
+            const size_t n = std::min(kBytes, bytes - off);
+            HC(hipMemcpyAsync(p, (const char*)src + off, n, hipMemcpyDeviceToHost, s));
+            HC(hipStreamSynchronize(s));
+            memcpy((char*)dst + off, p, n);
+        }
+    }
+    // pageable host → device; `src` may be reused on return (the stream has been synchronised)
+    void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+        ensure();
+        for (size_t off = 0; off < bytes; off += kBytes) {
+            const size_t n = std::min(kBytes, bytes - off);
+            memcpy(p, (const char*)src + off, n);
+            HC(hipMemcpyAsync((char*)dst + off, p, n, hipMemcpyHostToDevice, s));
+            HC(hipStreamSynchronize(s));
+        }
+    }
+};
+
 // Phase labels follow the reference's TimerOutputs sections (src/SPHCellList.jl:748-800).
 enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT, PH_PASS1_EDGE, PH_PASS2_EDGE };
 static const char* kPhaseNames[PH_COUNT] = {
@@ -126,6 +164,20 @@ struct Engine final : EngineBase {
     // nobody would take the decisions)
     bool fused_control() const { return fuse_ctrl && cfg.mdbc == SPHMI_MDBC_NONE && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0; }
     bool batch_fused = false;
+    // Accept masks handed from the predictor to the corrector of a step (ForceParams::mstore): plain handles whose launches run one
+    // wave per tile with the compiled-in model, 3-D, fp32.  max |v|² of the state travels in red_d[14 + rpar] (same parity
+    // as the reduction slots; a slot that was not zeroed in between only makes the skin wider).
+    int mask_store = 1;                // $SPHMI_MASK_STORE=0 switches it off
+    int mask_cap = 48;                 // chunks per tile kept ($SPHMI_MASK_CAP; a 3-D tile scans 27 on average, 45 at most in a filled lattice)
+    unsigned long long* mstore_d = nullptr; size_t mstore_tiles = 0;
+    bool mask_possible() const {
+        if (!(mask_store && D == 3 && sizeof(T) == 4 && cfg.mdbc == SPHMI_MDBC_NONE && motions.n == 0 && !dd_slab)) return false;
+        const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
+                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h && cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 &&
+                          cfg.kernel_output == SPHMI_KOUT_NONE && cfg.alpha != 0.0;
+        return dflt;
+    }
+    unsigned long long* vmx_slot(int par) const { return red_d + 14 + par; }
     static constexpr int kBatch = 16;  // most steps queued between two looks at the control flags
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
@@ -211,6 +263,8 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&ctrl_d, 2 * sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
         HC(hipMemset(ctrl_d, 0, 2 * sizeof(StepCtrl)));
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
+        if (const char* w = getenv("SPHMI_MASK_STORE")) mask_store = atoi(w);
+        if (const char* w = getenv("SPHMI_MASK_CAP")) mask_cap = std::max(1, atoi(w));
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 8 * 8));
@@ -253,7 +307,7 @@ struct Engine final : EngineBase {
         }
 #endif
         (void)hipFree(ctrl_d); (void)hipHostFree(ctrl_h);
-        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
+        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d); (void)hipFree(mstore_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
         (void)hipFree(cellx_d); (void)hipFree(uc_tsum);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -635,6 +689,19 @@ struct Engine final : EngineBase {
         if (resched0_pending) { resched0_pending = false; reschedule_from_work(0); }
         if (resched1_pending) { resched1_pending = false; reschedule_from_work(1); }
     }
+    bool masks_ready() {
+        if (!mask_possible()) return false;
+        const int ntile = list_tiles[0];
+        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptTiny ? 8 : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1)));
+        if (wpt != 1) return false;
+        const size_t tiles = (size_t)((N + kWave - 1) / kWave);
+        if (tiles > mstore_tiles) {
+            (void)hipFree(mstore_d); mstore_d = nullptr; mstore_tiles = 0;
+            if (hipMalloc(&mstore_d, tiles * (size_t)mask_cap * kWave * 8) != hipSuccess) { (void)hipGetLastError(); mask_store = 0; return false; }
+            mstore_tiles = tiles;
+        }
+        return true;
+    }
     void enqueue_step() {
         serve_reschedules();
         const bool fused = batch_fused;
@@ -646,11 +713,14 @@ struct Engine final : EngineBase {
         progress_motion(0.0, ctrl_cur());                                      // :765
         if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());                // :772
         ForceParams<T> P1 = force_params(iA, iA, iH, 0.0);
+        const bool masks = fused && masks_ready();
         if (fused) {
             // the predictor takes the decisions: reads control block / slots `cpar` / `rpar`, leaves the other ones to the corrector
             P1.ctl_in = ctrl_d + cpar; P1.ctl_out = ctrl_d + (cpar ^ 1);
             P1.red_in = red_d + 4 * rpar; P1.red_zero = red_d + 4 * (rpar ^ 1);
             P1.ctl_h = cfg.h; P1.ctl_c0 = cfg.c0; P1.ctl_CFL = cfg.CFL;
+            if (masks) { P1.mstore = mstore_d; P1.mask_cap = mask_cap; P1.vmx_in = vmx_slot(rpar); }
+            if (mask_possible()) P1.vmx_zero = vmx_slot(rpar ^ 1);
             cpar ^= 1; rpar ^= 1;
         } else P1.ctrl = ctrl_cur();
         Ev e1 = begin_phase(PH_PASS1);
@@ -658,6 +728,8 @@ struct Engine final : EngineBase {
         end_phase(e1);
         progress_motion(0.0, ctrl_cur());                                      // :787
         ForceParams<T> P2 = force_params(iH, iA, iB, 0.0); P2.ctrl = ctrl_cur();      // (force_params: P2.red = the current slots)
+        if (masks) { P2.mstore = mstore_d; P2.mask_cap = mask_cap; }
+        if (mask_possible()) P2.vmx = vmx_slot(rpar);
         Ev e2 = begin_phase(PH_PASS2);
         launch_force<PASS_CORRECTOR>(P2);                                      // :789-798
         end_phase(e2);
@@ -773,15 +845,15 @@ struct Engine final : EngineBase {
         const size_t n = (size_t)N;
         std::vector<V4> hrec(2 * n);                                     // the two packets of a particle side by side
         for (size_t i = 0; i < n; ++i) { hrec[2 * i] = h0[i]; hrec[2 * i + 1] = h1[i]; }
-        HC(hipMemcpyAsync(rec[iA], hrec.data(), 2 * n * sizeof(V4), hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(acc[cur], ha.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(ghost[cur], hg.data(), n * sizeof(V4), hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(type[cur], ty, n, hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(id[cur], ids, n * 8, hipMemcpyHostToDevice, stream));
-        if (groups) HC(hipMemcpyAsync(grp[cur], groups, n * 8, hipMemcpyHostToDevice, stream));
+        bounce.h2d(rec[iA], hrec.data(), 2 * n * sizeof(V4), stream);
+        bounce.h2d(acc[cur], ha.data(), n * sizeof(V4), stream);
+        bounce.h2d(ghost[cur], hg.data(), n * sizeof(V4), stream);
+        bounce.h2d(type[cur], ty, n, stream);
+        bounce.h2d(id[cur], ids, n * 8, stream);
+        if (groups) bounce.h2d(grp[cur], groups, n * 8, stream);
         else HC(hipMemsetAsync(grp[cur], 0, n * 8, stream));
         HC(hipMemsetAsync(key[cur], 0, n * 4, stream));
-        HC(hipMemsetAsync(red_d, 0, 8 * 8, stream));
+        HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); HC(hipMemsetAsync(red_d + 14, 0, 2 * 8, stream));
         cpar = 0; rpar = 0;
         const int nb256 = (N + 255) / 256;
         hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
@@ -789,7 +861,7 @@ struct Engine final : EngineBase {
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
                            (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
         hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N,
-                           (T)cfg.h, (T)cfg.eta2, red_d);
+                           (T)cfg.h, (T)cfg.eta2, red_d, red_d + 14);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream));
         uploaded = true; stepped = false; have_grid = false; index_counter = 0;
@@ -829,8 +901,7 @@ struct Engine final : EngineBase {
                 hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, tot_d + 1);
                 hipLaunchKernelGGL(k_scan_add_nototal, dim3(ntiles), dim3(kScanThreads), 0, stream, pos, (int)M, (const int*)tsum);
                 int tot[2] = {0, 0};
-                HC(hipMemcpyAsync(tot, tot_d, 8, hipMemcpyDeviceToHost, stream));
-                HC(hipStreamSynchronize(stream));
+                bounce.d2h(tot, tot_d, 8, stream);
                 if ((long long)base + tot[1] + nf > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: n_particles of the handle is smaller than the lattice (sphmi_dam_break_3d_count)");
                 hipLaunchKernelGGL(k_gen_boundary<T>, dim3(nbM), dim3(256), 0, stream, G, M, (const int*)flag, (const int*)pos, base, pk0[iA], pk1[iA],
                                    type[cur], id[cur], grp[cur]);
@@ -842,11 +913,11 @@ struct Engine final : EngineBase {
             hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur]);
             const size_t n = (size_t)N;
             HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
-            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); cpar = 0; rpar = 0;
+            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); HC(hipMemsetAsync(red_d + 14, 0, 2 * 8, stream)); cpar = 0; rpar = 0;
             const int nb256 = (N + 255) / 256;
             hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
             hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
-            hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d);
+            hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d, red_d + 14);
             HC(hipGetLastError());
             HC(hipStreamSynchronize(stream));
         } catch (...) { release(); throw; }
@@ -864,6 +935,7 @@ struct Engine final : EngineBase {
     // ---- output side: device-packed fields, one copy per field ----------------------------------
     char* out_arena = nullptr; size_t out_arena_bytes = 0;
     std::vector<std::pair<void*, size_t>> host_pinned;
+    HostBounce bounce;          // every copy to or from pageable host memory goes through it
     // Page-locking is the CALLER's decision (sphmi_host_register): only the caller knows that an array outlives the
     // handle's use of it — a registration that survived a free + reuse of the address range would be a stale mapping.
     void host_register(void* p, size_t bytes) override {
@@ -881,6 +953,7 @@ struct Engine final : EngineBase {
         }
     }
     hipStream_t copy_stream = nullptr; hipEvent_t ev_packed = nullptr; bool download_pending = false;
+    bool dl_dst_page_locked = false;               // slab engines: the multi-device handle downloads into its own page-locked staging
     unsigned long long* dl_tags_host = nullptr;    // slab engines: the order tags travel with a download (the multi-device handle merges by them)
     int out_comp = 0;          // components per output vector: D, or 3 (sphmi_set_output_components)
     void set_output_components(int c) override {
@@ -893,7 +966,7 @@ struct Engine final : EngineBase {
     void download_begin_as(void* position, void* velocity, void* acceleration, void* density, void* pressure,
                            int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) {
         if (!copy_stream) { HC(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)); HC(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming)); }
-        if (download_pending) { HC(hipStreamSynchronize(copy_stream)); download_pending = false; }
+        if (download_pending) download_end();
         const size_t n = (size_t)N, nd = n * (size_t)out_comp, ncell_d = n * (size_t)D;
         const size_t need = (4 * nd + 2 * n) * sizeof(H) + ncell_d * 8 + n * 25 + 256 * 13;
         if (need > out_arena_bytes) {
@@ -924,9 +997,13 @@ struct Engine final : EngineBase {
         if (a_tag) HC(hipMemcpyAsync(a_tag, otag[cur], n * 8, hipMemcpyDeviceToDevice, stream));
         HC(hipEventRecord(ev_packed, stream));
         HC(hipStreamWaitEvent(copy_stream, ev_packed, 0));
+        // arrays the caller page-locked (sphmi_host_register) are written by the copy engine while the caller advances; any
+        // other array is filled from the snapshot in download_end, through the bounce buffer (HostBounce, above)
+        out_deferred.clear();
         auto copy = [&](void* dst, const void* src, size_t bytes) {
-            if (!dst) return;
-            HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, copy_stream));
+            if (!dst || !bytes) return;
+            if (dl_dst_page_locked || is_registered(dst, bytes)) HC(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, copy_stream));
+            else out_deferred.push_back({dst, src, bytes});
         };
         copy(position, o.pos, nd * sizeof(H)); copy(velocity, o.vel, nd * sizeof(H));
         copy(acceleration, o.acc, nd * sizeof(H)); copy(density, o.rho, n * sizeof(H));
@@ -935,6 +1012,12 @@ struct Engine final : EngineBase {
         copy(ids, a_id, n * 8); copy(ty, a_ty, n); copy(groups, a_grp, n * 8);
         if (a_tag) copy(dl_tags_host, a_tag, n * 8);
         download_pending = true;
+    }
+    struct Deferred { void* dst; const void* src; size_t bytes; };
+    std::vector<Deferred> out_deferred;
+    bool is_registered(const void* q, size_t bytes) const {
+        for (auto& e : host_pinned) if ((const char*)q >= (const char*)e.first && (const char*)q + bytes <= (const char*)e.first + e.second) return true;
+        return false;
     }
     void download_begin(void* position, void* velocity, void* acceleration, void* density, void* pressure,
                         int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
@@ -948,6 +1031,8 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(cfg.device));
         HC(hipStreamSynchronize(copy_stream));
         download_pending = false;
+        for (const Deferred& d : out_deferred) bounce.d2h(d.dst, d.src, d.bytes, copy_stream);
+        out_deferred.clear();
     }
     void download(void* position, void* velocity, void* acceleration, void* density, void* pressure,
                   int64_t* ids, uint8_t* ty, uint64_t* groups, void* ghost_points, int64_t* cells) override {
@@ -960,7 +1045,7 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(cfg.device));
         HC(hipStreamSynchronize(stream));
         std::vector<V4> tmp(N);
-        HC(hipMemcpy(tmp.data(), kout_d, (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        bounce.d2h(tmp.data(), kout_d, (size_t)N * sizeof(V4), stream);
         const bool h8 = cfg.host_float_bytes == 8;
         if (kernel_gradient) { if (h8) unpack3(tmp, (double*)kernel_gradient, N, D); else unpack3(tmp, (float*)kernel_gradient, N, D); }
         if (kernel) for (int i = 0; i < N; ++i) { if (h8) ((double*)kernel)[i] = (double)tmp[i].w; else ((float*)kernel)[i] = (float)tmp[i].w; }
@@ -973,7 +1058,7 @@ struct Engine final : EngineBase {
         if (!prev_row) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_download_permutation: null array");
         HC(hipSetDevice(cfg.device));
         std::vector<int> tmp((size_t)N);
-        HC(hipMemcpyAsync(tmp.data(), prow[cur], (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        bounce.d2h(tmp.data(), prow[cur], (size_t)N * 4, stream);
         hipLaunchKernelGGL(k_iota, dim3((N + 255) / 256), dim3(256), 0, stream, prow[cur], N);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream));
@@ -1005,7 +1090,7 @@ struct Engine final : EngineBase {
         forces_local(apply_mdbc, false);
         sync_and_collect();
         std::vector<V4> tmp(N);
-        HC(hipMemcpy(tmp.data(), rec[iB], (size_t)N * sizeof(V4), hipMemcpyDeviceToHost));
+        bounce.d2h(tmp.data(), rec[iB], (size_t)N * sizeof(V4), stream);
         const bool h8 = cfg.host_float_bytes == 8;
         if (acceleration) { if (h8) unpack3(tmp, (double*)acceleration, N, D); else unpack3(tmp, (float*)acceleration, N, D); }
         if (drhodt) for (int i = 0; i < N; ++i) { if (h8) ((double*)drhodt)[i] = (double)tmp[i].w; else ((float*)drhodt)[i] = (float)tmp[i].w; }
@@ -1035,10 +1120,8 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&od, (size_t)nu * D * 8));
         hipLaunchKernelGGL(k_cells_out, dim3(nb256), dim3(256), 0, stream, (const int*)key[cur], (const int*)flag, (const int*)pos, N, grid, D, od);
         hipError_t e1 = hipGetLastError();
-        hipError_t e2 = hipMemcpyAsync(out, od, (size_t)nu * D * 8, hipMemcpyDeviceToHost, stream);
-        hipError_t e3 = hipStreamSynchronize(stream);
+        try { HC(e1); bounce.d2h(out, od, (size_t)nu * D * 8, stream); } catch (...) { (void)hipStreamSynchronize(stream); (void)hipFree(od); throw; }
         (void)hipFree(od);
-        HC(e1); HC(e2); HC(e3);
     }
     int* uc_tsum = nullptr; int uc_tsum_n = 0;
     int* tile_tsum_u(int ntiles) {
@@ -1060,8 +1143,7 @@ struct Engine final : EngineBase {
         for (int k = 0; k < 2; ++k) if (!otag[k]) HC(hipMalloc(&otag[k], (size_t)cap * 8));
         std::vector<unsigned long long> t((size_t)n);
         for (int64_t i = 0; i < n; ++i) t[i] = upload_index ? (unsigned long long)upload_index[i] : (unsigned long long)i;
-        HC(hipMemcpyAsync(otag[cur], t.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
-        HC(hipStreamSynchronize(stream));
+        bounce.h2d(otag[cur], t.data(), (size_t)n * 8, stream);
     }
     // ProgressMotion of the queued step (src/SPHCellList.jl:765,787) on owned particles AND ghost copies — a prescribed
     // motion is the same function of time on every rank — before the halo of the pass is packed
@@ -1123,7 +1205,7 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(cfg.device));
         rebuild();
         int live = 0;
-        HC(hipMemcpyAsync(&live, cstart + grid.ncell, 4, hipMemcpyDeviceToHost, stream));
+        bounce.d2h(&live, cstart + grid.ncell, 4, stream);
         sync_and_collect();
         if (live < N) index_counter -= 1;      // the graveyard is not a cell
         N = live;

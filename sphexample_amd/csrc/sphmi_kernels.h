@@ -69,8 +69,12 @@ constexpr int kWave = 64;
 // 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
 // The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
 // Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues.
+#ifndef SPHMI_QUEUE_C
+#define SPHMI_QUEUE_C SPHMI_QUEUE   // the same for the corrector pass alone
+#endif
 template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
-    return SPHMI_QUEUE > 0 ? SPHMI_QUEUE : (WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12));
+    constexpr int q = PASS == 2 ? (SPHMI_QUEUE_C) : (SPHMI_QUEUE);
+    return q > 0 ? q : (WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12));
 }
 
 // Round-3 switches of the pair loop (defaults = what was measured best; 0 restores the round-2 code for the ablation runs)
@@ -97,6 +101,15 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
 #define SPHMI_PIPE 1            // the pair loop is software-pipelined by ONE address: the queue refill (LDS read), the bit walk and the record offset
                                 // of the NEXT neighbour are worked out while the two gathers of the current one are in flight (no further load in
                                 // flight, one more register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links
+#endif
+#ifndef SPHMI_DEEP
+#define SPHMI_DEEP 0            // bit 0: predictor, bit 1: corrector — TWO neighbours in flight per lane: the gathers of the next pair are issued before the
+                                // arithmetic of the current one, into a second set of eight registers (the predictor has them to spare: LDS, not
+                                // registers, sets its six waves per SIMD).  Idle lanes pair their target with itself (every term exactly zero), so
+                                // neither the gathers nor the arithmetic sit under an execution mask and the wait is vmcnt(2)
+#endif
+#ifndef SPHMI_MASK_STORE
+#define SPHMI_MASK_STORE 1      // the kernels can hand the predictor's accept masks to the corrector (ForceParams::mstore; the engine decides per handle)
 #endif
 #ifndef SPHMI_SCAN_PF
 #define SPHMI_SCAN_PF 0         // phase 1 software-pipelined (one wave per tile): bit 0 = the candidate coordinates of the NEXT chunk of a row are
@@ -208,6 +221,16 @@ struct ForceParams {
     const StepCtrl* ctl_in; StepCtrl* ctl_out;
     const unsigned long long* red_in; unsigned long long* red_zero;
     double ctl_h, ctl_c0, ctl_CFL;
+    // Accept masks handed from the predictor to the corrector of the SAME step (plain handles, one wave per tile, 3-D fp32
+    // compiled-in model): the predictor tests against H + vmax·Δt — no pair can come closer than that within the half step —
+    // and stores the trimmed 64-bit mask of every chunk it scans, [tile][chunk][lane]; the corrector replays the chunk
+    // sequence (same cell list, same ranges) and LOADS the masks instead of running phase 1 (matrix cores + 64 sign
+    // extractions + trimming: ≈100 of its ≈119 vector instructions per chunk).  Chunks beyond mask_cap are scanned as before.
+    unsigned long long* mstore;            // null: off
+    int mask_cap;                          // chunks per tile kept
+    const unsigned long long* vmx_in;      // predictor: max |v|² of the state it reads (bit pattern; filled by the previous corrector / the upload)
+    unsigned long long* vmx_zero;          // predictor, block 0: the slot this step's corrector fills
+    unsigned long long* vmx;               // corrector: max |v|² of the state it writes
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (of its slowest wave × WPT), or null
@@ -407,13 +430,15 @@ k_neighbor_force(const ForceParams<T> P) {
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
 #endif
     T step_dt, step_dt2;
+    [[maybe_unused]] unsigned long long vmax2_bits = 0;
     if (PASS == PASS_PREDICTOR && P.ctl_in != nullptr) {
         StepCtrl c = *P.ctl_in;
         const unsigned long long r0 = P.red_in[0], r1 = P.red_in[1], r2 = P.red_in[2], r3 = P.red_in[3];
         const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, P.ctl_h, P.ctl_c0, P.ctl_CFL);
+        if (P.mstore) vmax2_bits = *P.vmx_in;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             *P.ctl_out = c;
-            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; }
+            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; if (P.vmx_zero) *P.vmx_zero = 0; }
         }
         if (!c.active) return;
         step_dt = (T)c.dt; step_dt2 = (T)c.dt2;
@@ -427,6 +452,7 @@ k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = queue_entries<T, PASS, WPT>();         // per-lane queue of non-empty accept masks
+    constexpr bool kMaskIO = SPHMI_MASK_STORE != 0 && WPT == 1 && D == 3 && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY && SPHMI_LDS_STAGE == 0;
     static_assert(QCAP >= 4 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[SPHMI_LDS_STAGE ? 1 : WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
@@ -511,7 +537,16 @@ k_neighbor_force(const ForceParams<T> P) {
     const float tt = txl * txl + tyl * tyl + tzl * tzl;
     float thr;
     {
-        const float H2f = (float)P.H2;
+        float H2f = (float)P.H2;
+        if constexpr (kMaskIO && PASS == PASS_PREDICTOR) {
+            if (P.mstore) {
+                // the corrector meets the same pairs at xₙ⁺ = xₙ + vₙ·Δt/2·ML: two particles approach by at most 2·vmax·Δt/2 meanwhile
+                // (vmax over the whole state, rounded up)
+                const float vmax = fast_sqrt(__uint_as_float((unsigned)vmax2_bits)) * 1.00001f;
+                const float Hs = fast_sqrt(H2f) * 1.000001f + vmax * (float)step_dt * 1.00001f;
+                H2f = Hs * Hs;
+            }
+        }
         const float Rm = fast_sqrt(wave_max(valid ? tt : 0.0f)) + 6.0f * (float)P.h;
         const float eps = 1e-5f + 1e-6f * (Rm * Rm) / H2f;
         thr = owned ? H2f * (1.0f + eps) - tt : -1e30f;
@@ -854,8 +889,48 @@ k_neighbor_force(const ForceParams<T> P) {
             if (v) pair(jr, n0, n1, plays_i(jr));
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
+    constexpr bool kDeep = ((SPHMI_DEEP >> (PASS == PASS_CORRECTOR ? 1 : 0)) & 1) != 0 && kPipe && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY;
+    auto run_pairs_deep = [&](const int keep, const bool drain) {
+        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+        unsigned qf = qn != 0 ? 1u : 0u;
+        // the next pair of this lane: refill when the mask is used up, lowest set bit, record offset
+        auto advance = [&]() {
+            unsigned m = cm;
+            if (cm < qf) {
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
+                m = ne.x; raddr = q_next(raddr); qn -= 1;
+                qf = min((unsigned)qn, 1u);
+                cbase = ne.y;
+            }
+            cm = m & (m - 1);
+            pv = m != 0;
+            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
+        };
+        auto more = [&]() { return __builtin_amdgcn_ballot_w64(drain ? pv : (qn > keep)) != 0; };
+        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) == 0) return;
+        if (!pv) advance();                                  // lanes that had nothing when the last burst ended may have been pushed entries since
+        unsigned fjr, gjr; V4 f0, f1, g0, g1;
+        // (a lane without a pair takes its own record: xᵢⱼ = 0, vᵢⱼ = 0 — every term of the compiled-in model is exactly zero)
+        fjr = pv ? pjr : self_r; f0 = gather_packet(rs0, fjr, 0, T()); f1 = gather_packet(rs0, fjr, 1, T());
+        advance();
+        for (;;) {
+            work_it += 1;
+            if (more()) {
+                gjr = pv ? pjr : self_r; g0 = gather_packet(rs0, gjr, 0, T()); g1 = gather_packet(rs0, gjr, 1, T());
+                advance();
+                pair(fjr, f0, f1, plays_i(fjr));
+            } else { pair(fjr, f0, f1, plays_i(fjr)); break; }
+            work_it += 1;
+            if (more()) {
+                fjr = pv ? pjr : self_r; f0 = gather_packet(rs0, fjr, 0, T()); f1 = gather_packet(rs0, fjr, 1, T());
+                advance();
+                pair(gjr, g0, g1, plays_i(gjr));
+            } else { pair(gjr, g0, g1, plays_i(gjr)); break; }
+        }
+    };
     auto run_pairs = [&](const int keep, const bool drain) {
-        if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);
+        if constexpr (kDeep) run_pairs_deep(keep, drain);
+        else if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);
         else if constexpr (kPipe) run_pairs_piped(keep, drain);
         else run_pairs_plain(keep, drain);
     };
@@ -927,6 +1002,11 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
     }
+    // masks handed from the predictor to the corrector: this tile's rows of [chunk][lane] words, and the running chunk number
+    [[maybe_unused]] unsigned long long* mrow = nullptr;
+    [[maybe_unused]] int ci = 0;
+    // (the tile number is wave-uniform: the row address stays in scalar registers, a lane adds 8·lane)
+    if constexpr (kMaskIO) { if (P.mstore) mrow = P.mstore + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)P.mask_cap * kWave; }
     constexpr int kPfMask = PASS == PASS_CORRECTOR ? (SPHMI_SCAN_PF_C) : (SPHMI_SCAN_PF);
     constexpr bool kPfChunks = (kPfMask & 1) != 0 && WPT == 1 && SPHMI_LDS_STAGE == 0;
     constexpr bool kPfRows = (kPfMask & 2) != 0 && WPT == 1 && !kShareRanges;
@@ -980,18 +1060,30 @@ k_neighbor_force(const ForceParams<T> P) {
             const bool split_row = kRoleEntries && ddt != kDdtNone && seg == NSEG / 2;
             const int need = split_row ? 4 : 2;
             if (__builtin_amdgcn_ballot_w64(qn > QCAP - need) != 0) run_pairs(min(QCAP - 1 - SPHMI_QUEUE_SLACK, QCAP - need), false);
-            if constexpr (!kPfChunks) cpk = chunk_packet(cb, HI);
-            unsigned long long m = scan_chunk(cb, HI, cpk);
+            unsigned long long m = 0ull;
+            bool handed = false;                                    // (wave-uniform)
+            if constexpr (kMaskIO && PASS == PASS_CORRECTOR) {
+                // the predictor of this step has scanned this very chunk (same list, same ranges, same skips) against H + vmax·Δt
+                if (mrow != nullptr && ci < P.mask_cap) { m = mrow[(size_t)ci * kWave + lane]; handed = true; }
+            }
+            if (!handed) {
+                if constexpr (!kPfChunks) cpk = chunk_packet(cb, HI);
+                m = scan_chunk(cb, HI, cpk);
+                // keep only the candidates of MY three cells of this row (the reference's stale cell list,
+                // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
+                const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
+                const int w = b1 - b0;
+                const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
+                m = (w > 0) ? (m & rm) : 0ull;
+                if constexpr (kMaskIO && PASS == PASS_PREDICTOR) {
+                    if (mrow != nullptr && ci < P.mask_cap) mrow[(size_t)ci * kWave + lane] = m;
+                }
+            }
+            ci += 1;
             work_ch += 1;
 #ifdef SPHMI_STATS
             st_chunks += 1;
 #endif
-            // keep only the candidates of MY three cells of this row (the reference's stale cell list,
-            // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
-            const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
-            const int w = b1 - b0;
-            const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
-            m = (w > 0) ? (m & rm) : 0ull;
 #if SPHMI_LDS_STAGE
             {
                 // Chunk-synchronous LDS staging (the design BASELINE config 3 names; DESIGN.md §4.4 and profiles/r03_lds_stage_ablation.md
@@ -1047,7 +1139,8 @@ k_neighbor_force(const ForceParams<T> P) {
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
-    int tile_work = 9 * work_it + 16 * work_ch + 16;
+    // (with the corrector's masks handed over a chunk costs the two passes ≈ 475 + 120 cycles: 10 per pass)
+    int tile_work = 9 * work_it + ((kMaskIO && P.mstore) ? 10 : 16) * work_ch + 16;
     if (P.xcd_clock && lane == 0 && wv == 0) {
         // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
         // shares of the estimated cost towards equal finishing times at the next rebuild.
@@ -1175,6 +1268,12 @@ k_neighbor_force(const ForceParams<T> P) {
         // every lane holds the three maxima: lanes 0, 1, 2 serve one slot each — ONE pre-test load and ONE atomic instruction
         // per wave instead of three dependent round trips to the coherence point (a device-scope load is served beyond the
         // XCD's L2; the epilogue of a lone wave: 5.3 → 4.1 µs, tools/trace_small.py)
+        if (P.vmx != nullptr) {
+            // max |v|² of the new state (particles that move): the skin of the next predictor's accept masks (ForceParams::mstore)
+            T v2 = owned ? (o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * ml : T(0);
+            v2 = wave_max(v2);
+            if (lane < 4) atomic_max_bits(lane < 3 ? &P.red[lane] : P.vmx, lane == 0 ? disp2 : (lane == 1 ? vis : (lane == 2 ? a2 : v2)));
+        } else
         if (lane < 3) atomic_max_bits(&P.red[lane], lane == 0 ? disp2 : (lane == 1 ? vis : a2));
     }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)

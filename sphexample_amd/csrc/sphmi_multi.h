@@ -548,10 +548,11 @@ struct MultiEngine final : EngineBase {
                     void* d = nullptr;
                     HC(hipMalloc(&d, sizeof id2));
                     try {
-                        HC(hipMemcpy(d, &id2, sizeof id2, hipMemcpyHostToDevice));
+                        HostBounce hb;                       // (the slab engines do not exist yet)
+                        hb.h2d(d, &id2, sizeof id2, nullptr);
                         NCX("ncclAllReduce (handing the second communicator's id round)", my_rank, -1, R[0].comm, N.AllReduce(d, d, sizeof id2, ncclUint8, ncclSum, R[0].comm, nullptr));
                         HC(hipStreamSynchronize(nullptr));
-                        HC(hipMemcpy(&id2, d, sizeof id2, hipMemcpyDeviceToHost));
+                        hb.d2h(&id2, d, sizeof id2, nullptr);
                     } catch (...) { (void)hipFree(d); throw; }
                     (void)hipFree(d);
                     NCX("ncclCommInitRank (allreduce communicator)", my_rank, -1, nullptr, N.CommInitRank(&R[0].comm_red, world, id2, my_rank));
@@ -626,10 +627,9 @@ struct MultiEngine final : EngineBase {
         Rank& r = R[0];
         HC(hipSetDevice(r.device));
         void* d = r.cost.need((size_t)n * 8);
-        HC(hipMemcpyAsync(d, v.data(), (size_t)n * 8, hipMemcpyHostToDevice, r.main));
+        r.e->bounce.h2d(d, v.data(), (size_t)n * 8, r.main);
         NCX("ncclAllReduce (rebuild-time host scalars)", r.rank, -1, r.comm_red, Rccl::get().AllReduce(d, d, (size_t)n, ncclInt64, op == OP_SUM ? ncclSum : ncclMax, r.comm_red, r.main));
-        HC(hipMemcpyAsync(v.data(), d, (size_t)n * 8, hipMemcpyDeviceToHost, r.main));
-        HC(hipStreamSynchronize(r.main));
+        r.e->bounce.d2h(v.data(), d, (size_t)n * 8, r.main);
     }
     // every local rank tells its neighbours one number per side; returns what the neighbours told it
     void host_neighbour_counts(const std::vector<long long>& to_l, const std::vector<long long>& to_r,
@@ -847,8 +847,7 @@ struct MultiEngine final : EngineBase {
                 unsigned long long* cd = (unsigned long long*)r.cost.need((size_t)ncols * 8);
                 HC(hipMemsetAsync(cd, 0, (size_t)ncols * 8, r.main));
                 r.e->dd_column_cost(gmin, ncols, (uint64_t*)cd);
-                HC(hipMemcpyAsync(cost[q].data(), cd, (size_t)ncols * 8, hipMemcpyDeviceToHost, r.main));
-                HC(hipStreamSynchronize(r.main));
+                r.e->bounce.d2h(cost[q].data(), cd, (size_t)ncols * 8, r.main);
                 long long mine = 0; for (auto v : cost[q]) mine += v;
                 tot[(size_t)q * 2] = mine;
             }
@@ -1162,7 +1161,7 @@ struct MultiEngine final : EngineBase {
             for (size_t q = 0; q < R.size(); ++q) {
                 Rank& r = R[q]; HC(hipSetDevice(r.device));
                 unsigned long long f = 0;
-                HC(hipMemcpy(&f, r.e->red_cur() + 3, 8, hipMemcpyDeviceToHost));
+                r.e->bounce.d2h(&f, r.e->red_cur() + 3, 8, r.main);
                 bad[q] = f != 0;
             }
             host_allreduce(bad, 1, OP_MAX);
@@ -1196,7 +1195,7 @@ struct MultiEngine final : EngineBase {
             Engine<T>& e = *r.e;
             HC(hipStreamSynchronize(r.main));
             std::vector<uint8_t> ty((size_t)e.N);
-            HC(hipMemcpy(ty.data(), e.type[e.cur], (size_t)e.N, hipMemcpyDeviceToHost));
+            e.bounce.d2h(ty.data(), e.type[e.cur], (size_t)e.N, r.main);
             for (auto t : ty) n += (t != 0 && !(t & kGhostMask)) ? 1 : 0;
         }
         return n;
@@ -1243,13 +1242,14 @@ struct MultiEngine final : EngineBase {
             e.set_output_components(out_comp);
             auto buf = [&](HostBuf& b, bool wanted, size_t bytes) -> void* { return wanted ? (void*)b.need(std::max<size_t>(bytes, 1)) : nullptr; };
             e.dl_tags_host = (unsigned long long*)P.tag.need(std::max<size_t>(n * 8, 1));
+            e.dl_dst_page_locked = true;               // (every destination below is a HostBuf: hipHostMalloc)
             try {
                 e.download_begin(buf(P.pos, position, n * C * hb), buf(P.vel, velocity, n * C * hb), buf(P.acc, acceleration, n * C * hb),
                                  buf(P.rho, density, n * hb), buf(P.prs, pressure, n * hb), (int64_t*)buf(P.id, ids, n * 8),
                                  (uint8_t*)buf(P.ty, true, n), (uint64_t*)buf(P.grp, groups, n * 8), buf(P.gho, ghost_points, n * C * hb),
                                  (int64_t*)buf(P.cel, cells, n * (size_t)D * 8));
-            } catch (...) { e.dl_tags_host = nullptr; throw; }
-            e.dl_tags_host = nullptr;
+            } catch (...) { e.dl_tags_host = nullptr; e.dl_dst_page_locked = false; throw; }
+            e.dl_tags_host = nullptr; e.dl_dst_page_locked = false;
         }
         pend = PendingDownload{position, velocity, acceleration, density, pressure, ghost_points, ids, cells, ty, groups, true};
     }
@@ -1296,9 +1296,9 @@ struct MultiEngine final : EngineBase {
             const size_t n = (size_t)e.N; ns[q] = n;
             data[q].resize(std::max<size_t>(n * elem, 1)); ty[q].resize(std::max<size_t>(n, 1)); tag[q].resize(std::max<size_t>(n, 1));
             if (n) {
-                HC(hipMemcpy(data[q].data(), src(e), n * elem, hipMemcpyDeviceToHost));
-                HC(hipMemcpy(ty[q].data(), e.type[e.cur], n, hipMemcpyDeviceToHost));
-                HC(hipMemcpy(tag[q].data(), e.otag[e.cur], n * 8, hipMemcpyDeviceToHost));
+                e.bounce.d2h(data[q].data(), src(e), n * elem, r.main);
+                e.bounce.d2h(ty[q].data(), e.type[e.cur], n, r.main);
+                e.bounce.d2h(tag[q].data(), e.otag[e.cur], n * 8, r.main);
             }
             tys[q] = ty[q].data(); tags[q] = tag[q].data();
         }
@@ -1403,8 +1403,7 @@ struct MultiEngine final : EngineBase {
             unsigned long long* cd = (unsigned long long*)r.cost.need((size_t)ncols * 8);
             HC(hipMemsetAsync(cd, 0, (size_t)ncols * 8, r.main));
             r.e->dd_column_cost(col0, ncols, (uint64_t*)cd);
-            HC(hipMemcpyAsync(h.data(), cd, (size_t)ncols * 8, hipMemcpyDeviceToHost, r.main));
-            HC(hipStreamSynchronize(r.main));
+            r.e->bounce.d2h(h.data(), cd, (size_t)ncols * 8, r.main);
             for (int c = 0; c < ncols; ++c) out[c] += h[(size_t)c];
         }
     }

@@ -449,21 +449,23 @@ template <class T>
 __global__ void __launch_bounds__(256) k_init_reduce(Half<const typename Vec4<T>::type> pk0,
                                                      Half<const typename Vec4<T>::type> pk1,
                                                      const typename Vec4<T>::type* acc, int N, T h, T eta2,
-                                                     unsigned long long* red) {
+                                                     unsigned long long* red, unsigned long long* vmx = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    T disp2 = 0, vis = 0, a2 = 0;
+    T disp2 = 0, vis = 0, a2 = 0, v2 = 0;
     if (i < N) {
         auto x = pk0[i]; auto v = pk1[i]; auto a = acc[i];
         const T rr = x.x * x.x + x.y * x.y + x.z * x.z;
         disp2 = rr;
         vis = absT(h * (v.x * x.x + v.y * x.y + v.z * x.z) / (rr + eta2));
         a2 = a.x * a.x + a.y * a.y + a.z * a.z;
+        v2 = v.x * v.x + v.y * v.y + v.z * v.z;          // (max |v|²: the skin of the first predictor's accept masks, ForceParams::mstore)
     }
-    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
+    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2); v2 = wave_max(v2);
     if ((threadIdx.x & 63) == 0) {
         atomic_max_bits(&red[0], disp2);
         atomic_max_bits(&red[1], vis);
         atomic_max_bits(&red[2], a2);
+        if (vmx) atomic_max_bits(vmx, v2);
     }
 }
 
