@@ -167,7 +167,7 @@ struct Engine final : EngineBase {
     // Accept masks handed from the predictor to the corrector of a step (ForceParams::mstore): plain handles whose launches run one
     // wave per tile with the compiled-in model, 3-D, fp32.  max |v|² of the state travels in red_d[14 + rpar] (same parity
     // as the reduction slots; a slot that was not zeroed in between only makes the skin wider).
-    int mask_store = 1;                // $SPHMI_MASK_STORE=0 switches it off
+    int mask_store = SPHMI_MASK_STORE; // (experiment builds only: measured and off, sphmi_kernels.h; $SPHMI_MASK_STORE=0 switches it off there)
     int mask_cap = 48;                 // chunks per tile kept ($SPHMI_MASK_CAP; a 3-D tile scans 27 on average, 45 at most in a filled lattice)
     unsigned long long* mstore_d = nullptr; size_t mstore_tiles = 0;
     bool mask_possible() const {

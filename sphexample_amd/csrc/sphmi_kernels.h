@@ -109,7 +109,11 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
                                 // neither the gathers nor the arithmetic sit under an execution mask and the wait is vmcnt(2)
 #endif
 #ifndef SPHMI_MASK_STORE
-#define SPHMI_MASK_STORE 1      // the kernels can hand the predictor's accept masks to the corrector (ForceParams::mstore; the engine decides per handle)
+#define SPHMI_MASK_STORE 0      // EXPERIMENT BUILD: the predictor hands its accept masks to the corrector of the same step (ForceParams::mstore).
+                                // MEASURED AND OFF: bit-identical results (tests/test_mask_handover_gpu.py on a -DSPHMI_MASK_STORE=1 build), the
+                                // corrector runs 17 % fewer vector instructions — and 10 % LONGER (0.513 → 0.564 ms at 1.06 M particles; the
+                                // predictor 0.494 → 0.522): 224 MB of masks per launch come back from beyond the L2s, one dependent load per
+                                // chunk, and the in-order vmcnt makes every gather behind a mask load (or store) wait for it
 #endif
 #ifndef SPHMI_SCAN_PF
 #define SPHMI_SCAN_PF 0         // phase 1 software-pipelined (one wave per tile): bit 0 = the candidate coordinates of the NEXT chunk of a row are
@@ -435,10 +439,10 @@ k_neighbor_force(const ForceParams<T> P) {
         StepCtrl c = *P.ctl_in;
         const unsigned long long r0 = P.red_in[0], r1 = P.red_in[1], r2 = P.red_in[2], r3 = P.red_in[3];
         const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, P.ctl_h, P.ctl_c0, P.ctl_CFL);
-        if (P.mstore) vmax2_bits = *P.vmx_in;
+        if (SPHMI_MASK_STORE != 0 && P.mstore) vmax2_bits = *P.vmx_in;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             *P.ctl_out = c;
-            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; if (P.vmx_zero) *P.vmx_zero = 0; }
+            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; if (SPHMI_MASK_STORE != 0 && P.vmx_zero) *P.vmx_zero = 0; }
         }
         if (!c.active) return;
         step_dt = (T)c.dt; step_dt2 = (T)c.dt2;
@@ -1268,7 +1272,7 @@ k_neighbor_force(const ForceParams<T> P) {
         // every lane holds the three maxima: lanes 0, 1, 2 serve one slot each — ONE pre-test load and ONE atomic instruction
         // per wave instead of three dependent round trips to the coherence point (a device-scope load is served beyond the
         // XCD's L2; the epilogue of a lone wave: 5.3 → 4.1 µs, tools/trace_small.py)
-        if (P.vmx != nullptr) {
+        if (kMaskIO && P.vmx != nullptr) {
             // max |v|² of the new state (particles that move): the skin of the next predictor's accept masks (ForceParams::mstore)
             T v2 = owned ? (o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * ml : T(0);
             v2 = wave_max(v2);

@@ -39,6 +39,12 @@ def load_library(rebuild_if_stale: bool = True) -> C.CDLL:
     return lib
 
 
+def _reset_library_cache() -> None:
+    """Forget the loaded library so that the next load_library() follows $SPHMI_LIB again (tests of experiment builds)."""
+    global _lib
+    _lib = None
+
+
 def backend_info() -> str:
     return load_library().sphmi_backend_info().decode()
 

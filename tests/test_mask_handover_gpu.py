@@ -4,13 +4,29 @@ H + vmax·Δt, so the handed-over masks are a SUPERSET of the pairs the correcto
 beyond H contribute exactly zero (the Wendland factor is clamped), and the order of a lane's pairs is the order of the chunks —
 so the state must come out BIT FOR BIT the same with the hand-over on, off, and with a capacity so small that most chunks
 fall back to scanning.  A missing pair (a skin that is too thin) would show as a difference."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import flowing, perturbed
 from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
 
-pytestmark = pytest.mark.gpu
+# The hand-over is an EXPERIMENT build (measured and off: sphmi_kernels.h, DESIGN §4.6): these tests run against a library built
+# with -DSPHMI_MASK_STORE=1 — `python tools/prebuild_variants.py "maskstore:-DSPHMI_MASK_STORE=1"` — and skip without one.
+_VARIANT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "variants", "libsphmi_maskstore.so")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(_VARIANT), reason="no -DSPHMI_MASK_STORE=1 build under build/variants/")]
+
+
+@pytest.fixture(autouse=True)
+def _variant_library(monkeypatch):
+    """Load the experiment build for the tests of this module, the shipped library again afterwards."""
+    from sphexample_amd import engine
+    monkeypatch.setenv("SPHMI_LIB", _VARIANT)
+    engine._reset_library_cache()
+    yield
+    monkeypatch.delenv("SPHMI_LIB")
+    engine._reset_library_cache()
 
 
 def _run(p, s, steps, monkeypatch, store, cap=None, calls=1):
