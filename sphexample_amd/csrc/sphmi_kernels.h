@@ -102,6 +102,9 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
                                 // of the NEXT neighbour are worked out while the two gathers of the current one are in flight (no further load in
                                 // flight, one more register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links
 #endif
+#ifndef SPHMI_PIPE2
+#define SPHMI_PIPE2 1           // the same pipelining for the two-pair loop of the lone-wave kernels (four or eight waves per tile)
+#endif
 #ifndef SPHMI_DEEP
 #define SPHMI_DEEP 0            // bit 0: predictor, bit 1: corrector — TWO neighbours in flight per lane: the gathers of the next pair are issued before the
                                 // arithmetic of the current one, into a second set of eight registers (the predictor has them to spare: LDS, not
@@ -893,6 +896,44 @@ k_neighbor_force(const ForceParams<T> P) {
             if (v) pair(jr, n0, n1, plays_i(jr));
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
+    // SPHMI_PIPE2: the two-pair loop with the addresses of the NEXT one or two neighbours worked out while the four gathers fly
+    // (compiled-in model only: the run-time variant's two-pair kernels — MovingSquare2d — lose 3 % with it, registers)
+    constexpr bool kPipe2 = SPHMI_PIPE2 != 0 && kTwoPairs && !kRoleEntries && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
+    [[maybe_unused]] bool pv2 = false;
+    [[maybe_unused]] unsigned pjr2 = 0;
+    auto run_pairs_piped2 = [&](const int keep, const bool drain) {
+        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+        unsigned qf = qn != 0 ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
+            work_it += 1;
+#ifdef SPHMI_STATS
+            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pv)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(pv2));
+#endif
+            const unsigned jr0 = pjr, jr1 = pjr2;
+            const bool v0 = pv, v1 = pv2;
+            V4 n0a, n1a, n0b, n1b;
+            if (v0) {
+                n0a = gather_packet(rs0, jr0, 0, T()); n1a = gather_packet(rs0, jr0, 1, T());
+                n0b = gather_packet(rs0, jr1, 0, T()); n1b = gather_packet(rs0, jr1, 1, T());      // (jr1 = jr0 when there is no second one)
+            }
+            unsigned m = cm;
+            if (cm < qf) {
+                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
+                m = ne.x; raddr = q_next(raddr); qn -= 1;
+                qf = min((unsigned)qn, 1u);
+                cbase = ne.y;
+            }
+            const unsigned m1 = m & (m - 1);
+            cm = m1 & (m1 - 1);
+            pv = m != 0; pv2 = m1 != 0;
+            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
+            pjr2 = pv2 ? ((unsigned)__builtin_ctz(m1) << kRecShift) + cbase : pjr;
+            if (v0) {
+                pair(jr0, n0a, n1a, plays_i(jr0));
+                if (v1) pair(jr1, n0b, n1b, plays_i(jr1));
+            }
+        } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
+    };
     constexpr bool kDeep = ((SPHMI_DEEP >> (PASS == PASS_CORRECTOR ? 1 : 0)) & 1) != 0 && kPipe && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY;
     auto run_pairs_deep = [&](const int keep, const bool drain) {
         auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
@@ -933,7 +974,8 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     };
     auto run_pairs = [&](const int keep, const bool drain) {
-        if constexpr (kDeep) run_pairs_deep(keep, drain);
+        if constexpr (kPipe2) run_pairs_piped2(keep, drain);
+        else if constexpr (kDeep) run_pairs_deep(keep, drain);
         else if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);
         else if constexpr (kPipe) run_pairs_piped(keep, drain);
         else run_pairs_plain(keep, drain);
