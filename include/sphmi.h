@@ -159,8 +159,12 @@ int sphmi_set_clock(sphmi_handle* h, int64_t iteration, double total_time);
  * device in stream order and starts the device→host copies on a second stream; the caller may call sphmi_advance
  * right away and must not touch the host arrays until sphmi_download_end returns.  sphmi_download = begin + end.
  * sphmi_host_register page-locks a host array the caller will hand in again and again (the fields of the
- * StructArray live for the whole run): it removes the runtime's staging copy where the platform needs one.
- * The caller must unregister (or destroy the handle) before freeing the array.
+ * StructArray live for the whole run): registered arrays are written by the copy engine WHILE the caller advances;
+ * arrays that are not registered are filled from the device-side snapshot inside sphmi_download_end, through a
+ * page-locked bounce buffer of the handle (the library never hands a pageable pointer to the runtime: its cached pins
+ * of the caller's pages go stale when the allocator re-uses the addresses).  The contract is the same either way: the
+ * arrays hold the snapshot when sphmi_download_end returns.  The caller must unregister (or destroy the handle) before
+ * freeing a registered array.
  */
 int sphmi_download_begin(sphmi_handle* h,
                          void* position, void* velocity, void* acceleration, void* density, void* pressure,
