@@ -396,6 +396,9 @@ struct Engine final : EngineBase {
     // tiles per block of the one-wave-per-tile launches (3-D fp32 compiled-in model; $SPHMI_TPB = 1, 2 or 4 overrides).  Measured at
     // 1.06 M particles (kernel ms per launch): 1 → 0.5601, 2 → 0.5591, 4 → 0.5558; it is what lets ONE tile segment per XCD
     // (the L2-friendly schedule) run as fast as sixteen: 0.5562 against 0.5585 / 0.5558
+#ifndef SPHMI_TPB_F64
+#define SPHMI_TPB_F64 1            // fp64 handles launch their one-wave tiles four per block too
+#endif
     int tpb = 4;
     int tpb2 = 1;                      // two-wave tiles in pairs (workgroups of four waves); $SPHMI_TPB2=0 switches it off
     template <int PASS, int MODEL, int TPB> void launch_force_tpb(const ForceParams<T>& P, int list) {
@@ -404,7 +407,7 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
     }
     template <int PASS, int MODEL, int WPT> void launch_force_wpt(const ForceParams<T>& P, int list) {
-        if constexpr (WPT == 1 && MODEL == kModelDefault && sizeof(T) == 4) {
+        if constexpr (WPT == 1 && MODEL == kModelDefault && (sizeof(T) == 4 || SPHMI_TPB_F64 != 0)) {
             if (D == 3 && tpb == 4) { launch_force_tpb<PASS, MODEL, 4>(P, list); return; }
             if (D == 3 && tpb == 2) { launch_force_tpb<PASS, MODEL, 2>(P, list); return; }
         }

@@ -615,6 +615,39 @@ def test_async_output_delivers_the_same_snapshots(dam_break_2d):
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_download_begin_advance_end_hands_out_the_snapshot(dam_break_2d, pinned):
+    """The contract of sphmi_download_begin / _end with BOTH kinds of destination: arrays the caller page-locked
+    (sphmi_host_register) are written by the copy engine while the run goes on, any other array is filled from the device-side
+    snapshot inside sphmi_download_end through the handle's bounce buffer (the library hands no pageable pointer to the
+    runtime).  Either way the arrays hold the state of the moment of `begin`, whatever was advanced in between —
+    and a second begin without an end delivers the first snapshot first."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d
+    eng = make_engine(p, s, device_float_bytes=8)
+    eng.advance(1e9, max_steps=7)
+    want = eng.download()
+    q = p.copy()
+    if pinned:
+        eng.pin(q)
+    eng.download_into_begin(q)
+    eng.advance(1e9, max_steps=9)                           # the state moves on while the copies fly / before they are made
+    eng.download_end()
+    for k in ("Position", "Velocity", "Density", "Pressure", "ID"):
+        np.testing.assert_array_equal(getattr(q, k), want[k], err_msg=k)
+    want2 = eng.download()
+    r = p.copy()
+    eng.download_into_begin(q)                              # snapshot 2 into q …
+    eng.advance(1e9, max_steps=3)
+    eng.download_into_begin(r)                              # … which must be complete before snapshot 3 starts
+    np.testing.assert_array_equal(q.Density, want2["Density"])
+    eng.download_end()
+    np.testing.assert_array_equal(r.Density, eng.download()["Density"])
+    assert not np.array_equal(r.Density, q.Density)
+    if pinned:
+        eng.unpin()
+
+
 def test_output_side_against_the_oracle_backed_driver(dam_break_2d_mdbc):
     """SURVEY §8 row f3 against the ORACLE, not against the engine itself: the asynchronous, device-packed, n×3-padded
     output of the HIP engine (sphmi_download_begin / _end + sphmi_set_output_components) equals, snapshot by snapshot,
