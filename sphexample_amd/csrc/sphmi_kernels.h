@@ -485,6 +485,13 @@ k_neighbor_force(const ForceParams<T> P) {
     int b;
     {
         const int x = blockIdx.x & 7, r = TPB == 1 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * TPB + tib;
+        // (Early returns and the workgroup barriers further down — TPB > 1 with WPT = 2, and kShareRanges: the waves of ONE tile
+        // return here, at the all-ghost test or on a cancelled step TOGETHER (the conditions are per tile or per launch), while the
+        // waves of the block's OTHER tile go on to `__syncthreads()`.  In the HIP model a barrier that not every thread of the block
+        // reaches is undefined; on gfx9 / CDNA `s_barrier` counts the waves of the workgroup that have not terminated — an ended wave
+        // is taken out of the barrier's count by the hardware ("s_endpgm" releases it) — and this kernel is built for gfx950 only.
+        // The tests force every WPT / TPB variant on layouts with partial last blocks and ghost-only tiles
+        // (test_every_waves_per_tile_variant_matches_the_oracle, tests/test_multi_gpu.py).)
         if (r >= P.part[8 + x]) return;
         b = P.order[P.part[x] + r];
     }
