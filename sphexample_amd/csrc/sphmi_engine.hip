@@ -162,7 +162,14 @@ struct Engine final : EngineBase {
     unsigned long long* red_cur() const { return red_d + 4 * rpar; }
     // (decided once per queued batch: before the first rebuild there is no tile schedule and the predictor launch is skipped —
     // nobody would take the decisions)
-    bool fused_control() const { return fuse_ctrl && cfg.mdbc == SPHMI_MDBC_NONE && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0; }
+    // (plain handles take the control inside the predictor; mDBC handles inside k_mdbc, which runs first — $SPHMI_FUSE_MDBC=0: not)
+    int fuse_mdbc = 1, fuse_mdbc_max_n = 32768;
+    bool fused_control() const {
+        // (every wave of k_mdbc that has a ghost node repeats the decisions — ≈0.15 µs of fp64 arithmetic: worth the 6 µs launch
+        // it replaces on the 2-D layouts, 37.5 against 40 µs per step; DucklingMDBC, 54 817 particles, loses 2 µs with it)
+        const bool mdbc_ok = fuse_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE && N <= fuse_mdbc_max_n;
+        return fuse_ctrl && (cfg.mdbc == SPHMI_MDBC_NONE || mdbc_ok) && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0;
+    }
     bool batch_fused = false;
     // Accept masks handed from the predictor to the corrector of a step (ForceParams::mstore): plain handles whose launches run one
     // wave per tile with the compiled-in model, 3-D, fp32.  max |v|² of the state travels in red_d[14 + rpar] (same parity
@@ -263,6 +270,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&ctrl_d, 2 * sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
         HC(hipMemset(ctrl_d, 0, 2 * sizeof(StepCtrl)));
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
+        if (const char* w = getenv("SPHMI_FUSE_MDBC")) fuse_mdbc = atoi(w);
         if (const char* w = getenv("SPHMI_MASK_STORE")) mask_store = atoi(w);
         if (const char* w = getenv("SPHMI_MASK_CAP")) mask_cap = std::max(1, atoi(w));
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
@@ -659,11 +667,19 @@ struct Engine final : EngineBase {
         if (m > 0) part_max[list] = m;
     }
 
-    void run_mdbc(const StepCtrl* ctrl = nullptr) {
+    // take_control: the kernel takes the decisions of the step itself (MdbcParams::ctl_in): reads control block `cpar` and slot set
+    // `rpar`, writes block cpar ^ 1; its flag goes to the set the coming corrector fills.  The caller flips both indices afterwards.
+    void run_mdbc(const StepCtrl* ctrl = nullptr, bool take_control = false) {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
         M.ctrl = ctrl;
         M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_cur(); M.N = N;
+        if (take_control) {
+            M.ctrl = nullptr;
+            M.ctl_in = ctrl_d + cpar; M.ctl_out = ctrl_d + (cpar ^ 1);
+            M.red_in = red_d + 4 * rpar; M.red = red_d + 4 * (rpar ^ 1);
+            M.ctl_h = cfg.h; M.ctl_c0 = cfg.c0; M.ctl_CFL = cfg.CFL;
+        }
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
         dim3 g((N + 3) / 4), b(256);               // one wave per particle, four per block
@@ -714,10 +730,16 @@ struct Engine final : EngineBase {
             end_phase(ev);
         }
         progress_motion(0.0, ctrl_cur());                                      // :765
-        if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());                // :772
+        const bool fused_in_mdbc = fused && cfg.mdbc == SPHMI_MDBC_SIMPLE;
+        if (fused_in_mdbc) { run_mdbc(nullptr, true); cpar ^= 1; rpar ^= 1; }   // :772, and the decisions of the step with it
+        else if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());           // :772
         ForceParams<T> P1 = force_params(iA, iA, iH, 0.0);
-        const bool masks = fused && masks_ready();
-        if (fused) {
+        const bool masks = fused && !fused_in_mdbc && masks_ready();
+        if (fused_in_mdbc) {
+            // decided by k_mdbc: the predictor reads the block it wrote and zeroes what that kernel could not
+            P1.ctrl = ctrl_cur();
+            P1.mdbc_zero = red_cur(); P1.mdbc_flag_zero = red_d + 4 * (rpar ^ 1) + 3;
+        } else if (fused) {
             // the predictor takes the decisions: reads control block / slots `cpar` / `rpar`, leaves the other ones to the corrector
             P1.ctl_in = ctrl_d + cpar; P1.ctl_out = ctrl_d + (cpar ^ 1);
             P1.red_in = red_d + 4 * rpar; P1.red_zero = red_d + 4 * (rpar ^ 1);

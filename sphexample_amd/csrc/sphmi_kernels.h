@@ -228,6 +228,11 @@ struct ForceParams {
     const StepCtrl* ctl_in; StepCtrl* ctl_out;
     const unsigned long long* red_in; unsigned long long* red_zero;
     double ctl_h, ctl_c0, ctl_CFL;
+    // mDBC handles take the control inside k_mdbc (MdbcParams::ctl_in), which runs before this kernel: the predictor of an
+    // executed step then only zeroes what k_mdbc could not zero itself — slots 0–2 of the set this step's corrector fills
+    // (mdbc_zero[0..2]; slot 3 holds k_mdbc's flag of this step) and the flag slot of the other set (mdbc_flag_zero), which the
+    // next step's k_mdbc and corrector fill.  Null: nothing to do.
+    unsigned long long* mdbc_zero; unsigned long long* mdbc_flag_zero;
     // Accept masks handed from the predictor to the corrector of the SAME step (plain handles, one wave per tile, 3-D fp32
     // compiled-in model): the predictor tests against H + vmax·Δt — no pair can come closer than that within the half step —
     // and stores the trimmed 64-bit mask of every chunk it scans, [tile][chunk][lane]; the corrector replays the chunk
@@ -451,6 +456,9 @@ k_neighbor_force(const ForceParams<T> P) {
         step_dt = (T)c.dt; step_dt2 = (T)c.dt2;
     } else {
         if (P.ctrl && !P.ctrl->active) return;             // a queued step that the control cancelled
+        if (PASS == PASS_PREDICTOR && P.mdbc_zero != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+            P.mdbc_zero[0] = 0; P.mdbc_zero[1] = 0; P.mdbc_zero[2] = 0; *P.mdbc_flag_zero = 0;
+        }
         step_dt = P.ctrl ? (T)P.ctrl->dt : P.dt; step_dt2 = P.ctrl ? (T)P.ctrl->dt2 : P.dt2;
     }
     const int visc = MODEL >= 0 ? (MODEL & 15) : P.visc;

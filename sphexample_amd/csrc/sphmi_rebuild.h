@@ -483,6 +483,15 @@ template <class T> struct MdbcParams {
     double H2, h_inv, h, alphaD, m0, rho0, eta2;
     int kernel;            // 0 WendlandC2, 1 CubicSpline
     const StepCtrl* ctrl;  // device-side step control (null: always run)
+    // Control taken INSIDE this kernel (mDBC handles without moving bodies or slabs; the same scheme as ForceParams::ctl_in of
+    // the predictor, which plain handles use): every wave takes the decisions of the step from the control block the previous
+    // step left and the slots its corrector filled, block 0 stores the decided state to the OTHER block, where the predictor
+    // and the corrector of this step read it.  `red` (the bad-density flag of this kernel) is then slot 3 of the set this
+    // step's corrector fills: the PREVIOUS step's predictor has zeroed it (a zeroing by this launch would race with its own
+    // blocks), and this step's predictor zeroes slots 0–2 of that set and slot 3 of the other one (ForceParams::mdbc_zero).
+    const StepCtrl* ctl_in; StepCtrl* ctl_out;
+    const unsigned long long* red_in;
+    double ctl_h, ctl_c0, ctl_CFL;
 };
 
 template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22) {
@@ -499,7 +508,17 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
     // ran the ≈300-candidate loop serially in fp64: 206 of the 288 µs of a DucklingMDBC step.
     constexpr int P = D + 1;
     using R = double;
-    if (M.ctrl && !M.ctrl->active) return;
+    if (M.ctl_in != nullptr) {
+        // (a wave without a ghost node has nothing to decide for — except the one that stores the decisions)
+        const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const bool idle = i0 >= M.N || M.ghost[i0 < M.N ? i0 : 0].w == T(0);
+        if (idle && !(blockIdx.x == 0 && threadIdx.x < 64)) return;
+        StepCtrl c = *M.ctl_in;
+        const unsigned long long r0 = M.red_in[0], r1 = M.red_in[1], r2 = M.red_in[2], r3 = M.red_in[3];
+        (void)step_control_decide<T>(r0, r1, r2, r3, c, M.ctl_h, M.ctl_c0, M.ctl_CFL);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *M.ctl_out = c;
+        if (!c.active) return;
+    } else if (M.ctrl && !M.ctrl->active) return;
     const int lane = threadIdx.x & 63;
     int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= M.N) return;

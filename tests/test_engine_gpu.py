@@ -738,6 +738,33 @@ def test_control_inside_the_predictor_keeps_the_step_sequence(dam_break_2d, fuse
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("case,dt_unit", [("still_wedge", 3.2e-4), ("dam_break_2d_mdbc", 9e-5)])
+def test_control_inside_the_mdbc_kernel_keeps_the_step_sequence(case, dt_unit, fuse, request, monkeypatch):
+    """mDBC handles take the step control inside k_mdbc, the first kernel of their step (MdbcParams::ctl_in): its bad-density
+    flag goes to the slot set the step's corrector fills, which the PREVIOUS step's predictor has cleared.  The same short
+    calls as above — odd and even lengths, by step count and by time, every call opening with a rebuild and a cancelled
+    control — against the oracle call by call, with the fusion (default) and with the one-thread control launch
+    (SPHMI_FUSE_MDBC=0)."""
+    monkeypatch.setenv("SPHMI_FUSE_MDBC", fuse)
+    p, s = request.getfixturevalue(case)
+    eng, orc = engines(p, s, 8)
+    now = 0.0
+    for k, n in enumerate([1, 2, 3, 1, 5, 8, 2, 17, 1, 4]):
+        if k % 3 == 2:
+            pe, po = eng.advance(now + dt_unit * n), orc.advance(now + dt_unit * n)
+        else:
+            pe, po = eng.advance(1e9, max_steps=n), orc.advance(1e9, max_steps=n)
+        assert (pe.iteration, pe.steps_done, pe.n_rebuilds) == (po.iteration, po.steps_done, po.n_rebuilds)
+        assert pe.last_dt == pytest.approx(po.last_dt, rel=1e-9)
+        assert pe.total_time == pytest.approx(po.total_time, rel=1e-11)
+        now = po.total_time
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-8
+    assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < 1e-10
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wpt", ["1", "2", "4", "8"])
 @pytest.mark.parametrize("case,steps", [("dam_break_3d_shipped", 12), ("dam_break_2d", 20)])
 def test_every_waves_per_tile_variant_matches_the_oracle(case, steps, wpt, request, monkeypatch):
