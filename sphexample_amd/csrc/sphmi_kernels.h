@@ -105,6 +105,16 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
 #ifndef SPHMI_PIPE2
 #define SPHMI_PIPE2 1           // the same pipelining for the two-pair loop of the lone-wave kernels (four or eight waves per tile)
 #endif
+#ifndef SPHMI_DIAG
+#define SPHMI_DIAG 0            // 1 / 2: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers
+#endif
+#ifndef SPHMI_F16_SCAN
+#define SPHMI_F16_SCAN 0        // the distance matrix of phase 1 from ONE v_mfma_f32_32x32x16_f16 per 32×32 block (32 cycles) instead of three
+                                // v_mfma_f32_32x32x2_f32 (64 cycles each: the f32-input form runs at the vector rate); coordinates split into
+                                // hi + lo halves, sixteen products per pair.  MEASURED AND OFF: parity-green, the matrix pipe's share of a launch
+                                // falls from 27 % to 4 %, the launch does not get shorter (0.4786 → 0.4810 ms; under the profiler predictor
+                                // −0.7 %, corrector −4 % at 83 registers) — the matrix pipe was never what a wave waits for
+#endif
 #ifndef SPHMI_DEEP
 #define SPHMI_DEEP 0            // bit 0: predictor, bit 1: corrector — TWO neighbours in flight per lane: the gathers of the next pair are issued before the
                                 // arithmetic of the current one, into a second set of eight registers (the predictor has them to spare: LDS, not
@@ -398,6 +408,16 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 // The neighbour + force kernel.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+// two floats → one register of two halves, round towards zero (any rounding will do for a hi + lo split: lo takes what hi left)
+__device__ __forceinline__ unsigned pk_h2(float a, float b) { const h16x2 p = __builtin_amdgcn_cvt_pkrtz(a, b); return __builtin_bit_cast(unsigned, p); }
+__device__ __forceinline__ float lo_half_as_float(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[0]; }
+// v = hi + lo + O(2⁻²⁰·|v|): { hi, lo } in one register
+__device__ __forceinline__ unsigned split_hl(float v) { const unsigned h = pk_h2(v, 0.0f); return pk_h2(v, v - lo_half_as_float(h)); }
+// … and as { hi, hi }, { lo, lo }
+__device__ __forceinline__ void split_hh_ll(float v, unsigned& hh, unsigned& ll) { hh = pk_h2(v, v); const float r = v - lo_half_as_float(hh); ll = pk_h2(r, r); }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // v_permlane32_swap: returns { {p.lower, q.lower}, {p.upper, q.upper} } — the lane pattern both MFMA
@@ -734,7 +754,12 @@ k_neighbor_force(const ForceParams<T> P) {
     };
     // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
     auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
+#if SPHMI_DIAG == 1 || SPHMI_DIAG == 4
+        // DIAGNOSTIC BUILD (wrong results): the gathers without the arithmetic — the floor set by the gather path
+        sum_c += n0.x + n1.x;
+#else
         pair_core(jr, xa - n0.x, ya - n0.y, (D == 3) ? za - n0.z : T(0), n0.w, n1, a_is_i);
+#endif
     };
 
     // ---- phase 2: every lane walks the set bits of its own accept masks -----------------------
@@ -895,7 +920,12 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned jr = pjr;
             const bool v = pv;
             V4 n0, n1;
+#if SPHMI_DIAG == 2 || SPHMI_DIAG == 4
+            // DIAGNOSTIC BUILD (wrong results): the arithmetic without the gathers — the floor set by the vector ALU
+            if (v) { n0 = q0; n1 = q1; n0.x += __uint_as_float(jr) * T(1e-30); n0.y += T(0.003); n0.w = q0.w + T(1); }
+#else
             if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); }
+#endif
             // 2. while they fly: the next pair of this lane — refill when the mask is used up, lowest set bit, record offset
             unsigned m = cm;
             if (cm < qf) {
@@ -1007,12 +1037,77 @@ k_neighbor_force(const ForceParams<T> P) {
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
     const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+#if SPHMI_F16_SCAN == 0
     float B0[2], B1[2], B2[2], A2;
     B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
     B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
+#endif
+    // ---- SPHMI_F16_SCAN: the same matrix from the f16 matrix instruction (K = 16, 32 cycles) -----------------------------
+    // Tile-local coordinates scaled by sc = 16/H — or less, so that the reach of the tile stays below 192 and |c|² inside the half
+    // range; every coordinate is split into hi + lo halves (products of halves are exact in the fp32 accumulator), so that
+    // |c|² − 2c·t + |t|² − (sc·H)²·(1+ε)  is the sum of sixteen products:
+    //   lanes 0-31 (k 0…7):  cxh·m2xh  cxh·m2xl  cxl·m2xh  cxl·m2xl   cyh·m2yh  cyh·m2yl  cyl·m2yh  cyl·m2yl      (m2 = −2t)
+    //   lanes 32-63 (k 8…15): the same four for z,   cch·1   ccl·1   1·thh   1·thl                                (cc = |c|², th = |t|² − cut)
+    // ε = 3·10⁻⁴ + 2.5·10⁻⁵·R² + 0.03/(sc·H)²  (R = reach of the tile in units of H) covers the residual of the splits (2⁻²⁰ relative
+    // per value, both roundings towards zero), the fp32 accumulation and half-precision subnormals flushed by the matrix pipe (lo
+    // parts below 6·10⁻⁵ times a partner of at most 384).  An ordinary tile reaches 4–5 H: ε ≈ 10⁻³, 0.15 % more candidates for the
+    // pair loop; a tile of spray that spans 100 H gets ε ≈ 0.26.  The mask is a superset either way; the pair loop applies the exact cut.
+    constexpr bool kF16 = SPHMI_F16_SCAN != 0;
+    [[maybe_unused]] unsigned Bh[2][4] = {};
+    [[maybe_unused]] float hinv = 0.0f;
+    if constexpr (kF16) {
+        const float Hinv = __builtin_amdgcn_rsqf((float)P.H2);
+        const float Rs = fast_sqrt(wave_max(valid ? tt : 0.0f)) * Hinv + 3.0f;            // wave-uniform
+        hinv = Hinv * min_raw(16.0f, 192.0f * fast_rcp(Rs));
+        const float thr_s = (hinv * hinv) * (float)P.H2;                                  // (sc·H)²: 256 for ordinary tiles
+        const float sx = owned ? txl * hinv : 0.0f, sy = owned ? tyl * hinv : 0.0f, sz = owned ? tzl * hinv : 0.0f;
+        const float tts = sx * sx + sy * sy + sz * sz;
+        const float eps16 = 3e-4f + 2.5e-5f * (Rs * Rs) + 0.03f * fast_rcp(thr_s);
+        float cut = thr_s * (1.0f + eps16);
+        if constexpr (kMaskIO && PASS == PASS_PREDICTOR) { if (P.mstore) cut = (thr + tt) * (hinv * hinv) + thr_s * eps16; }      // (the skin of the hand-over experiment)
+        const float th = owned ? tts - cut : 60000.0f;
+        unsigned X[4], Z[4];
+        X[0] = split_hl(-2.0f * sx); X[1] = X[0]; X[2] = split_hl(-2.0f * sy); X[3] = X[2];
+        Z[0] = split_hl(-2.0f * sz); Z[1] = Z[0]; Z[2] = pk_h2(1.0f, 1.0f); Z[3] = split_hl(th);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { swap_halves(X[k], Z[k]); Bh[0][k] = X[k]; Bh[1][k] = Z[k]; }
+    }
+    auto scan_chunk16 = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
+        const int c = cb + bperm;
+        const bool cv = c < HI;
+        // (a lane beyond the row's end: coordinates 0 and |c|² far beyond the cut — every sum stays positive)
+        const float cx = cv ? (float)(cpk.x - ox) * hinv : 0.0f, cy = cv ? (float)(cpk.y - oy) * hinv : 0.0f, cz = cv ? (float)(cpk.z - oz) * hinv : 0.0f;
+        const float cc = cv ? cx * cx + cy * cy + cz * cz : 60000.0f;
+        unsigned X[4], Z[4];
+        split_hh_ll(cx, X[0], X[1]); split_hh_ll(cy, X[2], X[3]);
+        split_hh_ll(cz, Z[0], Z[1]); Z[2] = split_hl(cc); Z[3] = pk_h2(1.0f, 1.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) swap_halves(X[k], Z[k]);             // X: block of candidates 0…31, Z: block of candidates 32…63
+        unsigned W[2] = {0u, 0u};
+#pragma unroll
+        for (int C = 1; C >= 0; --C) {
+            u32x4s aw; aw[0] = C ? Z[0] : X[0]; aw[1] = C ? Z[1] : X[1]; aw[2] = C ? Z[2] : X[2]; aw[3] = C ? Z[3] : X[3];
+            const f16x8 a = __builtin_bit_cast(f16x8, aw);
+#pragma unroll
+            for (int Tb = 0; Tb < 2; ++Tb) {
+                u32x4s bw; bw[0] = Bh[Tb][0]; bw[1] = Bh[Tb][1]; bw[2] = Bh[Tb][2]; bw[3] = Bh[Tb][3];
+                f32x16 d = {0};
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, bw), d, 0, 0, 0);
+#pragma unroll
+                for (int r = 15; r >= 0; --r)
+                    W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
+#if SPHMI_SEQ_BLOCKS
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+        swap_halves(W[0], W[1]);
+        return ((unsigned long long)W[1] << 32) | W[0];
+    };
     auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
+#if SPHMI_F16_SCAN == 0
     auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
         const int c = cb + bperm;
         const bool cv = c < HI;
@@ -1041,6 +1136,7 @@ k_neighbor_force(const ForceParams<T> P) {
         swap_halves(W[0], W[1]);
         return ((unsigned long long)W[1] << 32) | W[0];
     };
+#endif
 
     int g0 = 0;                      // WPT > 1: chunks of the rows before this one, mod WPT (wave-uniform)
     auto row_offset = [&](const int seg) { return (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp : (seg - 1) * P.nxp; };
@@ -1132,7 +1228,11 @@ k_neighbor_force(const ForceParams<T> P) {
             }
             if (!handed) {
                 if constexpr (!kPfChunks) cpk = chunk_packet(cb, HI);
+#if SPHMI_F16_SCAN
+                m = scan_chunk16(cb, HI, cpk);
+#else
                 m = scan_chunk(cb, HI, cpk);
+#endif
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
                 const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
@@ -1201,6 +1301,9 @@ k_neighbor_force(const ForceParams<T> P) {
     run_pairs(0, true);
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
+#if SPHMI_DIAG != 0
+    { const T z = (T)P.exact_cut; drho *= z; ax *= z; ay *= z; az *= z; }      // (0 at run time for the compiled-in model: the state stays sane, the loop stays alive)
+#endif
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
     // (with the corrector's masks handed over a chunk costs the two passes ≈ 475 + 120 cycles: 10 per pass)
