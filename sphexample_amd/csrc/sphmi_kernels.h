@@ -920,7 +920,12 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned jr = pjr;
             const bool v = pv;
             V4 n0, n1;
-#if SPHMI_DIAG == 2 || SPHMI_DIAG == 4
+#if SPHMI_DIAG == 5
+            // DIAGNOSTIC BUILD (wrong results): every odd lane gathers the record its even neighbour gathers — what the texture path
+            // charges when the two lanes of a pair address the same 32 bytes (the lane-pair design of DESIGN §4.6)
+            if (v) { const unsigned js = (unsigned)__builtin_amdgcn_mov_dpp((int)jr, 0xA0, 0xF, 0xF, true);      // quad_perm [0, 0, 2, 2]
+                     n0 = gather_packet(rs0, js, 0, T()); n1 = gather_packet(rs0, js, 1, T()); }
+#elif SPHMI_DIAG == 2 || SPHMI_DIAG == 4
             // DIAGNOSTIC BUILD (wrong results): the arithmetic without the gathers — the floor set by the vector ALU
             if (v) { n0 = q0; n1 = q1; n0.x += __uint_as_float(jr) * T(1e-30); n0.y += T(0.003); n0.w = q0.w + T(1); }
 #else
