@@ -593,7 +593,7 @@ k_neighbor_force(const ForceParams<T> P) {
         const float eps = 1e-5f + 1e-6f * (Rm * Rm) / H2f;
         thr = owned ? H2f * (1.0f + eps) - tt : -1e30f;
     }
-    const float m2x = -2.0f * txl, m2y = -2.0f * tyl, m2z = -2.0f * tzl;
+    [[maybe_unused]] const float m2x = -2.0f * txl, m2y = -2.0f * tyl, m2z = -2.0f * tzl;
 
     T drho = 0, ax = 0, ay = 0, az = 0;
     T gcx = 0, gcy = 0, gcz = 0, divr = 0;            // PlanarShifting: ∇Cᵢ, ∇◌rᵢ (corrector pass)
@@ -1049,6 +1049,7 @@ k_neighbor_force(const ForceParams<T> P) {
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
 #endif
+#if SPHMI_F16_SCAN
     // ---- SPHMI_F16_SCAN: the same matrix from the f16 matrix instruction (K = 16, 32 cycles) -----------------------------
     // Tile-local coordinates scaled by sc = 16/H — or less, so that the reach of the tile stays below 192 and |c|² inside the half
     // range; every coordinate is split into hi + lo halves (products of halves are exact in the fp32 accumulator), so that
@@ -1111,6 +1112,7 @@ k_neighbor_force(const ForceParams<T> P) {
         swap_halves(W[0], W[1]);
         return ((unsigned long long)W[1] << 32) | W[0];
     };
+#endif
     auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
 #if SPHMI_F16_SCAN == 0
     auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
