@@ -259,6 +259,14 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&prow[k], n * 4));
         }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
+        // $SPHMI_POISON=<byte>: the record sets and the accelerations start out filled with that byte (255 / 127: NaNs of either sign)
+        // instead of whatever the allocation held — a row that is read before it was ever written then shows in the results of EVERY
+        // run, not in one of a few (tests/test_multi_gpu.py::test_rows_never_written_are_never_read)
+        if (const char* w = getenv("SPHMI_POISON")) {
+            const int b = atoi(w) & 255;
+            for (int k = 0; k < 3; ++k) HC(hipMemset(rec[k], b, 2 * n * sizeof(V4)));
+            for (int k = 0; k < 2; ++k) HC(hipMemset(acc[k], b, n * sizeof(V4)));
+        }
         const size_t nt = n / kWave + 2;
         for (int k = 0; k < 2; ++k) { HC(hipMalloc(&tile_cost[k], nt * 4)); HC(hipMalloc(&tile_order[k], 8 * nt * 4)); }
         HC(hipMalloc(&tile_scan, nt * 4)); HC(hipMalloc(&tile_cls, nt)); HC(hipMalloc(&tile_work_d, nt * 4)); HC(hipMalloc(&tile_work1_d, nt * 4));

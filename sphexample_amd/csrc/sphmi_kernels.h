@@ -531,7 +531,8 @@ k_neighbor_force(const ForceParams<T> P) {
     // state arrives by halo exchange, so they get no accept masks, and nothing is stored or reduced for them
     const uint8_t ty_raw = P.type[ac];
     const bool owned = valid && !(ty_raw & 0xC0);
-    if (__builtin_amdgcn_ballot_w64(owned) == 0) return;          // a tile of ghosts only
+    const unsigned long long owned_lanes = __builtin_amdgcn_ballot_w64(owned);
+    if (owned_lanes == 0) return;                                 // a tile of ghosts only
 
     // target data
     const V4 q0 = P.src0[ac];
@@ -574,8 +575,14 @@ k_neighbor_force(const ForceParams<T> P) {
     // The mask only has to be a SUPERSET of the pairs within H (the pair loop is exact), so fp64 handles run the same
     // fp32 matrix: local coordinates are formed in T and rounded to fp32 (2.27 → ≈1.8 ms per launch at 1 M particles
     // against one target per iteration through SGPRs on the fp64 vector ALU).
-    const T ox = rl(xa, 0), oy = rl(ya, 0), oz = rl(za, 0);
-    const float txl = (float)(xa - ox), tyl = (float)(ya - oy), tzl = (float)(za - oz);
+    // (The origin is the first OWNED particle of the tile, and a ghost copy takes part with local coordinates 0: the interior launch of
+    // a slab runs BEFORE the halo of the pass has landed, a tile may hold ghost rows next to owned ones, and what those rows contain then
+    // is last step's state — or, in a record set that has never been written, whatever the allocation held: a NaN there made the origin,
+    // the reach and with it the cut-off of every lane NaN, and the whole tile lost or gained all its candidates by the sign of that NaN.
+    // Found by a fresh generation of tests/test_fuzz_gpu.py: three slabs, first steps of a new handle, intermittent.)
+    const int lane_o = __builtin_ctzll(owned_lanes);
+    const T ox = rl(xa, lane_o), oy = rl(ya, lane_o), oz = rl(za, lane_o);
+    const float txl = owned ? (float)(xa - ox) : 0.0f, tyl = owned ? (float)(ya - oy) : 0.0f, tzl = owned ? (float)(za - oz) : 0.0f;
     const float tt = txl * txl + tyl * tyl + tzl * tzl;
     float thr;
     {
@@ -589,7 +596,7 @@ k_neighbor_force(const ForceParams<T> P) {
                 H2f = Hs * Hs;
             }
         }
-        const float Rm = fast_sqrt(wave_max(valid ? tt : 0.0f)) + 6.0f * (float)P.h;
+        const float Rm = fast_sqrt(wave_max(owned ? tt : 0.0f)) + 6.0f * (float)P.h;
         const float eps = 1e-5f + 1e-6f * (Rm * Rm) / H2f;
         thr = owned ? H2f * (1.0f + eps) - tt : -1e30f;
     }
@@ -1065,7 +1072,7 @@ k_neighbor_force(const ForceParams<T> P) {
     [[maybe_unused]] float hinv = 0.0f;
     if constexpr (kF16) {
         const float Hinv = __builtin_amdgcn_rsqf((float)P.H2);
-        const float Rs = fast_sqrt(wave_max(valid ? tt : 0.0f)) * Hinv + 3.0f;            // wave-uniform
+        const float Rs = fast_sqrt(wave_max(owned ? tt : 0.0f)) * Hinv + 3.0f;            // wave-uniform
         hinv = Hinv * min_raw(16.0f, 192.0f * fast_rcp(Rs));
         const float thr_s = (hinv * hinv) * (float)P.H2;                                  // (sc·H)²: 256 for ordinary tiles
         const float sx = owned ? txl * hinv : 0.0f, sy = owned ? tyl * hinv : 0.0f, sz = owned ? tzl * hinv : 0.0f;

@@ -1138,7 +1138,19 @@ struct MultiEngine final : EngineBase {
                     reductions_and_control();
                     if (have_halo) { pass(1); pass(2); }                 // before the first rebuild there is no ghost layer to exchange
                 }
-                for (auto& r : R) { HC(hipSetDevice(r.device)); sphmi_dd_control s{}; r.e->dd_ctrl_sync(&s); if (&r == &R[0]) st = s; }
+                for (auto& r : R) {
+                    HC(hipSetDevice(r.device)); sphmi_dd_control s{}; r.e->dd_ctrl_sync(&s);
+                    if (&r == &R[0]) st = s;
+                    else if (s.steps_done != st.steps_done || s.need_rebuild != st.need_rebuild || s.stop != st.stop || s.error != st.error ||
+                             memcmp(&s.total_time, &st.total_time, sizeof(double)) != 0) {
+                        // every slab takes the same decisions from the same merged maxima: a difference is a bug of the driver, never a
+                        // state to hand out
+                        char buf[200];
+                        snprintf(buf, sizeof buf, "slab %d is out of step with slab %d (steps %lld / %lld, t %.17g / %.17g, rebuild %d / %d, stop %d / %d)",
+                                 r.rank, R[0].rank, (long long)s.steps_done, (long long)st.steps_done, s.total_time, st.total_time, s.need_rebuild, st.need_rebuild, s.stop, st.stop);
+                        throw EngineError(SPHMI_ERR_STATE, buf);
+                    }
+                }
                 steps = st.steps_done;
                 total_time = st.total_time; last_dt = st.last_dt; dxl = st.delta_x;
                 const int64_t grown = (steps - steps0) + (st.need_rebuild ? 1 : 0);

@@ -8,6 +8,7 @@ model tags — on one device and, when there are enough particles, on slabs.  Ch
 evaluation to 1e-10 of the field maximum, the loop counters and the state after a few steps.
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,8 @@ import pytest
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 SHAPES = ("box", "sheet", "line", "clusters", "blob")
+# $SPHMI_FUZZ_SEED0 shifts every seed: `SPHMI_FUZZ_SEED0=1000 pytest tests/test_fuzz_gpu.py` is a fresh generation of the same tests
+SEED0 = int(os.environ.get("SPHMI_FUZZ_SEED0", "0"))
 
 
 def _case(seed):
@@ -57,7 +60,7 @@ def _by_id(st):
     return {k: v[o] for k, v in st.items()}
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + 40))
 def test_fuzzed_cloud_matches_the_oracle(seed):
     from oracle.oracle import make_oracle
     from sphexample_amd.engine import make_engine
@@ -77,13 +80,26 @@ def test_fuzzed_cloud_matches_the_oracle(seed):
     # negative density; the engine keeps the MotionLimiter flag in the sign of ρ, so it must REFUSE (SPHMI_ERR_NUMERIC) — in the
     # very call that produced it — and must never hand such a state out as if it were good.
     bad = bool((orc.download(("Density",))["Density"] <= 0).any()) or not np.isfinite(po.last_dt)
+    from sphexample_amd._abi import ERR_NUMERIC, SphmiError
     if bad:
-        from sphexample_amd._abi import ERR_NUMERIC, SphmiError
         with pytest.raises(SphmiError) as ei:
             eng.advance(1e9, max_steps=steps)
         assert ei.value.status == ERR_NUMERIC
         return
-    pe = eng.advance(1e9, max_steps=steps)
+    try:
+        pe = eng.advance(1e9, max_steps=steps)
+    except SphmiError as exc:
+        # The oracle's FINAL state is sane, the engine refused: legitimate only if a density went through zero at an INTERMEDIATE step
+        # and came back (the reference never looks).  The oracle stepped one step at a time shows it (the rebuild every call opens
+        # with changes the summation order, not the physics).
+        assert exc.status == ERR_NUMERIC, exc
+        o1 = make_oracle(p, s)
+        seen = False
+        for _ in range(steps):
+            o1.advance(1e9, max_steps=1)
+            seen = seen or bool((o1.download(("Density",))["Density"] <= 0).any())
+        assert seen, f"the engine refused a run in which no density of the oracle ever reaches zero ({shape}): {exc}"
+        return
     assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter)
     assert pe.total_time == pytest.approx(po.total_time, rel=1e-9)
     e, o = _by_id(eng.download()), _by_id(orc.download())
@@ -141,7 +157,7 @@ def _case2(seed):
     return p, s, shape, int(rng.choice([8, 8, 4]))
 
 
-@pytest.mark.parametrize("seed", range(100, 160))
+@pytest.mark.parametrize("seed", range(SEED0 + 100, SEED0 + 160))
 def test_fuzzed_switches_match_the_oracle(seed):
     from oracle.oracle import make_oracle
     from sphexample_amd._abi import ERR_NUMERIC, SphmiError
@@ -150,6 +166,14 @@ def test_fuzzed_switches_match_the_oracle(seed):
     p, s, shape, fb = _case2(seed)
     mdbc = s.SimMetaData.BMode is SimpleMDBC
     tol_f = 1e-10 if fb == 8 else 1e-3
+    if fb == 4:
+        # fp32 handles keep ABSOLUTE coordinates: a cloud 50 m from the origin resolves 4·10⁻⁶ m, and two random particles may sit
+        # 10⁻⁴ m apart — the distance of that pair, and every 1/(r² + η²) of it, is then known to a few per cent only.  The bound grows
+        # with (coordinate resolution) / (closest pair); well-conditioned clouds keep 10⁻³.
+        from scipy.spatial import cKDTree
+        if len(p) > 1:
+            dmin = cKDTree(p.Position).query(p.Position, k=2)[0][:, 1].min()
+            tol_f *= 1.0 + 2000.0 * (np.abs(p.Position).max() * 6e-8) / max(dmin, 1e-300)
     what = f"{shape} fb{fb} {type(s.SimViscosity).__name__} {type(s.SimDensityDiffusion).__name__} {type(s.SimKernel.kernel).__name__} k{s.SimKernel.k:.2f} " \
            f"{s.SimMetaData.SMode.__name__} {s.SimMetaData.KMode.__name__} {s.SimMetaData.BMode.__name__} motion={getattr(p, 'geometries', None) is not None}"
 

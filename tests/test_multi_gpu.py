@@ -141,6 +141,44 @@ def test_more_slabs_in_one_handle(world, request):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("poison", ["255", "127"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_rows_never_written_are_never_read(world, poison, monkeypatch):
+    """The interior launch of a slab runs BEFORE the halo of its pass has landed.  A tile of a sparse cloud may hold ghost rows
+    next to owned ones (an empty boundary cell: the sort puts the ghost column of one cell row next to the first cells of the
+    next), and what a ghost row holds at that moment is last step's state — or, in a record set no pass has written yet,
+    whatever the allocation held.  A NaN there used to become the tile's origin and reach, and every lane of the tile lost
+    (or gained) all its candidates by the sign of that NaN: intermittent wrong densities in the first steps of a new handle,
+    found by a fresh generation of tests/test_fuzz_gpu.py.  $SPHMI_POISON fills the record sets with NaNs of either sign at
+    creation, so the read shows in every run: a random 2-D cloud on 2 and 3 slabs against the one-device handle, one call of
+    five steps (a batch: the sets rotate without a rebuild in between)."""
+    from sphexample_amd import (LinearDensityDiffusion, SimulationConstants, SimulationMetaData, SPHKernelInstance, WendlandC2,
+                                ZeroViscosity, particles_from_arrays)
+    from sphexample_amd.cases import CaseSetup
+    from sphexample_amd.engine import make_engine
+    rng = np.random.default_rng(8005)
+    n, dx = 6000, 0.02
+    side = n ** 0.5 * dx
+    pos = rng.uniform(0, side, size=(n, 2)) - 50.0
+    typ = rng.choice([1, 1, 1, 2, 3], size=n).astype(np.uint8)
+    p = particles_from_arrays(2, pos, 1000.0 + rng.uniform(-5, 15, n), typ, rng.integers(1, 4, n), rng.permutation(n) + 1)
+    p.Velocity[:] = rng.uniform(-1, 1, size=(n, 2))
+    s = CaseSetup("sparse cloud", SimulationConstants(dx=dx, m0=1000 * dx ** 2, c0=40.0, alpha=0.01, g=9.81, CFL=0.2),
+                  SPHKernelInstance(2, WendlandC2(), dx=dx, k=2.0), SimulationMetaData(Dimensions=2), ZeroViscosity(), LinearDensityDiffusion())
+    ref = make_engine(p, s, device_float_bytes=8)
+    pr = ref.advance(1e9, max_steps=5)
+    r = _by_id(ref.download())
+    monkeypatch.setenv("SPHMI_POISON", poison)
+    dd = make_engine(p, s, device_float_bytes=8, devices=[0] * world)
+    pd = dd.advance(1e9, max_steps=5)
+    assert (pd.iteration, pd.n_rebuilds, pd.index_counter) == (pr.iteration, pr.n_rebuilds, pr.index_counter)
+    d = _by_id(dd.download())
+    assert np.isfinite(d["Density"]).all()
+    assert np.abs(d["Density"] - r["Density"]).max() < 1e-9 * np.abs(r["Density"]).max()
+    assert np.abs(d["Position"] - r["Position"]).max() < 1e-12 * np.abs(r["Position"]).max()
+
+
+@pytest.mark.gpu
 def test_serial_halo_path(request, monkeypatch):
     """SPHMI_DD_OVERLAP=0: halo → whole pass on one stream (the path mDBC's pass 1 always takes)."""
     _compare("dam_break_3d_shipped", 30, 8, 1e-9, 1, 2, request, env={"SPHMI_DD_OVERLAP": "0"}, monkeypatch=monkeypatch)
