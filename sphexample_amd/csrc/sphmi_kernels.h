@@ -819,7 +819,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // unconditionally the compiler knows how many are outstanding and waits for packet 1 with vmcnt(1), leaving the next
     // neighbour's packet 0 in flight through the arithmetic.
     const unsigned self_r = (unsigned)ac << kRecShift;
-    auto run_pairs_prefetch = [&](const int keep, const bool drain) {
+    auto run_pairs_prefetch = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0) do {
@@ -849,7 +849,7 @@ k_neighbor_force(const ForceParams<T> P) {
             pair_core(jr, dx, dy, dz, n0w, n1, plays_i(jr));
         } while (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0);
     };
-    auto run_pairs_plain = [&](const int keep, const bool drain) {
+    auto run_pairs_plain = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
         // SPHMI_QFLAG: "current mask used up AND something queued" is ONE unsigned compare, cm < min(qn, 1); the 0 / 1 flag is
         // kept up to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration
@@ -915,7 +915,7 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr bool kPipe = SPHMI_PIPE != 0 && !kTwoPairs && !kRoleEntries && !kPrefetch && SPHMI_LDS_STAGE == 0;
     [[maybe_unused]] bool pv = false;
     [[maybe_unused]] unsigned pjr = 0;
-    auto run_pairs_piped = [&](const int keep, const bool drain) {
+    auto run_pairs_piped = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
@@ -961,7 +961,7 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr bool kPipe2 = SPHMI_PIPE2 != 0 && kTwoPairs && !kRoleEntries && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
     [[maybe_unused]] bool pv2 = false;
     [[maybe_unused]] unsigned pjr2 = 0;
-    auto run_pairs_piped2 = [&](const int keep, const bool drain) {
+    auto run_pairs_piped2 = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
@@ -995,7 +995,7 @@ k_neighbor_force(const ForceParams<T> P) {
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
     constexpr bool kDeep = ((SPHMI_DEEP >> (PASS == PASS_CORRECTOR ? 1 : 0)) & 1) != 0 && kPipe && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY;
-    auto run_pairs_deep = [&](const int keep, const bool drain) {
+    auto run_pairs_deep = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         // the next pair of this lane: refill when the mask is used up, lowest set bit, record offset
@@ -1033,7 +1033,7 @@ k_neighbor_force(const ForceParams<T> P) {
             } else { pair(gjr, g0, g1, plays_i(gjr)); break; }
         }
     };
-    auto run_pairs = [&](const int keep, const bool drain) {
+    auto run_pairs = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         if constexpr (kPipe2) run_pairs_piped2(keep, drain);
         else if constexpr (kDeep) run_pairs_deep(keep, drain);
         else if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);

@@ -110,3 +110,24 @@ def test_the_committed_counter_record_matches_the_tree():
         pytest.skip("no counter record committed yet")
     ident = _identity()
     assert bench.counters_for(ident, 1000, 0.5)[2] is None
+
+
+def test_no_neighbour_kernel_spills_or_calls_a_function(tmp_path):
+    """Every instantiation of k_neighbor_force must be ONE straight kernel: no scratch (registers spilled to memory) and no device
+    function left outside it.  Round 3 lost a factor five on `MovingSquare2d` (run-time models, 4 / 8 waves per tile) without a
+    single failing test: once the pair loop had several bodies to choose from, the compiler stopped inlining the lambda that runs
+    it — and a lambda that captures by reference and is CALLED keeps every accumulator of the tile in scratch (134 registers,
+    976 bytes of scratch, 15 → 105 µs per launch).  The lambdas are force-inlined now; this reads the code object's metadata
+    and symbol table (no GPU needed)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_report
+    from sphexample_amd import build
+    lib = build.build()
+    co = isa_report.code_object(lib, str(tmp_path))
+    meta = isa_report.metadata(co)
+    names = isa_report.demangle(list(meta))
+    assert sum("k_neighbor_force" in d for d in names.values()) > 100
+    spilled = {names[k]: v["scratch_bytes"] for k, v in meta.items() if v["scratch_bytes"]}      # (true of every kernel of the library)
+    assert not spilled, spilled
+    outlined = [d for k, d in isa_report.demangle(list(isa_report.kernels(co))).items() if k not in meta]
+    assert not outlined, outlined[:4]

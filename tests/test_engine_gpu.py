@@ -438,6 +438,28 @@ def test_moving_square_example(moving_square, fb, tol):
     assert relmax(e["Position"], o["Position"]) < tol and relmax(e["Density"], o["Density"]) < tol
 
 
+@pytest.mark.parametrize("case,limit_us", [("moving_square", 140.0), ("duckling", 370.0), ("dam_break_3d_shipped", 160.0), ("dam_break_2d", 75.0)])
+def test_example_step_times_stay_in_their_class(case, limit_us):
+    """A coarse guard, 2.5 × the step times recorded in BASELINE.md §4 (fp32: MovingSquare2d 55 µs, DucklingMDBC 148, Dambreak3d
+    Dp0.02 62, the 2-D dam break 30): parity tests do not see a kernel that spills its accumulators to scratch — round 3 carried
+    a five-fold slowdown of the run-time-model kernels with four and eight waves per tile (MovingSquare2d 55 → 272 µs per step)
+    through every green suite until `tools/bench_examples.py` was compared with round 2's figures."""
+    import time
+    import conftest
+    from sphexample_amd.engine import make_engine
+    p, s = getattr(conftest, "load_" + case)()
+    eng = make_engine(p, s, device_float_bytes=4)
+    if hasattr(p, "geometries"):
+        eng.set_motions(p.geometries)
+    eng.advance(1e9, max_steps=100)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.advance(1e9, max_steps=300)
+        best = min(best, (time.perf_counter() - t0) / 300 * 1e6)
+    assert best < limit_us, f"{case}: {best:.1f} µs per step"
+
+
 @pytest.mark.parametrize("k", [1.5, 2.0, 2.5])
 @pytest.mark.parametrize("fb,tol", [(8, 1e-10), (4, 5e-4)])
 def test_cutoff_other_than_2h(dam_break_2d, k, fb, tol):

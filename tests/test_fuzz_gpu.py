@@ -174,6 +174,11 @@ def test_fuzzed_switches_match_the_oracle(seed):
         if len(p) > 1:
             dmin = cKDTree(p.Position).query(p.Position, k=2)[0][:, 1].min()
             tol_f *= 1.0 + 2000.0 * (np.abs(p.Position).max() * 6e-8) / max(dmin, 1e-300)
+        if s.SimKernel.k < 2.0:
+            # a kernel cut off BEFORE its support ends (k < 2) jumps at r = H: a pair that fp64 finds just inside and fp32 just
+            # outside (or the reverse) changes a particle's sum by a whole pair term (seeds 13106, 14145: 2 particles in 6000 / 2331,
+            # 1.1e-3 and 1.3e-3 of the field maximum)
+            tol_f *= 3.0
     what = f"{shape} fb{fb} {type(s.SimViscosity).__name__} {type(s.SimDensityDiffusion).__name__} {type(s.SimKernel.kernel).__name__} k{s.SimKernel.k:.2f} " \
            f"{s.SimMetaData.SMode.__name__} {s.SimMetaData.KMode.__name__} {s.SimMetaData.BMode.__name__} motion={getattr(p, 'geometries', None) is not None}"
 
@@ -192,7 +197,7 @@ def test_fuzzed_switches_match_the_oracle(seed):
     if fb == 4:
         return                                            # (K steps of a violent cloud in fp32: chaos, not parity)
     eng, orc = both()
-    prog = []
+    done = 0
     for steps in (2, 3):                                  # two calls: the rebuild that opens the second, the carried reductions
         po = orc.advance(1e9, max_steps=steps)
         bad = bool((orc.download(("Density",))["Density"] <= 0).any()) or not np.isfinite(po.last_dt) or not np.isfinite(orc.download(("Position",))["Position"]).all()
@@ -201,7 +206,26 @@ def test_fuzzed_switches_match_the_oracle(seed):
                 eng.advance(1e9, max_steps=steps)
             assert ei.value.status == ERR_NUMERIC, what
             return
-        pe = eng.advance(1e9, max_steps=steps)
+        try:
+            pe = eng.advance(1e9, max_steps=steps)
+        except SphmiError as exc:
+            # The oracle's state after the call is sane and the engine refused: legitimate only if mDBC extrapolated a NON-POSITIVE
+            # density to some boundary particle at the start of one of the steps (random ghost nodes do that; the reference carries
+            # on with it and the boundary clamp at the end of the step hides it — the engine keeps the MotionLimiter flag in the
+            # sign of ρ and must refuse).  The oracle shows it: the mDBC pass on the state at the start of every step of the call.
+            assert exc.status == ERR_NUMERIC and mdbc, f"{what}: {exc}"
+            seen = False
+            for k in range(done, done + steps):
+                o1 = make_oracle(p, s)
+                if getattr(p, "geometries", None) is not None:
+                    o1.set_motions(p.geometries)
+                if k:
+                    o1.advance(1e9, max_steps=k)
+                o1.forces_once(apply_mdbc=True)
+                seen = seen or bool((o1.download(("Density",))["Density"] <= 0).any())
+            assert seen, f"the engine refused a run in which mDBC never produces a non-positive density in the oracle ({what}): {exc}"
+            return
+        done += steps
         assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter), what
         assert pe.total_time == pytest.approx(po.total_time, rel=1e-9), what
     e, o = _by_id(eng.download()), _by_id(orc.download())
