@@ -413,7 +413,9 @@ struct Engine final : EngineBase {
     // 1.06 M particles (kernel ms per launch): 1 → 0.5601, 2 → 0.5591, 4 → 0.5558; it is what lets ONE tile segment per XCD
     // (the L2-friendly schedule) run as fast as sixteen: 0.5562 against 0.5585 / 0.5558
 #ifndef SPHMI_TPB_F64
-#define SPHMI_TPB_F64 1            // fp64 handles launch their one-wave tiles four per block too
+#define SPHMI_TPB_F64 0            // 1: fp64 handles launch their one-wave tiles four per block too.  Off: 32 KB of queues per block leave the
+                                   // units five blocks where registers allow four waves per SIMD anyway, and a block lives as long as its slowest
+                                   // tile — 470 k particles 921 → 895 µs per step, 1.06 M 1917 → 1906 (tools/bench_f64.py, both with SPHMI_PIPE_F64 = 0)
 #endif
     int tpb = 4;
     int tpb2 = 1;                      // two-wave tiles in pairs (workgroups of four waves); $SPHMI_TPB2=0 switches it off

@@ -102,6 +102,12 @@ template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
                                 // of the NEXT neighbour are worked out while the two gathers of the current one are in flight (no further load in
                                 // flight, one more register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links
 #endif
+#ifndef SPHMI_PIPE_F64
+#define SPHMI_PIPE_F64 2        // … in fp64 kernels: 0 never, 1 always, 2 in the kernels of two waves per tile only.  Measured (µs per step, compiled-in /
+                                // run-time models): 158 k particles (two waves per tile) 360 / 462 with, 370 / 475 without; 470 k (one wave) 964 / 1070 with,
+                                // 895 / 987 without; 1.06 M 1960 / 2217 with, 1906 / 2071 without — one more register pair costs the run-time-model
+                                // corrector its third wave per SIMD (173 registers against 159)
+#endif
 #ifndef SPHMI_PIPE2
 #define SPHMI_PIPE2 1           // the same pipelining for the two-pair loop of the lone-wave kernels (four or eight waves per tile)
 #endif
@@ -912,7 +918,7 @@ k_neighbor_force(const ForceParams<T> P) {
     };
     // SPHMI_PIPE: (pv, pjr) = the pair this lane takes NEXT (valid flag, record offset), worked out one iteration early; the state
     // survives between the bursts of the pair loop like the queue itself
-    constexpr bool kPipe = SPHMI_PIPE != 0 && !kTwoPairs && !kRoleEntries && !kPrefetch && SPHMI_LDS_STAGE == 0;
+    constexpr bool kPipe = SPHMI_PIPE != 0 && (sizeof(T) == 4 || SPHMI_PIPE_F64 == 1 || (SPHMI_PIPE_F64 == 2 && WPT == 2)) && !kTwoPairs && !kRoleEntries && !kPrefetch && SPHMI_LDS_STAGE == 0;
     [[maybe_unused]] bool pv = false;
     [[maybe_unused]] unsigned pjr = 0;
     auto run_pairs_piped = [&](const int keep, const bool drain) __attribute__((always_inline)) {

@@ -160,25 +160,30 @@ def _case2(seed):
 @pytest.mark.parametrize("seed", range(SEED0 + 100, SEED0 + 160))
 def test_fuzzed_switches_match_the_oracle(seed):
     from oracle.oracle import make_oracle
-    from sphexample_amd._abi import ERR_NUMERIC, SphmiError
+    from sphexample_amd._abi import ERR_DOMAIN, ERR_NUMERIC, SphmiError
     from sphexample_amd.config import SimpleMDBC, StoreKernelOutput
     from sphexample_amd.engine import make_engine
     p, s, shape, fb = _case2(seed)
     mdbc = s.SimMetaData.BMode is SimpleMDBC
     tol_f = 1e-10 if fb == 8 else 1e-3
     if fb == 4:
-        # fp32 handles keep ABSOLUTE coordinates: a cloud 50 m from the origin resolves 4·10⁻⁶ m, and two random particles may sit
-        # 10⁻⁴ m apart — the distance of that pair, and every 1/(r² + η²) of it, is then known to a few per cent only.  The bound grows
-        # with (coordinate resolution) / (closest pair); well-conditioned clouds keep 10⁻³.
+        # fp32 handles keep ABSOLUTE coordinates in fp32: a cloud 50 m from the origin resolves 4·10⁻⁶ m, two random particles may sit
+        # 10⁻⁴ m apart, and with k < 2 the kernel jumps at r = H — what an fp64 oracle fed with the ORIGINAL coordinates then shows is
+        # the conditioning of the case, not the arithmetic of the kernels (seeds 13106, 14145, 16106: a handful of particles off by
+        # a whole pair term).  So the case itself is rounded to fp32 first: engine and oracle start from the same numbers, the
+        # oracle evaluates them exactly, and what is left is the engine's own arithmetic — tile-relative differences, rounded once
+        # (6·10⁻⁸ of a few H) against the closest pair.
+        for f in ("Position", "Velocity", "Density", "GhostPoints"):
+            getattr(p, f)[...] = getattr(p, f).astype(np.float32).astype(np.float64)
         from scipy.spatial import cKDTree
         if len(p) > 1:
             dmin = cKDTree(p.Position).query(p.Position, k=2)[0][:, 1].min()
-            tol_f *= 1.0 + 2000.0 * (np.abs(p.Position).max() * 6e-8) / max(dmin, 1e-300)
-        if s.SimKernel.k < 2.0:
-            # a kernel cut off BEFORE its support ends (k < 2) jumps at r = H: a pair that fp64 finds just inside and fp32 just
-            # outside (or the reverse) changes a particle's sum by a whole pair term (seeds 13106, 14145: 2 particles in 6000 / 2331,
-            # 1.1e-3 and 1.3e-3 of the field maximum)
-            tol_f *= 3.0
+            tol_f *= 1.0 + 2000.0 * (8.0 * s.SimKernel.H * 6e-8) / max(dmin, 1e-300)
+        # What remains after that (ten generations, the worst particles listed one by one): up to 2.5·10⁻³ of the field maximum in dρ/dt on a few
+        # particles of the planes x = (n ± ½)·H the generator puts a fifth of the cloud on — hundreds of particles with EQUAL x,
+        # pairs at 10⁻³ H, large terms of both signs — with or without the moving group, every particle type alike; the fp64
+        # kernels hold 10⁻¹⁰ on the same cases, so the sums are the right sums.  fp32 on such a cloud is good to 4·10⁻³.
+        tol_f *= 4.0
     what = f"{shape} fb{fb} {type(s.SimViscosity).__name__} {type(s.SimDensityDiffusion).__name__} {type(s.SimKernel.kernel).__name__} k{s.SimKernel.k:.2f} " \
            f"{s.SimMetaData.SMode.__name__} {s.SimMetaData.KMode.__name__} {s.SimMetaData.BMode.__name__} motion={getattr(p, 'geometries', None) is not None}"
 
@@ -213,6 +218,14 @@ def test_fuzzed_switches_match_the_oracle(seed):
             # density to some boundary particle at the start of one of the steps (random ghost nodes do that; the reference carries
             # on with it and the boundary clamp at the end of the step hides it — the engine keeps the MotionLimiter flag in the
             # sign of ρ and must refuse).  The oracle shows it: the mDBC pass on the state at the start of every step of the call.
+            if exc.status == ERR_DOMAIN:
+                # A blob that flies apart: the engine's cell list is a DENSE grid over the bounding box of the cloud (the reference
+                # sorts cell indices and has no such limit), and 2²⁷ cells is where it refuses — with a text that says so.  Legitimate
+                # iff the oracle's cloud spans that many cells by the end of the call.
+                x = orc.download(("Position",))["Position"]
+                span = np.floor(x.max(0) / s.SimKernel.H) - np.floor(x.min(0) / s.SimKernel.H) + 3
+                assert np.prod(span) > 2.0 ** 27 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
+                return
             assert exc.status == ERR_NUMERIC and mdbc, f"{what}: {exc}"
             seen = False
             for k in range(done, done + steps):
@@ -238,3 +251,27 @@ def test_fuzzed_switches_match_the_oracle(seed):
         i1, i2 = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
         assert np.abs(k1[i1] - k2[i2]).max() <= 1e-9 * max(np.abs(k2).max(), 1e-300), what
         assert np.abs(g1[i1] - g2[i2]).max() <= 1e-8 * max(np.abs(g2).max(), 1e-300), what
+    if len(p) >= 200 and shape in ("box", "sheet", "line", "clusters"):
+        # the same switches on slabs of ONE handle (two or three, along the longest axis): mDBC ghost nodes in a neighbour's slab,
+        # the moving group across a cut, shifting and the kernel sums of particles whose neighbours are ghost rows
+        nd = 2 + seed % 2
+        try:
+            dd = make_engine(p, s, device_float_bytes=8, devices=[0] * nd)
+        except Exception as exc:                        # too few cell columns for the slabs: a planning error, with a text
+            assert "slab" in str(exc) or "devices" in str(exc) or "columns" in str(exc), exc
+            return
+        if getattr(p, "geometries", None) is not None:
+            dd.set_motions(p.geometries)
+        for steps in (2, 3):
+            pd = dd.advance(1e9, max_steps=steps)
+        assert (pd.iteration, pd.n_rebuilds, pd.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter), what
+        np.testing.assert_array_equal(dd.download(("ID",))["ID"], eng.download(("ID",))["ID"], err_msg=what)
+        d = _by_id(dd.download())
+        assert np.abs(d["Density"] - o["Density"]).max() < 1e-8 * np.abs(o["Density"]).max(), what
+        assert np.abs(d["Position"] - o["Position"]).max() < 1e-9 * scale + 1e-15 * np.abs(o["Position"]).max(), what
+        assert np.abs(d["Velocity"] - o["Velocity"]).max() < 1e-8 * max(np.abs(o["Velocity"]).max(), 1e-300), what
+        if s.SimMetaData.KMode is StoreKernelOutput:
+            k3, g3 = dd.kernel_output()
+            i3 = np.argsort(dd.download(("ID",))["ID"], kind="stable")
+            assert np.abs(k3[i3] - k2[i2]).max() <= 1e-9 * max(np.abs(k2).max(), 1e-300), what
+            assert np.abs(g3[i3] - g2[i2]).max() <= 1e-8 * max(np.abs(g2).max(), 1e-300), what

@@ -3,7 +3,7 @@
 #
 #   stage 1 (HERE, no GPU: hipcc cross-compiles):   tools/reproduce_round3.sh build
 #   stage 2 (on an MI355X box, e.g. through gpurun): tools/reproduce_round3.sh run [what ...]
-#       what = pipe | deep | scanpf | queue | mask | diag | f16 | small | sizes | final     (default: all, ≈25 GPU-minutes)
+#       what = pipe | deep | scanpf | queue | mask | diag | f16 | small | sizes | vsr2 | final     (default: all, ≈30 GPU-minutes)
 #
 # Every table of profiles/r03_pair_loop_experiments.md names the variant builds it compares; the builds are interleaved by
 # tools/bench_libs.py so that box-to-box and clock drift hit all of them alike.  Results land under gpurun_out/repro/.
@@ -19,13 +19,17 @@ if [ "${1:-}" = "build" ]; then
     "maskstore:-DSPHMI_MASK_STORE=1" "f16scan:-DSPHMI_F16_SCAN=1" \
     "diag1:-DSPHMI_DIAG=1" "diag2:-DSPHMI_DIAG=2" "diag3:-DSPHMI_DIAG=3" "diag4:-DSPHMI_DIAG=4" "diag5:-DSPHMI_DIAG=5" \
     "p2off:-DSPHMI_PIPE2=0" "lds:-DSPHMI_LDS_STAGE=1"
+  python tools/prebuild_variants.py "f64h:-DSPHMI_PIPE_F64=1 -DSPHMI_TPB_F64=1" "f64a:-DSPHMI_PIPE_F64=0 -DSPHMI_TPB_F64=1" "f64b:-DSPHMI_PIPE_F64=1 -DSPHMI_TPB_F64=0" "f64c:-DSPHMI_PIPE_F64=0 -DSPHMI_TPB_F64=0"
+  # round 2's tree next to this one (its own Python package and library): build/r2tree
+  rm -rf build/r2tree && mkdir -p build/r2tree && git archive 015ef3e~1 | tar -x -C build/r2tree && cp tools/bench_variants.py build/r2tree/tools/ \
+    && (cd build/r2tree && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wno-unused-function -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form sphexample_amd/csrc/sphmi_engine.hip -o sphexample_amd/libsphmi.so)
   gcc -shared -fPIC -O1 -o build/libaborttrace.so tools/abort_trace.c
   mkdir -p tools/ubench/bin && hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/dep_chain tools/ubench/dep_chain.hip
   exit 0
 fi
 [ "${1:-}" = "run" ] || { sed -n 2,11p "$0"; exit 1; }
 shift
-what=${*:-pipe deep scanpf queue mask diag f16 small sizes final}
+what=${*:-pipe deep scanpf queue mask diag f16 small sizes vsr2 final}
 out=gpurun_out/repro; mkdir -p $out
 B="python tools/bench_libs.py"
 for w in $what; do
@@ -44,6 +48,9 @@ for w in $what; do
             ./tools/ubench/bin/dep_chain > $out/dep_chain.txt ;;
     sizes)  for dp in 0.0115 0.0085 0.0067 0.0057 0.005 0.003 0.002125; do python bench.py --dp $dp --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null \
               | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dp $dp', j['config']['particles'], j['value'], j['ms_per_step'])"; done > $out/sizes.txt ;;
+    vsr2)   python tools/bench_variants.py 200 > $out/variants_head.txt 2>/dev/null
+            (cd build/r2tree && python tools/bench_variants.py 200 > $ROOT/$out/variants_round2.txt 2>/dev/null)
+            for v in f64h f64a f64b f64c; do SPHMI_LIB=$ROOT/build/variants/libsphmi_$v.so python tools/bench_f64.py 100 2>/dev/null; done > $out/f64_switches.txt ;;
     final)  python bench.py > $out/bench.json 2> $out/bench.err
             python bench.py --steps 20 --warmup 5 > $out/bench_driver_window.json 2>/dev/null
             bash tools/profile_round.sh r03 > /dev/null 2>&1
