@@ -44,31 +44,53 @@ static thread_local std::string g_create_error;
 // directly, and so is everything the engine allocates with hipHostMalloc.
 struct HostBounce {
     static constexpr size_t kBytes = size_t(16) << 20;
+    static constexpr int kSlots = 8;                       // a ring of 2 MB pieces: the copy engine fills one while the host empties another
+    static constexpr size_t kSlot = kBytes / kSlots;
     char* p = nullptr;
+    hipEvent_t ev[kSlots] = {};
     HostBounce() = default;
     HostBounce(const HostBounce&) = delete;
     HostBounce& operator=(const HostBounce&) = delete;
-    ~HostBounce() { if (p) (void)hipHostFree(p); }
-    void ensure() { if (!p) HC(hipHostMalloc((void**)&p, kBytes)); }
-    // device → pageable host; the data are in `dst` on return (the stream has been synchronised)
+    ~HostBounce() {
+        if (p) (void)hipHostFree(p);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    void ensure() {
+        if (p) return;
+        HC(hipHostMalloc((void**)&p, kBytes));
+        for (auto& e : ev) HC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // device → pageable host; the data are in `dst` on return.  Piece k travels while piece k − 1 … is copied out of the ring
+    // (1 M particles, every field into plain numpy arrays: 8.0 ms with one piece at a time, round 2's direct copies 3.3 ms).
     void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
         ensure();
-        for (size_t off = 0; off < bytes; off += kBytes) {
-            const size_t n = std::min(kBytes, bytes - off);
-            HC(hipMemcpyAsync(p, (const char*)src + off, n, hipMemcpyDeviceToHost, s));
-            HC(hipStreamSynchronize(s));
-            memcpy((char*)dst + off, p, n);
+        const size_t pieces = (bytes + kSlot - 1) / kSlot;
+        size_t out = 0;                                    // pieces already handed to the caller
+        auto hand_out = [&]() {
+            HC(hipEventSynchronize(ev[out % kSlots]));
+            memcpy((char*)dst + out * kSlot, p + (out % kSlots) * kSlot, std::min(kSlot, bytes - out * kSlot));
+            out += 1;
+        };
+        for (size_t k = 0; k < pieces; ++k) {
+            if (k - out == (size_t)kSlots) hand_out();
+            HC(hipMemcpyAsync(p + (k % kSlots) * kSlot, (const char*)src + k * kSlot, std::min(kSlot, bytes - k * kSlot), hipMemcpyDeviceToHost, s));
+            HC(hipEventRecord(ev[k % kSlots], s));
+            if (k > out) hand_out();                       // (keeps one piece in flight behind the one being copied out)
         }
+        while (out < pieces) hand_out();
     }
-    // pageable host → device; `src` may be reused on return (the stream has been synchronised)
+    // pageable host → device; `src` may be reused on return (every piece has left the ring)
     void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
         ensure();
-        for (size_t off = 0; off < bytes; off += kBytes) {
-            const size_t n = std::min(kBytes, bytes - off);
-            memcpy(p, (const char*)src + off, n);
-            HC(hipMemcpyAsync((char*)dst + off, p, n, hipMemcpyHostToDevice, s));
-            HC(hipStreamSynchronize(s));
+        const size_t pieces = (bytes + kSlot - 1) / kSlot;
+        for (size_t k = 0; k < pieces; ++k) {
+            if (k >= (size_t)kSlots) HC(hipEventSynchronize(ev[k % kSlots]));       // the piece that used this slot has reached the device
+            const size_t n = std::min(kSlot, bytes - k * kSlot);
+            memcpy(p + (k % kSlots) * kSlot, (const char*)src + k * kSlot, n);
+            HC(hipMemcpyAsync((char*)dst + k * kSlot, p + (k % kSlots) * kSlot, n, hipMemcpyHostToDevice, s));
+            HC(hipEventRecord(ev[k % kSlots], s));
         }
+        HC(hipStreamSynchronize(s));
     }
 };
 
@@ -206,7 +228,7 @@ struct Engine final : EngineBase {
     // waves per tile by tile count (measured with the paired two-wave launches and sixteen classes, updates/s WPT 2 / WPT 1:
     // 2 481 tiles 8.03 / 7.16e8, 3 454: 8.47 / 8.22, 5 050: 9.19 / 9.02, 6 985: 9.62 / 9.80, 9 428: 9.76e8 / 1.022e9,
     // 11 689: 0.986 / 1.054e9, 16 527: 0.978 / 1.08e9)
-    static constexpr int kWptTiny = 512, kWptSmall = 1024;
+    static constexpr int kWptTiny = 448, kWptSmall = 1152;   // crossovers of tools/wpt_sweep.py (fp32, 3-D): 8 | 4 waves at ≈450 tiles, 4 | 2 at ≈1 150
     int kWptMedium = 6000;             // $SPHMI_WPT2_BELOW
     int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
     // domain decomposition: slab axis and the rank's cell-column range along it
