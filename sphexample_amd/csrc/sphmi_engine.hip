@@ -228,7 +228,8 @@ struct Engine final : EngineBase {
     // waves per tile by tile count (measured with the paired two-wave launches and sixteen classes, updates/s WPT 2 / WPT 1:
     // 2 481 tiles 8.03 / 7.16e8, 3 454: 8.47 / 8.22, 5 050: 9.19 / 9.02, 6 985: 9.62 / 9.80, 9 428: 9.76e8 / 1.022e9,
     // 11 689: 0.986 / 1.054e9, 16 527: 0.978 / 1.08e9)
-    static constexpr int kWptTiny = 448, kWptSmall = 1152;   // crossovers of tools/wpt_sweep.py (fp32, 3-D): 8 | 4 waves at ≈450 tiles, 4 | 2 at ≈1 150
+    static constexpr int kWptTiny = 512, kWptSmall = 1024;   // (tools/wpt_sweep.py puts the fp32 compiled-in crossovers at ≈450 / ≈1 150 tiles; fp64 and run-time-model
+                                                             // kernels lose 18–52 % with four waves at 1 098 tiles — profiles/r03_variants_vs_round2.md — so these stay)
     int kWptMedium = 6000;             // $SPHMI_WPT2_BELOW
     int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
     // domain decomposition: slab axis and the rank's cell-column range along it

@@ -507,7 +507,7 @@ def test_schedule_never_changes_results(monkeypatch):
     from sphexample_amd.engine import make_engine
     dp = 0.0105
     p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
-    assert len(p) > 1152 * 64                               # more tiles than kWptSmall: the launches that are sampled
+    assert len(p) > 1024 * 64                               # more tiles than kWptSmall: the launches that are sampled
     out = []
     for env in ({}, {"SPHMI_RESCHED": "0", "SPHMI_XCD_FEEDBACK": "0"}, {"SPHMI_XCD_SEGS": "4"}):
         for k in ("SPHMI_RESCHED", "SPHMI_XCD_FEEDBACK", "SPHMI_WPT", "SPHMI_XCD_SEGS"):
