@@ -391,11 +391,26 @@ def main():
     copy_gbs = measured_copy_bandwidth(torch.device("cuda", device)) if rank == 0 else 0.0
     if scratch is not None and args.precondition_ms > 0:
         pre_steps = precondition(scratch, args.precondition_ms)
+    run_watchdog = None
+    if world > 1:
+        # the same for the steps themselves: a halo exchange or an allreduce whose peer never arrives waits for ever — say so and
+        # leave instead of sitting in the driver's time limit ($SPHMI_BENCH_RUN_TIMEOUT seconds, default 900)
+        import threading
+
+        def give_up_run():
+            print(f"[bench] rank {rank}: warm-up + {args.steps} steps did not finish within the time limit (a collective waiting for a peer?) — "
+                  f"try `bench.py --gpus {world} --single-process` or SPHMI_TRANSPORT=shm", file=sys.stderr, flush=True)
+            os._exit(4)
+        run_watchdog = threading.Timer(float(os.environ.get("SPHMI_BENCH_RUN_TIMEOUT", "900")), give_up_run)
+        run_watchdog.daemon = True
+        run_watchdog.start()
     if active:
         elapsed, prog, kern_ms, kern_launches, rebuild_s, rebuilds = timed_window(eng, args.warmup, args.steps, barrier, reduce_max)
     else:
         barrier(); torch.cuda.synchronize(); torch.cuda.synchronize(); barrier()
         reduce_max(0.0)
+    if run_watchdog is not None:
+        run_watchdog.cancel()
 
     if rank == 0:
         value = n_total * args.steps / elapsed
