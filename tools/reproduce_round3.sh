@@ -25,6 +25,7 @@ if [ "${1:-}" = "build" ]; then
     && (cd build/r2tree && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wno-unused-function -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form sphexample_amd/csrc/sphmi_engine.hip -o sphexample_amd/libsphmi.so)
   gcc -shared -fPIC -O1 -o build/libaborttrace.so tools/abort_trace.c
   mkdir -p tools/ubench/bin && hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/dep_chain tools/ubench/dep_chain.hip
+  hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o tools/ubench/bin/mask_pack tools/ubench/mask_pack.hip
   exit 0
 fi
 [ "${1:-}" = "run" ] || { sed -n 2,11p "$0"; exit 1; }
@@ -45,7 +46,8 @@ for w in $what; do
     f16)    $B 3 pipe1 f16scan > $out/f16scan.txt
             SPHMI_LIB=$ROOT/build/variants/libsphmi_f16scan.so python -m pytest tests/test_engine_gpu.py -q -k "single_force or k_step or waves_per_tile or cutoff or dam_break" > $out/f16scan_parity.txt 2>&1 ;;
     small)  for v in p2off pipe1; do echo "== $v"; SPHMI_LIB=$ROOT/build/variants/libsphmi_$v.so python tools/bench_examples.py 2000 2>&1 | grep fp32; done > $out/examples_pipe2.txt
-            ./tools/ubench/bin/dep_chain > $out/dep_chain.txt ;;
+            ./tools/ubench/bin/dep_chain > $out/dep_chain.txt
+            ./tools/ubench/bin/mask_pack > $out/mask_pack.txt ;;
     sizes)  for dp in 0.0115 0.0085 0.0067 0.0057 0.005 0.003 0.002125; do python bench.py --dp $dp --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null \
               | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dp $dp', j['config']['particles'], j['value'], j['ms_per_step'])"; done > $out/sizes.txt ;;
     vsr2)   python tools/bench_variants.py 200 > $out/variants_head.txt 2>/dev/null
