@@ -7,6 +7,7 @@
 //      the slots of lane half 0 and in rows 1 / 5 for those of half 1, leaves −(byte of half 0) in accumulator 0 and −(byte of
 //      half 1) in accumulator 1 of BOTH lanes of a column: exact integers, no lane exchange.
 // Compared against the v_alignbit construction the kernel uses today.  Prints the number of mismatches (0 = feasible).
+// (What became of it: profiles/r03_pair_loop_experiments.md §10 — exact here, but slower in the kernel and not exact on near-ties of the real chain.)
 // hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/mask_pack tools/ubench/mask_pack.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
