@@ -7,6 +7,9 @@
 import json, os, re, sys
 N = 1057738
 BENCH = {"predictor": "k_neighbor_force<float, 3, 1, 33, 1, 4>", "corrector": "k_neighbor_force<float, 3, 2, 33, 1, 4>"}
+if os.environ.get("PMC_KERNELS"):            # other kernels than the bench's: "predictor name|corrector name" ($PMC_FLOAT_BYTES = 8 for fp64 handles)
+    BENCH = dict(zip(("predictor", "corrector"), os.environ["PMC_KERNELS"].split("|")))
+FB = int(os.environ.get("PMC_FLOAT_BYTES", "4"))
 
 
 def parse(path):
@@ -66,10 +69,10 @@ def main():
     # MI355X_MICROARCH.md prescribes for gfx950 (the counter reports half of a 16 B/lane read stream)
     cal = {}
     if "k_init_reduce" in p and "FETCH_SIZE" in p["k_init_reduce"]:
-        known = 48.0 * N / 1024.0
+        known = 48.0 * (FB / 4) * N / 1024.0
         cal["k_init_reduce"] = {"known_read_KiB": round(known, 1), "FETCH_SIZE_KiB": p["k_init_reduce"]["FETCH_SIZE"], "ratio": round(p["k_init_reduce"]["FETCH_SIZE"] / known, 3)}
     if "k_eos" in p and "FETCH_SIZE" in p["k_eos"]:
-        known = 32.0 * N / 1024.0
+        known = 32.0 * (FB / 4) * N / 1024.0
         cal["k_eos"] = {"known_read_KiB": round(known, 1), "FETCH_SIZE_KiB": p["k_eos"]["FETCH_SIZE"], "ratio": round(p["k_eos"]["FETCH_SIZE"] / known, 3),
                         "WRITE_SIZE_KiB": p["k_eos"].get("WRITE_SIZE")}
     if cal:
@@ -80,7 +83,7 @@ def main():
         rec["traffic"] = {"calibration": cal, "fetch_correction": round(corr, 3),
                           "bytes_per_particle_per_launch_corrected": round((fetch * corr + write) / N, 1),
                           "bytes_per_particle_per_launch_uncorrected": round((fetch + write) / N, 1),
-                          "algorithmic_bytes_per_particle_per_launch": 77.0,
+                          "algorithmic_bytes_per_particle_per_launch": 77.0 if FB == 4 else 153.0,
                           "note": "bytes leaving the L2s (Infinity-Cache hits included): fabric traffic, not HBM traffic — the three state sets fit the 256 MB Infinity Cache"}
     json.dump(rec, open(out, "w"), indent=1)
     keys = ("launch_cycles", "valu_insts_per_tile", "valu_busy_frac", "waves_per_simd_mean", "wave_time_parked_on_waitcnt", "ta_busy_frac", "l1_hit_frac",
