@@ -228,9 +228,22 @@ struct Engine final : EngineBase {
     // waves per tile by tile count (measured with the paired two-wave launches and sixteen classes, updates/s WPT 2 / WPT 1:
     // 2 481 tiles 8.03 / 7.16e8, 3 454: 8.47 / 8.22, 5 050: 9.19 / 9.02, 6 985: 9.62 / 9.80, 9 428: 9.76e8 / 1.022e9,
     // 11 689: 0.986 / 1.054e9, 16 527: 0.978 / 1.08e9)
-    static constexpr int kWptTiny = 512, kWptSmall = 1024;   // (tools/wpt_sweep.py puts the fp32 compiled-in crossovers at ≈450 / ≈1 150 tiles; fp64 and run-time-model
-                                                             // kernels lose 18–52 % with four waves at 1 098 tiles — profiles/r03_variants_vs_round2.md — so these stay)
-    int kWptMedium = 6000;             // $SPHMI_WPT2_BELOW
+    // Waves per tile by the number of tiles of the launch (tools/wpt_sweep.py; profiles/r03_raw/wpt_sweep.txt): 8 below `tiny`, 4 below
+    // `small`, 2 below `medium`, else 1.  The crossovers depend on what a wave of the kernel holds: fp64 kernels and the run-time-model
+    // kernels have fewer waves per SIMD to begin with and lose them to extra waves per tile earlier.
+    //   fp32   512 / 1 024 / 6 000   (compiled-in models: measured crossovers ≈450 / ≈1 150, one and two waves level from 2.5 k tiles on.  Run-time
+    //                                 models: Laminar would take 1 300 / 3 000 (−4 … −7 %), LaminarSPS + Complex loses 22 % with four waves at
+    //                                 1 098 tiles — one table for all of them, so these stay)
+    //   fp64   400 /   400 / 2 000   (four waves never win; every model gains: 159 k particles −7 … −22 %, DucklingMDBC 216 → 167 µs per step)
+    int kWptMedium = -1;               // $SPHMI_WPT2_BELOW: overrides `medium` for every kernel
+    int waves_per_tile(int ntile, bool generic) const {
+        if (force_wpt > 0) return force_wpt;
+        int tiny = 512, small = 1024, medium = 6000;
+        if (sizeof(T) == 8) { tiny = 400; small = 400; medium = 2000; }
+        (void)generic;
+        if (kWptMedium >= 0) medium = kWptMedium;
+        return ntile < tiny ? 8 : (ntile < small ? 4 : (ntile < medium ? 2 : 1));
+    }
     int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
@@ -472,7 +485,7 @@ struct Engine final : EngineBase {
         // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip (per list: the
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
         const int ntile = list_tiles[list];        // fixed at the rebuild: the choice must not follow the measured run lengths
-        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptTiny ? 8 : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1)));
+        const int wpt = waves_per_tile(ntile, MODEL < 0);
         bool resched_after = false;
         if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && batch_step == 0) {
             // (the first step of a batch executes unless the batch starts with a rebuild request; then nothing is
@@ -744,7 +757,7 @@ struct Engine final : EngineBase {
     bool masks_ready() {
         if (!mask_possible()) return false;
         const int ntile = list_tiles[0];
-        const int wpt = force_wpt > 0 ? force_wpt : (ntile < kWptTiny ? 8 : (ntile < kWptSmall ? 4 : (ntile < kWptMedium ? 2 : 1)));
+        const int wpt = waves_per_tile(ntile, false);
         if (wpt != 1) return false;
         const size_t tiles = (size_t)((N + kWave - 1) / kWave);
         if (tiles > mstore_tiles) {

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Waves per tile against the size of the launch: µs per step of the 3-D dam-break lattice for $SPHMI_WPT = 1, 2, 4, 8 at sizes
-around the thresholds of Engine::launch_force_model (kWptTiny / kWptSmall / kWptMedium tiles).   python tools/wpt_sweep.py [fb]"""
+around the thresholds of Engine::launch_force_model (kWptTiny / kWptSmall / kWptMedium tiles).   python tools/wpt_sweep.py [fb] [laminar]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fb = sys.argv[1] if len(sys.argv) > 1 else "4"
+model = sys.argv[2] if len(sys.argv) > 2 else "default"
 code = r'''
 import sys, time
 sys.path.insert(0, %r)
@@ -11,6 +12,10 @@ from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
 from sphexample_amd.engine import make_engine
 dp, fb = float(sys.argv[1]), int(sys.argv[2])
 p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
+if sys.argv[3] == 'laminar':
+    import dataclasses
+    from sphexample_amd import Laminar
+    s = dataclasses.replace(s, SimViscosity=Laminar())
 e = make_engine(p, s, device_float_bytes=fb)
 e.advance(1e9, max_steps=30)
 best = 1e9
@@ -27,7 +32,7 @@ for dp in ("0.02", "0.016", "0.0135", "0.0115", "0.0100", "0.0085", "0.0075", "0
             env["SPHMI_WPT"] = w
         else:
             env.pop("SPHMI_WPT", None)
-        r = subprocess.run([sys.executable, "-c", code, dp, fb], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", code, dp, fb, model], env=env, capture_output=True, text=True)
         try:
             n, us = r.stdout.split(); row.append(f"{float(us):7.1f}")
         except Exception:
