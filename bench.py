@@ -3,6 +3,10 @@
 
   python bench.py --gpus 1 --steps K --warmup W                        (N = 1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W      (one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W                        (N > 1 WITHOUT a launcher: bench.py starts the N ranks
+                                                                        itself — the same torch.distributed.run command line —
+                                                                        and, if that cannot be done, falls into the one-process
+                                                                        handle below; `config.launch` says which)
   python bench.py --gpus N --single-process --steps K --warmup W       (ONE process, one handle over N GPUs: sphmi_create
                                                                         with a device list — what the reference's single
                                                                         Julia process would run)
@@ -52,7 +56,7 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 # 157.3 TFLOP/s fp32 vector peak when every instruction is an FMA; MI355X_MICROARCH.md).  The SQ "busy" counter charges a
 # quad-cycle per instruction instead (measured issue cost of most of this kernel's instructions: tools/ubench/valu_rates2.hip).
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
-COUNTER_RECORD = "profiles/r03_counters.json"
+COUNTER_RECORD = "profiles/r04_counters.json"
 DP1 = 0.00425
 BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 1, 4>", "corrector": "k_neighbor_force<float, 3, 2, 33, 1, 4>"}
 
@@ -262,6 +266,22 @@ def parallelism_text(world, info, n_dev, how):
     return base + tr + f"; {how}"
 
 
+def self_spawn(world, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks here, with the command
+    line the contract names (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py …), and pass their output through.  Returns the launcher's exit code."""
+    import subprocess
+    from sphexample_amd.rendezvous import free_port
+    port = free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, SPHMI_BENCH_LAUNCH=f"self-spawned: bench.py was started without a launcher (WORLD_SIZE unset) and ran "
+                                              f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node={world} --master-addr 127.0.0.1 "
+                                              f"--master-port {port} bench.py …` itself — one rank per GPU, as the contract's launch does")
+    print("[bench] no launcher (WORLD_SIZE unset): " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +298,18 @@ def main():
                     help="use the slab driver even for one rank (measures its host overhead)")
     args = ap.parse_args()
 
+    launch = os.environ.get("SPHMI_BENCH_LAUNCH", "")
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # Started like the N = 1 line (`python bench.py --gpus N …`): the ranks are started here; a launcher that cannot be
+        # started (or ranks that fail) leaves the one-process handle over the N GPUs — a line comes out either way.
+        rc = self_spawn(args.gpus, sys.argv[1:])
+        if rc == 0:
+            return
+        print(f"[bench] the self-spawned ranks ended with exit code {rc}: falling back to ONE process with one handle over "
+              f"{args.gpus} devices (--single-process)", file=sys.stderr, flush=True)
+        args.single_process = True
+        launch = (f"one process, one multi-device handle: bench.py was started without a launcher, its self-spawned "
+                  f"torch.distributed.run ranks failed (exit code {rc})")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -427,6 +459,7 @@ def main():
                                    f"example/Dambreak3d.jl parameters, fp32 kernels",
                        "particles": n_total, "particles_per_gpu": n_local,
                        "parallelism": parallelism_text(world, info, n_dev, how),
+                       "launch": launch or ("torch.distributed.run (RANK / WORLD_SIZE from the launcher)" if env_world > 1 else "one process"),
                        "rebuilds_in_window": int(rebuilds), "sim_time": prog.total_time,
                        "preconditioning": (f"{pre_steps} untimed steps of a scratch handle (≈{args.precondition_ms:.0f} ms of the same kernels) before the "
                                            f"{args.warmup} warm-up steps: clock governor out of its idle state; the measured handle ran {args.warmup} + {args.steps} "
@@ -438,7 +471,10 @@ def main():
                          "peak_measured_source": "1 GiB device-to-device copy (read + write bytes) on this GPU, measured in this run before the warm-up steps",
                          "traffic": traffic,
                          "traffic_source": COUNTER_RECORD + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes leaving the L2s, Infinity-Cache hits included)",
-                         "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms, "launches": kern_launches,
+                         "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms,
+                         # two launches per step (predictor, corrector); the average is taken over HIP-event pairs on every 8th
+                         # step (an event pair costs a stream bubble), each weighted 8: `launch_time_samples` is that weighted count
+                         "launches": 2 * args.steps, "launch_time_samples": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "valu": valu, "kernel_identity": identity},
             "value_excl_rebuild": n_total * args.steps / max(elapsed - rebuild_s, 1e-9),
             "rebuild_ms_in_window": rebuild_s * 1e3,

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SPHMI_ABI_VERSION 3
+#define SPHMI_ABI_VERSION 4
 #define SPHMI_MAX_DEVICES 16
 
 /* status codes */

@@ -25,11 +25,11 @@
 # are asserted against the library at first use (sphmi_create refuses a mismatching struct_size / abi_version).
 module SPHExampleMI355X
 
-using SPHExample, StaticArrays
+using SPHExample, StaticArrays, TimerOutputs
 import SPHExample.SPHCellList: SimulationLoop, next_output_time
 
 const LIB = get(ENV, "SPHMI_LIB", "libsphmi.so")
-const ABI_VERSION = Int32(3)
+const ABI_VERSION = Int32(4)
 
 struct SphmiConfig                       # struct sphmi_config, field for field (include/sphmi.h)
     struct_size::Int32; abi_version::Int32; dims::Int32; host_float_bytes::Int32; device_float_bytes::Int32
@@ -57,6 +57,8 @@ tag(::ZeroGravityLinearDensityDiffusion) = Int32(1); tag(::LinearDensityDiffusio
 mutable struct Session
     h::Ptr{Cvoid}
     prev_row::Vector{Int64}              # sphmi_download_permutation: row i now was row prev_row[i] (0-based) at the previous call
+    secs::Vector{Float64}                # sphmi_timers at the previous call (device seconds per phase), calls likewise
+    calls::Vector{Int64}
     perm::Vector{Int}                    # the same, 1-based
     ucells::Vector{Int64}
 end
@@ -68,8 +70,10 @@ function check(h, rc)
 end
 
 # the columns sphmi_download writes every interval: page-locked once (the arrays of the StructArray live for the whole run;
-# a multi-device handle accepts the call and stages through its own buffers)
-pin(h, a::Array) = isempty(a) || check(h, ccall((:sphmi_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), h, pointer(a), sizeof(a)))
+# a multi-device handle accepts the call and stages through its own buffers).  Pinning is an optimisation only — an array that
+# cannot be page-locked (locked-memory limit, a range the runtime already knows) is filled through the engine's bounce buffer
+# in sphmi_download_end — so a refusal is not an error.
+pin(h, a::Array) = isempty(a) || ccall((:sphmi_host_register, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), h, pointer(a), sizeof(a))
 
 function open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData::SimulationMetaData{D,T,S,K,B,L}, SimConstants, P, MotionDefinition) where {D,T,S,K,B,L}
     devs = parse.(Int32, split(get(ENV, "SPHMI_DEVICES", "0"), ","))
@@ -86,6 +90,7 @@ function open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData:
     href = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sphmi_create, LIB), Cint, (Ref{SphmiConfig}, Ref{Ptr{Cvoid}}), cfg, href))
     h = href[]
+    try                                   # (from here on the handle exists and is not yet in SESSIONS: an error must not leak it)
     for (group, m) in enumerate(MotionDefinition)                                  # RunSimulation's table, :846-850
         m === nothing && continue
         dir = Float64[m.Direction...]
@@ -102,7 +107,27 @@ function open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData:
         pin(h, a)
     end
     B <: SimpleMDBC && pin(h, P.GhostPoints)
-    return Session(h, Vector{Int64}(undef, N), Vector{Int}(undef, N), Vector{Int64}(undef, SimMetaData.ExportGridCells ? N * D : 0))
+    return Session(h, Vector{Int64}(undef, N), zeros(8), zeros(Int64, 8), Vector{Int}(undef, N), Vector{Int64}(undef, SimMetaData.ExportGridCells ? N * D : 0))
+    catch
+        ccall((:sphmi_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+        rethrow()
+    end
+end
+
+# The engine's phases under the reference's own TimerOutputs labels (src/SPHCellList.jl:748-798: "01 Update TimeStep", "02a Actual
+# Calculate IndexCounter", "04 Apply MDBC before Half TimeStep", "05 First NeighborLoop", "08 Second NeighborLoop"), nested under
+# "00 SimulationLoop" (:883) like the reference's: a section is opened empty, then credited with the DEVICE seconds and calls the
+# engine measured since the previous interval (`accumulated_data` is TimerOutputs' own field: ncalls, time in ns).
+function forward_timers!(to::TimerOutput, s::Session)
+    names = Vector{Cstring}(undef, 8); secs = zeros(8); calls = zeros(Int64, 8); n = Ref{Int32}(0)
+    check(s.h, ccall((:sphmi_timers, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Cstring}, Ptr{Float64}, Ptr{Int64}, Ref{Int32}), s.h, 8, names, secs, calls, n))
+    for k in 1:min(Int(n[]), 5)
+        label = unsafe_string(names[k])
+        @timeit to label nothing
+        d = (isempty(to.timer_stack) ? to : to.timer_stack[end])[label].accumulated_data
+        d.time += round(Int64, (secs[k] - s.secs[k]) * 1e9); d.ncalls += calls[k] - s.calls[k] - 1
+    end
+    s.secs .= secs; s.calls .= calls
 end
 
 # the reference's sort! permutes every column (src/SPHCellList.jl:142): the ones the engine does not carry follow by gather
@@ -121,6 +146,7 @@ function SimulationLoop(SimDensityDiffusion::BuiltinDDT, SimViscosity::BuiltinVi
     check(h, ccall((:sphmi_advance, LIB), Cint, (Ptr{Cvoid}, Float64, Int64, Ref{SphmiProgress}), h, Float64(next_output_time(SimMetaData)), -1, prog))
     SimMetaData.Iteration, SimMetaData.CurrentTimeStep, SimMetaData.TotalTime = prog.iteration, T(prog.last_dt), T(prog.total_time)
     SimMetaData.IndexCounter = prog.index_counter
+    forward_timers!(SimMetaData.HourGlass, s)
     GC.@preserve P s begin
         # the carried fields: snapshot on the device, copies on a second stream, straight into the StructArray's columns
         # (Cells: a Vector{CartesianIndex{D}} is N·D Int64; Type is a per-particle constant and follows the gather below)

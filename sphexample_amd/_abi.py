@@ -13,7 +13,7 @@ import numpy as np
 from .config import (NoMDBC, SimpleMDBC, SimulationConstants, SimulationMetaData, SPHDensityDiffusion,
                      SPHKernelInstance, SPHViscosity)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DEVICES = 16
 
 OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NUMERIC, ERR_DOMAIN, ERR_STATE = range(6)

@@ -46,6 +46,35 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     return out
 
 
+# Variant libraries the GPU test suite loads (built HERE by __graft_entry__.build(), git-ignored, shipped to the GPU box with
+# the snapshot): every test that loads a library other than LIB loads one of these, so the driver can rebuild what it runs.
+VARIANT_DIR = os.path.join(os.path.dirname(_HERE), "build", "variants")
+VARIANTS = {
+    # BASELINE config 3 names "LDS cell-tile staging on": the ablation build of DESIGN §4.5 (measured, off) — tests/test_lds_stage_variant_gpu.py
+    "ldsstage": ("-DSPHMI_LDS_STAGE=1",),
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(VARIANT_DIR, f"libsphmi_{name}.so")
+
+
+def build_variants(force: bool = False, verbose: bool = False) -> dict:
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    out = {}
+    for name, flags in VARIANTS.items():
+        path = variant_path(name)
+        fresh = os.path.exists(path) and all(os.path.getmtime(os.path.join(CSRC, f)) <= os.path.getmtime(path) for f in SOURCES + HEADERS)
+        if force or not fresh:
+            build(force=True, verbose=verbose, extra_flags=flags, out=path)
+            with open(path + ".flags", "w") as f:
+                f.write(" ".join(flags) + "\n")
+        out[name] = path
+    return out
+
+
 if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_variants(force="--force" in sys.argv, verbose=True))

@@ -98,7 +98,7 @@ struct HostBounce {
 enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT, PH_PASS1_EDGE, PH_PASS2_EDGE };
 static const char* kPhaseNames[PH_COUNT] = {
     "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
-    "05 First NeighborLoop (+06/07 half step)", "08 Second NeighborLoop (+09/10/11 full step)"};
+    "05 First NeighborLoop", "08 Second NeighborLoop"};      // (05 holds the fused 06 / 07 half step, 08 the fused 09 / 10 / 11 full step)
 
 // what the slab driver reads back after a batch of queued steps (Engine::dd_ctrl_sync)
 struct sphmi_dd_control {
@@ -193,20 +193,6 @@ struct Engine final : EngineBase {
         return fuse_ctrl && (cfg.mdbc == SPHMI_MDBC_NONE || mdbc_ok) && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0;
     }
     bool batch_fused = false;
-    // Accept masks handed from the predictor to the corrector of a step (ForceParams::mstore): plain handles whose launches run one
-    // wave per tile with the compiled-in model, 3-D, fp32.  max |v|² of the state travels in red_d[14 + rpar] (same parity
-    // as the reduction slots; a slot that was not zeroed in between only makes the skin wider).
-    int mask_store = SPHMI_MASK_STORE; // (experiment builds only: measured and off, sphmi_kernels.h; $SPHMI_MASK_STORE=0 switches it off there)
-    int mask_cap = 48;                 // chunks per tile kept ($SPHMI_MASK_CAP; a 3-D tile scans 27 on average, 45 at most in a filled lattice)
-    unsigned long long* mstore_d = nullptr; size_t mstore_tiles = 0;
-    bool mask_possible() const {
-        if (!(mask_store && D == 3 && sizeof(T) == 4 && cfg.mdbc == SPHMI_MDBC_NONE && motions.n == 0 && !dd_slab)) return false;
-        const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
-                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h && cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 &&
-                          cfg.kernel_output == SPHMI_KOUT_NONE && cfg.alpha != 0.0;
-        return dflt;
-    }
-    unsigned long long* vmx_slot(int par) const { return red_d + 14 + par; }
     static constexpr int kBatch = 16;  // most steps queued between two looks at the control flags
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
@@ -315,8 +301,6 @@ struct Engine final : EngineBase {
         HC(hipMemset(ctrl_d, 0, 2 * sizeof(StepCtrl)));
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
         if (const char* w = getenv("SPHMI_FUSE_MDBC")) fuse_mdbc = atoi(w);
-        if (const char* w = getenv("SPHMI_MASK_STORE")) mask_store = atoi(w);
-        if (const char* w = getenv("SPHMI_MASK_CAP")) mask_cap = std::max(1, atoi(w));
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 8 * 8));
@@ -359,7 +343,7 @@ struct Engine final : EngineBase {
         }
 #endif
         (void)hipFree(ctrl_d); (void)hipHostFree(ctrl_h);
-        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d); (void)hipFree(mstore_d);
+        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
         (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
         (void)hipFree(cellx_d); (void)hipFree(uc_tsum);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -405,6 +389,17 @@ struct Engine final : EngineBase {
         else { double d; memcpy(&d, &bits, 8); return d; }
     }
 
+    // The compiled-in model accumulates the accelerations in units of the viscosity constant Kv2 = 2·m₀·α·c₀·h and scales the
+    // sums back once (sphmi_kernels.h, kFoldKv2): that needs Kv2 — IN THE KERNEL'S TYPE — to be a normal number with a finite
+    // reciprocal.  A tiny α (or m₀·c₀·h product) underflows to 0 or a subnormal in fp32: such handles take the run-time variant,
+    // which multiplies by Kv2 per pair.  One predicate for the kernel choice and for inv_Kv2 (round-3 advice).
+    T kv2() const { return (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h); }
+    bool kv2_foldable() const { const T k = kv2(); return std::isnormal(k) && std::isfinite(T(1) / k) && std::isnormal(T(1) / k); }
+    bool compiled_in_model() const {
+        // the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
+        return cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR && cfg.shifting == SPHMI_SHIFT_NONE &&
+               cfg.H >= 2.0 * cfg.h && cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE && kv2_foldable();
+    }
     ForceParams<T> force_params(int src, int a, int out, double dt) const {
         ForceParams<T> P{};
         P.src0 = pk0[src]; P.src1 = pk1[src];
@@ -422,8 +417,8 @@ struct Engine final : EngineBase {
         P.Kddt = (T)(cfg.delta_phi * cfg.h * cfg.c0 * cfg.m0);
         P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
         P.eta2 = (T)cfg.eta2;
-        P.Kv2 = (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h);
-        P.inv_Kv2 = P.Kv2 != T(0) ? (T)(1.0 / (2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h)) : T(1);
+        P.Kv2 = kv2();
+        P.inv_Kv2 = kv2_foldable() ? T(1) / P.Kv2 : T(1);
         P.visc = cfg.viscosity; P.ddt = cfg.density_diffusion; P.shift = cfg.shifting == SPHMI_SHIFT_PLANAR;
         P.exact_cut = !(cfg.H >= 2.0 * cfg.h);
         P.kernel = cfg.kernel; P.kout = kout_d;
@@ -521,12 +516,7 @@ struct Engine final : EngineBase {
     }
     // list: 0 = interior tiles (all tiles when the handle has no slab), 1 = slab-edge tiles
     template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {
-        // the compiled-in variant: the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
-        const bool dflt = cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR &&
-                          cfg.shifting == SPHMI_SHIFT_NONE && cfg.H >= 2.0 * cfg.h &&
-                          cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE &&
-                          cfg.alpha != 0.0;      // (the compiled-in variant accumulates accelerations in units of the viscosity constant)
-        if (dflt) launch_force_model<PASS, kModelDefault>(P, list);
+        if (compiled_in_model()) launch_force_model<PASS, kModelDefault>(P, list);
         else      launch_force_model<PASS, kModelGeneric>(P, list);
     }
 
@@ -754,19 +744,6 @@ struct Engine final : EngineBase {
         if (resched0_pending) { resched0_pending = false; reschedule_from_work(0); }
         if (resched1_pending) { resched1_pending = false; reschedule_from_work(1); }
     }
-    bool masks_ready() {
-        if (!mask_possible()) return false;
-        const int ntile = list_tiles[0];
-        const int wpt = waves_per_tile(ntile, false);
-        if (wpt != 1) return false;
-        const size_t tiles = (size_t)((N + kWave - 1) / kWave);
-        if (tiles > mstore_tiles) {
-            (void)hipFree(mstore_d); mstore_d = nullptr; mstore_tiles = 0;
-            if (hipMalloc(&mstore_d, tiles * (size_t)mask_cap * kWave * 8) != hipSuccess) { (void)hipGetLastError(); mask_store = 0; return false; }
-            mstore_tiles = tiles;
-        }
-        return true;
-    }
     void enqueue_step() {
         serve_reschedules();
         const bool fused = batch_fused;
@@ -780,7 +757,6 @@ struct Engine final : EngineBase {
         if (fused_in_mdbc) { run_mdbc(nullptr, true); cpar ^= 1; rpar ^= 1; }   // :772, and the decisions of the step with it
         else if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());           // :772
         ForceParams<T> P1 = force_params(iA, iA, iH, 0.0);
-        const bool masks = fused && !fused_in_mdbc && masks_ready();
         if (fused_in_mdbc) {
             // decided by k_mdbc: the predictor reads the block it wrote and zeroes what that kernel could not
             P1.ctrl = ctrl_cur();
@@ -790,8 +766,6 @@ struct Engine final : EngineBase {
             P1.ctl_in = ctrl_d + cpar; P1.ctl_out = ctrl_d + (cpar ^ 1);
             P1.red_in = red_d + 4 * rpar; P1.red_zero = red_d + 4 * (rpar ^ 1);
             P1.ctl_h = cfg.h; P1.ctl_c0 = cfg.c0; P1.ctl_CFL = cfg.CFL;
-            if (masks) { P1.mstore = mstore_d; P1.mask_cap = mask_cap; P1.vmx_in = vmx_slot(rpar); }
-            if (mask_possible()) P1.vmx_zero = vmx_slot(rpar ^ 1);
             cpar ^= 1; rpar ^= 1;
         } else P1.ctrl = ctrl_cur();
         Ev e1 = begin_phase(PH_PASS1);
@@ -799,8 +773,6 @@ struct Engine final : EngineBase {
         end_phase(e1);
         progress_motion(0.0, ctrl_cur());                                      // :787
         ForceParams<T> P2 = force_params(iH, iA, iB, 0.0); P2.ctrl = ctrl_cur();      // (force_params: P2.red = the current slots)
-        if (masks) { P2.mstore = mstore_d; P2.mask_cap = mask_cap; }
-        if (mask_possible()) P2.vmx = vmx_slot(rpar);
         Ev e2 = begin_phase(PH_PASS2);
         launch_force<PASS_CORRECTOR>(P2);                                      // :789-798
         end_phase(e2);
@@ -924,7 +896,7 @@ struct Engine final : EngineBase {
         if (groups) bounce.h2d(grp[cur], groups, n * 8, stream);
         else HC(hipMemsetAsync(grp[cur], 0, n * 8, stream));
         HC(hipMemsetAsync(key[cur], 0, n * 4, stream));
-        HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); HC(hipMemsetAsync(red_d + 14, 0, 2 * 8, stream));
+        HC(hipMemsetAsync(red_d, 0, 8 * 8, stream));
         cpar = 0; rpar = 0;
         const int nb256 = (N + 255) / 256;
         hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
@@ -932,7 +904,7 @@ struct Engine final : EngineBase {
         hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0,
                            (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
         hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N,
-                           (T)cfg.h, (T)cfg.eta2, red_d, red_d + 14);
+                           (T)cfg.h, (T)cfg.eta2, red_d);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream));
         uploaded = true; stepped = false; have_grid = false; index_counter = 0;
@@ -984,11 +956,11 @@ struct Engine final : EngineBase {
             hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur]);
             const size_t n = (size_t)N;
             HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
-            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); HC(hipMemsetAsync(red_d + 14, 0, 2 * 8, stream)); cpar = 0; rpar = 0;
+            HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); cpar = 0; rpar = 0;
             const int nb256 = (N + 255) / 256;
             hipLaunchKernelGGL(k_iota, dim3(nb256), dim3(256), 0, stream, prow[cur], N);
             hipLaunchKernelGGL(k_eos<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], N, (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0));
-            hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d, red_d + 14);
+            hipLaunchKernelGGL(k_init_reduce<T>, dim3(nb256), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur], N, (T)cfg.h, (T)cfg.eta2, red_d);
             HC(hipGetLastError());
             HC(hipStreamSynchronize(stream));
         } catch (...) { release(); throw; }
@@ -1215,6 +1187,13 @@ struct Engine final : EngineBase {
         std::vector<unsigned long long> t((size_t)n);
         for (int64_t i = 0; i < n; ++i) t[i] = upload_index ? (unsigned long long)upload_index[i] : (unsigned long long)i;
         bounce.h2d(otag[cur], t.data(), (size_t)n * 8, stream);
+        // … and its row for sphmi_download_permutation is its row in the caller's arrays (the column travels with the sorts,
+        // the migration records and the ghost-layer records like every other)
+        if (upload_index) {
+            std::vector<int> rows((size_t)n);
+            for (int64_t i = 0; i < n; ++i) rows[(size_t)i] = (int)upload_index[i];
+            bounce.h2d(prow[cur], rows.data(), (size_t)n * 4, stream);
+        }
     }
     // ProgressMotion of the queued step (src/SPHCellList.jl:765,787) on owned particles AND ghost copies — a prescribed
     // motion is the same function of time on every rank — before the halo of the pass is packed
@@ -1249,7 +1228,7 @@ struct Engine final : EngineBase {
         if (n <= 0) return;
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           ghost[cur], id[cur], grp[cur], otag[cur], type[cur], idx_dev, (int)n, buf_dev);
+                           ghost[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], idx_dev, (int)n, buf_dev);
         HC(hipGetLastError());
     }
     void dd_kill(const int32_t* idx_dev, int64_t n) {
@@ -1268,7 +1247,7 @@ struct Engine final : EngineBase {
         if ((int64_t)N + n > cap) throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: rank capacity exceeded (too many arrivals)");
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_append<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           ghost[cur], id[cur], grp[cur], otag[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
+                           ghost[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
         HC(hipGetLastError());
         N += (int)n;
     }
@@ -1385,9 +1364,9 @@ struct sphmi_handle { sphmi::EngineBase* e; };
 
 extern "C" {
 
-static_assert(SPHMI_ABI_VERSION == 3, "update the text of sphmi_backend_info");
+static_assert(SPHMI_ABI_VERSION == 4, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
-    return "sphmi abi 3 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+    return "sphmi abi 4 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
            "counting-sort cell list, mDBC, moving bodies, shifting | multi-device handles: slabs over device copies / RCCL "
            "(RCCL transport not yet run with more than one rank) | no CPU fallback";
 }

@@ -52,98 +52,29 @@ template <class V> struct Half {
 };
 
 constexpr int kWave = 64;
-#ifndef SPHMI_SEQ_BLOCKS
-#define SPHMI_SEQ_BLOCKS 1
-#endif
-#ifndef SPHMI_QUEUE
-#define SPHMI_QUEUE 0           // per-lane queue of non-empty 32-candidate accept masks (entries); 0 = by kernel variant, below
-#endif
-#ifndef SPHMI_QUEUE_SLACK
-#define SPHMI_QUEUE_SLACK 1     // a full queue is consumed down to QUEUE − 1 − SLACK entries before scanning goes on
-#endif
-// Queue depth.  A simulation of the queues on real tiles and the loop counters of the kernel agree: with 8
-// entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the pair-loop iterations (the bound set by the
-// lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.  LDS pays for the depth —
-// 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32): 8 → 1.013e9 /
-// –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
+// Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles
+// and the loop counters of the kernel agree: with 8 entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the
+// pair-loop iterations (the bound set by the lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.
+// LDS pays for the depth — 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32):
+// 8 → 1.013e9 / –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
 // 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
 // The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
 // Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues.
-#ifndef SPHMI_QUEUE_C
-#define SPHMI_QUEUE_C SPHMI_QUEUE   // the same for the corrector pass alone
-#endif
-template <class T, int PASS, int WPT = 1> constexpr int queue_entries() {
-    constexpr int q = PASS == 2 ? (SPHMI_QUEUE_C) : (SPHMI_QUEUE);
-    return q > 0 ? q : (WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12));
-}
+template <class T, int WPT = 1> constexpr int queue_entries() { return WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12); }
+constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
 
-// Round-3 switches of the pair loop (defaults = what was measured best; 0 restores the round-2 code for the ablation runs)
-#ifndef SPHMI_ROLE_ENTRIES
-#define SPHMI_ROLE_ENTRIES 0    // the i / j role of a pair (density-diffusion orientation, Q4) rides in the queue entry: no index compares per pair.
-                                // MEASURED AND OFF: −3 vector instructions per pair, but the own-row chunks push up to four entries (earlier drains,
-                                // more refills): 1.058 → 1.020e9 updates/s alone, 1.067 → 1.036e9 on top of the other three (gpurun_out/r3_sweep1.txt)
-#endif
-#ifndef SPHMI_PROD_RCP
-#define SPHMI_PROD_RCP 1        // 1/(r²+η²) and 1/((r²+η²)(ρ̄ᵢ+ρ̄ⱼ)) from ONE v_rcp_f32 of the product (fp32 kernels)
-#endif
-#ifndef SPHMI_KV2_FOLD
-#define SPHMI_KV2_FOLD 1        // the viscosity constant folded into the lane constants: accelerations accumulated in units of Kv2
-#endif
+// Build switches that remain.  Everything else that rounds 2 and 3 measured and left off (role bits in the queue entries, half
+// prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the f16 distance matrix, the predictor's masks handed to the
+// corrector, the sign bits on the matrix pipe) lives as patches under profiles/ (r03_raw/mask_mfma_experiment.patch,
+// r04_retired_switches.patch) with its figures in profiles/r03_pair_loop_experiments.md — not in this file.
 #ifndef SPHMI_LDS_STAGE
 #define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
-#endif
-#ifndef SPHMI_PREFETCH
-#define SPHMI_PREFETCH 0        // packet 0 of the NEXT neighbour is gathered before the arithmetic of the current one (its registers are free by
-                                // then: the four values taken from packet 0 are the first thing a pair computes); packet 1 follows from the same line
-#endif
-#ifndef SPHMI_PIPE
-#define SPHMI_PIPE 1            // the pair loop is software-pipelined by ONE address: the queue refill (LDS read), the bit walk and the record offset
-                                // of the NEXT neighbour are worked out while the two gathers of the current one are in flight (no further load in
-                                // flight, one more register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links
-#endif
-#ifndef SPHMI_PIPE_F64
-#define SPHMI_PIPE_F64 2        // … in fp64 kernels: 0 never, 1 always, 2 in the kernels of two waves per tile only.  Measured (µs per step, compiled-in /
-                                // run-time models): 158 k particles (two waves per tile) 360 / 462 with, 370 / 475 without; 470 k (one wave) 964 / 1070 with,
-                                // 895 / 987 without; 1.06 M 1960 / 2217 with, 1906 / 2071 without — one more register pair costs the run-time-model
-                                // corrector its third wave per SIMD (173 registers against 159)
-#endif
-#ifndef SPHMI_PIPE2
-#define SPHMI_PIPE2 1           // the same pipelining for the two-pair loop of the lone-wave kernels (four or eight waves per tile)
+                                // (build/variants/libsphmi_ldsstage.so: __graft_entry__.build(); parity: tests/test_lds_stage_variant_gpu.py)
 #endif
 #ifndef SPHMI_DIAG
-#define SPHMI_DIAG 0            // 1 / 2: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers
-#endif
-#ifndef SPHMI_F16_SCAN
-#define SPHMI_F16_SCAN 0        // the distance matrix of phase 1 from ONE v_mfma_f32_32x32x16_f16 per 32×32 block (32 cycles) instead of three
-                                // v_mfma_f32_32x32x2_f32 (64 cycles each: the f32-input form runs at the vector rate); coordinates split into
-                                // hi + lo halves, sixteen products per pair.  MEASURED AND OFF: parity-green, the matrix pipe's share of a launch
-                                // falls from 27 % to 4 %, the launch does not get shorter (0.4786 → 0.4810 ms; under the profiler predictor
-                                // −0.7 %, corrector −4 % at 83 registers) — the matrix pipe was never what a wave waits for
-#endif
-#ifndef SPHMI_DEEP
-#define SPHMI_DEEP 0            // bit 0: predictor, bit 1: corrector — TWO neighbours in flight per lane: the gathers of the next pair are issued before the
-                                // arithmetic of the current one, into a second set of eight registers (the predictor has them to spare: LDS, not
-                                // registers, sets its six waves per SIMD).  Idle lanes pair their target with itself (every term exactly zero), so
-                                // neither the gathers nor the arithmetic sit under an execution mask and the wait is vmcnt(2)
-#endif
-#ifndef SPHMI_MASK_STORE
-#define SPHMI_MASK_STORE 0      // EXPERIMENT BUILD: the predictor hands its accept masks to the corrector of the same step (ForceParams::mstore).
-                                // MEASURED AND OFF: bit-identical results (tests/test_mask_handover_gpu.py on a -DSPHMI_MASK_STORE=1 build), the
-                                // corrector runs 17 % fewer vector instructions — and 10 % LONGER (0.513 → 0.564 ms at 1.06 M particles; the
-                                // predictor 0.494 → 0.522): 224 MB of masks per launch come back from beyond the L2s, one dependent load per
-                                // chunk, and the in-order vmcnt makes every gather behind a mask load (or store) wait for it
-#endif
-#ifndef SPHMI_SCAN_PF
-#define SPHMI_SCAN_PF 0         // phase 1 software-pipelined (one wave per tile): bit 0 = the candidate coordinates of the NEXT chunk of a row are
-                                // requested before the current chunk is worked on (3 registers), bit 1 = the index ranges of the NEXT row are
-                                // requested before the current row is scanned (2 registers)
-#endif
-#ifndef SPHMI_SCAN_PF_C
-#define SPHMI_SCAN_PF_C SPHMI_SCAN_PF   // the same switch for the corrector pass (its kernel has fewer registers to spare)
-#endif
-#ifndef SPHMI_SETPRIO
-#define SPHMI_SETPRIO 0         // s_setprio in the pair loop: 1 = raised while the address is formed and the gathers are issued, 2 = raised during the arithmetic
+#define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
+                                // neither / adjacent lanes sharing a gathered record
 #endif
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
@@ -249,16 +180,6 @@ struct ForceParams {
     // (mdbc_zero[0..2]; slot 3 holds k_mdbc's flag of this step) and the flag slot of the other set (mdbc_flag_zero), which the
     // next step's k_mdbc and corrector fill.  Null: nothing to do.
     unsigned long long* mdbc_zero; unsigned long long* mdbc_flag_zero;
-    // Accept masks handed from the predictor to the corrector of the SAME step (plain handles, one wave per tile, 3-D fp32
-    // compiled-in model): the predictor tests against H + vmax·Δt — no pair can come closer than that within the half step —
-    // and stores the trimmed 64-bit mask of every chunk it scans, [tile][chunk][lane]; the corrector replays the chunk
-    // sequence (same cell list, same ranges) and LOADS the masks instead of running phase 1 (matrix cores + 64 sign
-    // extractions + trimming: ≈100 of its ≈119 vector instructions per chunk).  Chunks beyond mask_cap are scanned as before.
-    unsigned long long* mstore;            // null: off
-    int mask_cap;                          // chunks per tile kept
-    const unsigned long long* vmx_in;      // predictor: max |v|² of the state it reads (bit pattern; filled by the previous corrector / the upload)
-    unsigned long long* vmx_zero;          // predictor, block 0: the slot this step's corrector fills
-    unsigned long long* vmx;               // corrector: max |v|² of the state it writes
     const int* order;    // tile schedule: block b of XCD run x = b % 8 processes tile order[part[x] + b / 8]
     const int* part;     // [0..7] first entry of run x in order[], [8..15] tiles in run x
     int* tile_work;              // sampled launch: tile_work[tile] = 9·pair-loop iterations + 16·chunks of this tile (of its slowest wave × WPT), or null
@@ -272,7 +193,7 @@ struct ForceParams {
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
     T nhinv_half, Cfac, big;   // −1/(2h);  −8·Cgw: ∇W factor = Cfac·u³ with u = clamp(1 − q/2);  2⁴⁰ (step01)
-    T inv_Kv2;                 // 1 / Kv2 (SPHMI_KV2_FOLD; 1 when Kv2 = 0: such handles run the run-time variant)
+    T inv_Kv2;                 // 1 / Kv2 (the compiled-in model accumulates in units of Kv2; handles whose Kv2 is not a normal number run the run-time variant)
     T alphaD, tens_eps, inv_Wdx;   // CubicSpline: αD, CubicSpline.eps, 1 / W(q := dx) (src/SPHKernels.jl:114-126)
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
@@ -283,25 +204,12 @@ struct ForceParams {
 // small helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float  fast_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }
-#ifndef SPHMI_F64_DIV
-#define SPHMI_F64_DIV 0
-#endif
-#ifndef SPHMI_F64_NEWTON
-#define SPHMI_F64_NEWTON 1
-#endif
 __device__ __forceinline__ double fast_rcp(double x) {
-#if SPHMI_F64_DIV
-    return 1.0 / x;
-#else
     // v_rcp_f64 (≈2⁻²⁶ relative) + ONE Newton step: ≈2⁻⁵² for the normal, positive arguments of the pair loop (a second
-    // step, -DSPHMI_F64_NEWTON=2, makes it ≤ 1 ulp and costs 4 % of the fp64 kernel; parity to the oracle is the same)
+    // step makes it ≤ 1 ulp and costs 4 % of the fp64 kernel; parity to the oracle is the same; IEEE division: 2.3e8 → 4.7e8 with this)
     double y = __builtin_amdgcn_rcp(x);
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-#if SPHMI_F64_NEWTON > 1
-    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-#endif
     return y;
-#endif
 }
 __device__ __forceinline__ float  fast_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }   // (v_rsq_f64 + Newton: no faster)
@@ -329,13 +237,9 @@ __device__ __forceinline__ double min_raw(double a, double b) { return a < b ? a
 // u = clamp(a·b + 1, 0, 1) in ONE instruction (output modifier): with a = r, b = −1/(2h) this is 1 − q/2 clamped, and
 // (q − 2)³ of the Wendland gradient (src/SPHKernels.jl:85-86, q = clamp(r/h, 0, 2) of src/SPHCellList.jl:280) = −8u³
 __device__ __forceinline__ float fma1_clamp01(float a, float b) {
-#ifdef SPHMI_NO_ASM_CLAMP
-    return __builtin_fmaxf(__builtin_fmaf(a, b, 1.0f), 0.0f);
-#else
     // s_nop: `a` is the result of v_sqrt_f32 one instruction earlier, and a VALU instruction that reads the result of a
     // transcendental needs one wait state on gfx950 — the compiler pads its own instructions but cannot see into an asm
     float r; asm("s_nop 0\n\tv_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "s"(b)); return r;
-#endif
 }
 __device__ __forceinline__ double fma1_clamp01(double a, double b) {
     const double t = __builtin_fma(a, b, 1.0);
@@ -343,11 +247,7 @@ __device__ __forceinline__ double fma1_clamp01(double a, double b) {
 }
 // 1 for a positive (Fluid) signed density, 0 for a negative one — the MotionLimiter of the neighbour as a factor
 __device__ __forceinline__ float step01(float s, float big) {
-#ifdef SPHMI_NO_ASM_CLAMP
-    return s > 0.0f ? 1.0f : 0.0f;
-#else
     float r; asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(s), "s"(big)); return r;
-#endif
 }
 __device__ __forceinline__ double step01(double s, double) { return s > 0.0 ? 1.0 : 0.0; }
 
@@ -414,16 +314,6 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 // The neighbour + force kernel.
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-// two floats → one register of two halves, round towards zero (any rounding will do for a hi + lo split: lo takes what hi left)
-__device__ __forceinline__ unsigned pk_h2(float a, float b) { const h16x2 p = __builtin_amdgcn_cvt_pkrtz(a, b); return __builtin_bit_cast(unsigned, p); }
-__device__ __forceinline__ float lo_half_as_float(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[0]; }
-// v = hi + lo + O(2⁻²⁰·|v|): { hi, lo } in one register
-__device__ __forceinline__ unsigned split_hl(float v) { const unsigned h = pk_h2(v, 0.0f); return pk_h2(v, v - lo_half_as_float(h)); }
-// … and as { hi, hi }, { lo, lo }
-__device__ __forceinline__ void split_hh_ll(float v, unsigned& hh, unsigned& ll) { hh = pk_h2(v, v); const float r = v - lo_half_as_float(hh); ll = pk_h2(r, r); }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // v_permlane32_swap: returns { {p.lower, q.lower}, {p.upper, q.upper} } — the lane pattern both MFMA
@@ -436,7 +326,6 @@ __device__ __forceinline__ void swap_halves(unsigned& p, unsigned& q) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(p, q, false, false);
     p = r[0]; q = r[1];
 }
-
 
 // LDS hand-off inside ONE wave (ds operations of a wave execute in order; this only pins the compiler)
 __device__ __forceinline__ void wave_sync() {
@@ -456,27 +345,22 @@ __device__ __forceinline__ void wave_sync() {
 // TPB: tiles per block.  The TPB tiles of a workgroup are TPB consecutive entries of the XCD's run —
 // neighbouring tiles, whose candidate rows overlap by three quarters — and run on the four SIMDs of ONE compute unit,
 // so the rows are fetched into that unit's L1 once instead of by four units.
-#ifndef SPHMI_MIN_WAVES
-#define SPHMI_MIN_WAVES 0       // fp32 compiled-in-model kernels: waves per SIMD the register allocator must leave room for (0 = its own choice)
-#endif
 template <class T, int D, int PASS, int MODEL, int WPT, int TPB = 1>
 __global__ void __launch_bounds__(kWave * WPT * TPB)
-__attribute__((amdgpu_waves_per_eu((SPHMI_MIN_WAVES > 0 && sizeof(T) == 4 && MODEL >= 0 && D == 3) ? SPHMI_MIN_WAVES : 1, 8)))
+__attribute__((amdgpu_waves_per_eu(1, 8)))
 k_neighbor_force(const ForceParams<T> P) {
     static_assert(TPB == 1 || WPT <= 2, "several tiles per block: one or two waves per tile");
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
 #endif
     T step_dt, step_dt2;
-    [[maybe_unused]] unsigned long long vmax2_bits = 0;
     if (PASS == PASS_PREDICTOR && P.ctl_in != nullptr) {
         StepCtrl c = *P.ctl_in;
         const unsigned long long r0 = P.red_in[0], r1 = P.red_in[1], r2 = P.red_in[2], r3 = P.red_in[3];
         const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, P.ctl_h, P.ctl_c0, P.ctl_CFL);
-        if (SPHMI_MASK_STORE != 0 && P.mstore) vmax2_bits = *P.vmx_in;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             *P.ctl_out = c;
-            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; if (SPHMI_MASK_STORE != 0 && P.vmx_zero) *P.vmx_zero = 0; }
+            if (consumed) { P.red_zero[0] = 0; P.red_zero[1] = 0; P.red_zero[2] = 0; P.red_zero[3] = 0; }
         }
         if (!c.active) return;
         step_dt = (T)c.dt; step_dt2 = (T)c.dt2;
@@ -492,9 +376,8 @@ k_neighbor_force(const ForceParams<T> P) {
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    constexpr int QCAP = queue_entries<T, PASS, WPT>();         // per-lane queue of non-empty accept masks
-    constexpr bool kMaskIO = SPHMI_MASK_STORE != 0 && WPT == 1 && D == 3 && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY && SPHMI_LDS_STAGE == 0;
-    static_assert(QCAP >= 4 && SPHMI_QUEUE_SLACK >= 1 && SPHMI_QUEUE_SLACK <= QCAP - 1, "queue geometry");
+    constexpr int QCAP = queue_entries<T, WPT>();         // per-lane queue of non-empty accept masks
+    static_assert(QCAP >= 4 && kQueueSlack >= 1 && kQueueSlack <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[SPHMI_LDS_STAGE ? 1 : WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
     // SPHMI_LDS_STAGE: the two packets of the 64 candidates of the chunk being worked on, per wave (2 / 4 KB in fp32 / fp64)
@@ -562,10 +445,10 @@ k_neighbor_force(const ForceParams<T> P) {
     const T rm_a = rho_a * P.m0;
     // lane constants of the pair terms: −m₀/ρₐ (pressure), −2·δᵩhc₀m₀·MLₐ (density diffusion; ZeroGravityLinear has no
     // MotionLimiter factor), Pₐ − Cb/γ·… (corrector: Pₐ + P_b = Cbe·r_b⁷ + (Pₐ − Cbe))
-    // (SPHMI_KV2_FOLD: the compiled-in model accumulates a / (Kv2·Cfac) and the density sums / Cfac — the viscosity term loses its
+    // (the compiled-in model accumulates a / (Kv2·Cfac) and the density sums / Cfac — the viscosity term loses its
     // constant, the pressure term takes 1/Kv2 into its lane constant, ∇W's factor is the bare u³; the sums are scaled back once
     // after the loop; the host routes α = 0 to the run-time variant)
-    constexpr bool kFoldKv2 = SPHMI_KV2_FOLD && MODEL >= 0 && (MODEL & 15) == kViscArtificial && sizeof(T) == 4;
+    constexpr bool kFoldKv2 = MODEL >= 0 && (MODEL & 15) == kViscArtificial && sizeof(T) == 4;
     const T c_a = kFoldKv2 ? -P.m0 * inv_rho_a * P.inv_Kv2 : -P.m0 * inv_rho_a;
     const T Kd_a = (ddt == kDdtZeroGravityLinear || fluid_a) ? T(-2) * P.Kddt : T(0);
     const T PaC = P_a - P.Cbe;
@@ -592,16 +475,7 @@ k_neighbor_force(const ForceParams<T> P) {
     const float tt = txl * txl + tyl * tyl + tzl * tzl;
     float thr;
     {
-        float H2f = (float)P.H2;
-        if constexpr (kMaskIO && PASS == PASS_PREDICTOR) {
-            if (P.mstore) {
-                // the corrector meets the same pairs at xₙ⁺ = xₙ + vₙ·Δt/2·ML: two particles approach by at most 2·vmax·Δt/2 meanwhile
-                // (vmax over the whole state, rounded up)
-                const float vmax = fast_sqrt(__uint_as_float((unsigned)vmax2_bits)) * 1.00001f;
-                const float Hs = fast_sqrt(H2f) * 1.000001f + vmax * (float)step_dt * 1.00001f;
-                H2f = Hs * Hs;
-            }
-        }
+        const float H2f = (float)P.H2;
         const float Rm = fast_sqrt(wave_max(owned ? tt : 0.0f)) + 6.0f * (float)P.h;
         const float eps = 1e-5f + 1e-6f * (Rm * Rm) / H2f;
         thr = owned ? H2f * (1.0f + eps) - tt : -1e30f;
@@ -620,19 +494,8 @@ k_neighbor_force(const ForceParams<T> P) {
     T sum_c = 0, sum_d = 0;                             // Σ (1/ρ_b)·(∇W·vᵢⱼ) (continuity without ρₐm₀), Σ density diffusion
     constexpr int kRecShift = sizeof(T) == 4 ? 5 : 6;      // log2 of the record size
     const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
-    unsigned rmask = 0;              // role of the current queue entry: all ones = the target plays "i" (SPHMI_ROLE_ENTRIES, below)
     // `if_i` when the target plays "i", `if_j` otherwise
-    auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T {
-        if constexpr (SPHMI_ROLE_ENTRIES != 0 && SPHMI_LDS_STAGE == 0) {
-            if constexpr (sizeof(T) == 4) return __uint_as_float((rmask & __float_as_uint(if_i)) | (~rmask & __float_as_uint(if_j)));      // v_bfi_b32
-            else {
-                const unsigned long long m64 = ((unsigned long long)rmask << 32) | rmask;
-                return __longlong_as_double((long long)((m64 & (unsigned long long)__double_as_longlong(if_i)) | (~m64 & (unsigned long long)__double_as_longlong(if_j))));
-            }
-        } else return a_is_i ? if_i : if_j;
-    };
-    // (the pair physics takes xᵢⱼ and the fourth word of packet 0 instead of the packet: with SPHMI_PREFETCH the registers of packet 0
-    // are re-used by the gather of the NEXT neighbour as soon as those four values have been taken from them)
+    auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T { return a_is_i ? if_i : if_j; };
     auto pair_core = [&](const unsigned jr, const T dx, const T dy, const T dz, const T n0w, const V4& n1, const bool a_is_i) {
         const T r2 = (D == 3) ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
         T rho_b, rhon_b, s_b;
@@ -667,7 +530,7 @@ k_neighbor_force(const ForceParams<T> P) {
         const T inv_rho_b = fast_rcp(rho_b);
         // continuity, src/SPHCellList.jl:289-291 (both orientations give the same target term); ρₐm₀ after the loop
         sum_c += inv_rho_b * (fac * vdx);
-        constexpr bool kProdRcp = SPHMI_PROD_RCP && sizeof(T) == 4 && MODEL >= 0 && (MODEL & 15) == kViscArtificial;
+        constexpr bool kProdRcp = sizeof(T) == 4 && MODEL >= 0 && (MODEL & 15) == kViscArtificial;
         T inv_r2e, inv_r2e_rs = T(0);                          // 1/(r²+η²);  1/((r²+η²)(ρ̄ₐ+ρ̄_b)) (artificial viscosity)
         if constexpr (kProdRcp) {
             const T rs = rhon_a + rhon_b;
@@ -795,90 +658,39 @@ k_neighbor_force(const ForceParams<T> P) {
     int qn = 0;
     unsigned cbase = 0;              // record offset of the candidate at bit 0 of the current mask
     unsigned cm = 0;                 // unconsumed bits of the current mask
-    // SPHMI_ROLE_ENTRIES: which lanes' CURRENT entry holds pairs whose target plays "i" (orientation rule of the density diffusion,
-    // the target plays "i" iff j sorts before its cell, or after it inside it).  The role is a property of the
-    // ENTRY — phase 1 pushes the candidates of the target's own row split by role — so a lane keeps it as an all-ones / all-zeros
-    // word set at the refill (one arithmetic shift of the entry's second word: (record offset of bit 0) >> 1 with the role in
-    // bit 31) and SELECTS with it through v_bfi_b32: no index compares and no condition code per pair (3 of ≈64 vector instructions).
-    constexpr bool kRoleEntries = SPHMI_ROLE_ENTRIES != 0 && SPHMI_LDS_STAGE == 0;
     char* const s_qb = reinterpret_cast<char*>(s_q);
     // Phase 2 runs until no lane holds more than `keep` queued entries (`drain`: nor any fetched bit).
     // Lanes consume at their own pace: a lane fetches its next NON-EMPTY mask the moment its current one
     // is used up, so nobody waits for a neighbour lane and nobody spends an iteration on an empty mask.
-#ifndef SPHMI_TWO_PAIRS_MIN_WPT
-#define SPHMI_TWO_PAIRS_MIN_WPT 4
-#endif
-    // (measured, µs per step one → two pairs: 2-D dam break 35.1 → 32.5, Dambreak3d Dp0.02 84.8 → 76.6, MovingSquare2d 53.0 →
-    // 49.4; the 3-D run-time-model kernel at four waves per tile — DucklingMDBC — loses, 147.6 → 157.8: its corrector has no
-    // registers left for a second neighbour)
-    constexpr bool kTwoPairs = WPT >= 2 * SPHMI_TWO_PAIRS_MIN_WPT || (WPT >= SPHMI_TWO_PAIRS_MIN_WPT && (MODEL >= 0 || D == 2));
-#ifndef SPHMI_QFLAG
-#define SPHMI_QFLAG 1
-#endif
-    // SPHMI_PREFETCH state (persists between the bursts of the pair loop): the neighbour whose packet 0 is already on its way
-    constexpr bool kPrefetch = SPHMI_PREFETCH != 0 && !kTwoPairs && !kRoleEntries && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
-    [[maybe_unused]] bool pf_ok = false;
-    [[maybe_unused]] unsigned pf_jr = (unsigned)ac << kRecShift;      // nothing requested yet: the lane's own record (a pair that adds nothing)
-    [[maybe_unused]] V4 pf_n0 = q0;
-    // A lane with nothing to do pairs its target with ITSELF: xᵢⱼ = 0 and vᵢⱼ = 0 make every term of the compiled-in model exactly
-    // zero, so the loop needs no execution mask around the gathers — and with the two gathers of an iteration issued
-    // unconditionally the compiler knows how many are outstanding and waits for packet 1 with vmcnt(1), leaving the next
-    // neighbour's packet 0 in flight through the arithmetic.
-    const unsigned self_r = (unsigned)ac << kRecShift;
-    auto run_pairs_prefetch = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+    // Lone waves (a tile of four or eight waves = a launch too small to hide latency behind other waves) take TWO neighbours per
+    // iteration (measured, µs per step one → two pairs: 2-D dam break 35.1 → 32.5, Dambreak3d Dp0.02 84.8 → 76.6, MovingSquare2d
+    // 53.0 → 49.4; the 3-D run-time-model kernel at four waves per tile — DucklingMDBC — loses, 147.6 → 157.8: its corrector has
+    // no registers left for a second neighbour)
+    constexpr bool kTwoPairs = WPT >= 8 || (WPT >= 4 && (MODEL >= 0 || D == 2));
+    // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
+    // cell (j < cs_a) or after it inside it (a < j < ce_a)
+    auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+    // "current mask used up AND something queued" is ONE unsigned compare, cm < qf with qf = min(qn, 1): the 0 / 1 flag is kept up
+    // to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration.  The loop tests are
+    // computed once per iteration, at its END (a hand-rotated do … while: written top-tested the compiler copied six accumulators
+    // per iteration).
+    auto run_pairs_plain = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         unsigned qf = qn != 0 ? 1u : 0u;
-        if (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0) do {
-            work_it += 1;
-#ifdef SPHMI_STATS
-            st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pf_ok));
-#endif
-            // 1. the pair of this iteration: its packet 0 was requested an iteration (or a burst) ago; packet 1 is in the same line
-            const unsigned jr = pf_jr;
-            const V4 n1 = gather_packet(rs0, jr, 1, T());
-            const T dx = xa - pf_n0.x, dy = ya - pf_n0.y, dz = (D == 3) ? za - pf_n0.z : T(0), n0w = pf_n0.w;
-            __builtin_amdgcn_sched_barrier(0);
-            // 2. the next neighbour of this lane (its own record when it has none): refill when the mask is used up, request packet 0
+        bool more = qn != 0, have = cm != 0;
+        if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0) do {
             unsigned m = cm;
-            if (cm < qf) {
+            if (cm < qf) {      // fetch the next non-empty mask of MY queue
                 const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
                 m = ne.x; raddr = q_next(raddr); qn -= 1;
                 qf = min((unsigned)qn, 1u);
                 cbase = ne.y;
             }
-            cm = m & (m - 1);
-            pf_ok = m != 0;
-            pf_jr = pf_ok ? ((unsigned)__builtin_ctz(m) << kRecShift) + cbase : self_r;
-            pf_n0 = gather_packet(rs0, pf_jr, 0, T());
-            __builtin_amdgcn_sched_barrier(0);
-            // 3. the arithmetic of the current pair, while the next packet 0 is in flight
-            pair_core(jr, dx, dy, dz, n0w, n1, plays_i(jr));
-        } while (__builtin_amdgcn_ballot_w64(drain ? ((qf | cm) != 0u) | pf_ok : (qn > keep)) != 0);
-    };
-    auto run_pairs_plain = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        // (`more` / `have` are computed once per iteration, at its end, and serve both the exit test and the next refill)
-        // SPHMI_QFLAG: "current mask used up AND something queued" is ONE unsigned compare, cm < min(qn, 1); the 0 / 1 flag is
-        // kept up to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration
-        unsigned qf = qn != 0 ? 1u : 0u;
-        bool more = qn != 0, have = cm != 0;
-        if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0) do {
-            unsigned m = cm;
-            if (SPHMI_QFLAG ? (cm < qf) : (!have & more)) {      // fetch the next non-empty mask of MY queue
-                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
-                m = ne.x; raddr = q_next(raddr); qn -= 1;
-                if (SPHMI_QFLAG) qf = min((unsigned)qn, 1u);
-                if constexpr (kRoleEntries) { rmask = (unsigned)((int)ne.y >> 31); cbase = ne.y << 1; } else cbase = ne.y;
-            }
             work_it += 1;
 #ifdef SPHMI_STATS
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0));
 #endif
-            // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
-            // cell (j < cs_a) or after it inside it (a < j < ce_a)
-            auto plays_i = [&](const unsigned jr) { return kRoleEntries ? rmask != 0u : (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
             if constexpr (kTwoPairs) {
-                // Lone waves (a tile of four or eight waves = a launch too small to hide latency behind other waves): TWO
-                // neighbours per iteration, their four gathers in flight together; the pairs are still accumulated one after
+                // TWO neighbours per iteration, their four gathers in flight together; the pairs are still accumulated one after
                 // the other, in mask order, so the sums are those of the one-pair loop bit for bit.
                 const unsigned m1 = m & (m - 1);
                 cm = m1 & (m1 - 1);
@@ -896,33 +708,27 @@ k_neighbor_force(const ForceParams<T> P) {
             } else {
                 cm = m & (m - 1);                                    // (0 stays 0)
                 if (m != 0) {
-#if SPHMI_SETPRIO == 1
-                    __builtin_amdgcn_s_setprio(1);
-#endif
                     const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
                     const V4 n0 = gather_packet(rs0, jr, 0, T());
                     const V4 n1 = gather_packet(rs0, jr, 1, T());
-#if SPHMI_SETPRIO == 1
-                    __builtin_amdgcn_s_setprio(0);
-#elif SPHMI_SETPRIO == 2
-                    __builtin_amdgcn_s_setprio(1);
-#endif
                     pair(jr, n0, n1, plays_i(jr));
-#if SPHMI_SETPRIO == 2
-                    __builtin_amdgcn_s_setprio(0);
-#endif
                 }
             }
-            if (SPHMI_QFLAG) { more = (qf | cm) != 0u; have = false; } else { more = qn != 0; have = cm != 0; }
+            more = (qf | cm) != 0u; have = false;
         } while (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0);
     };
-    // SPHMI_PIPE: (pv, pjr) = the pair this lane takes NEXT (valid flag, record offset), worked out one iteration early; the state
-    // survives between the bursts of the pair loop like the queue itself
-    constexpr bool kPipe = SPHMI_PIPE != 0 && (sizeof(T) == 4 || SPHMI_PIPE_F64 == 1 || (SPHMI_PIPE_F64 == 2 && WPT == 2)) && !kTwoPairs && !kRoleEntries && !kPrefetch && SPHMI_LDS_STAGE == 0;
+    // The pair loop software-pipelined by ONE address: the queue refill (LDS read), the bit walk and the record offset of the NEXT
+    // neighbour are worked out while the two gathers of the current one are in flight (no further load in flight, one more
+    // register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links (1.0673 → 1.0999e9
+    // updates/s at C3).  (pv, pjr) = the pair this lane takes NEXT (valid flag, record offset); the state survives between the
+    // bursts of the pair loop like the queue itself.
+    // fp64 kernels: in the kernels of two waves per tile only.  Measured (µs per step, compiled-in / run-time models): 158 k
+    // particles (two waves per tile) 360 / 462 with, 370 / 475 without; 470 k (one wave) 964 / 1070 with, 895 / 987 without; 1.06 M
+    // 1960 / 2217 with, 1906 / 2071 without — one more register pair costs the run-time-model corrector its third wave per SIMD.
+    constexpr bool kPipe = (sizeof(T) == 4 || WPT == 2) && !kTwoPairs && SPHMI_LDS_STAGE == 0;
     [[maybe_unused]] bool pv = false;
     [[maybe_unused]] unsigned pjr = 0;
     auto run_pairs_piped = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
             work_it += 1;
@@ -962,13 +768,13 @@ k_neighbor_force(const ForceParams<T> P) {
             if (v) pair(jr, n0, n1, plays_i(jr));
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
-    // SPHMI_PIPE2: the two-pair loop with the addresses of the NEXT one or two neighbours worked out while the four gathers fly
-    // (compiled-in model only: the run-time variant's two-pair kernels — MovingSquare2d — lose 3 % with it, registers)
-    constexpr bool kPipe2 = SPHMI_PIPE2 != 0 && kTwoPairs && !kRoleEntries && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
+    // the two-pair loop with the addresses of the NEXT one or two neighbours worked out while the four gathers fly (compiled-in
+    // model only: the run-time variant's two-pair kernels — MovingSquare2d — lose 3 % with it, registers): 2-D dam break 32.0 →
+    // 30.2 µs per step, Dambreak3d Dp0.02 73.0 → 63.5
+    constexpr bool kPipe2 = kTwoPairs && SPHMI_LDS_STAGE == 0 && MODEL >= 0;
     [[maybe_unused]] bool pv2 = false;
     [[maybe_unused]] unsigned pjr2 = 0;
     auto run_pairs_piped2 = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
         unsigned qf = qn != 0 ? 1u : 0u;
         if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
             work_it += 1;
@@ -1000,49 +806,8 @@ k_neighbor_force(const ForceParams<T> P) {
             }
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
-    constexpr bool kDeep = ((SPHMI_DEEP >> (PASS == PASS_CORRECTOR ? 1 : 0)) & 1) != 0 && kPipe && MODEL >= 0 && sizeof(T) == 4 && PASS != PASS_FORCES_ONLY;
-    auto run_pairs_deep = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
-        unsigned qf = qn != 0 ? 1u : 0u;
-        // the next pair of this lane: refill when the mask is used up, lowest set bit, record offset
-        auto advance = [&]() {
-            unsigned m = cm;
-            if (cm < qf) {
-                const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
-                m = ne.x; raddr = q_next(raddr); qn -= 1;
-                qf = min((unsigned)qn, 1u);
-                cbase = ne.y;
-            }
-            cm = m & (m - 1);
-            pv = m != 0;
-            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
-        };
-        auto more = [&]() { return __builtin_amdgcn_ballot_w64(drain ? pv : (qn > keep)) != 0; };
-        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) == 0) return;
-        if (!pv) advance();                                  // lanes that had nothing when the last burst ended may have been pushed entries since
-        unsigned fjr, gjr; V4 f0, f1, g0, g1;
-        // (a lane without a pair takes its own record: xᵢⱼ = 0, vᵢⱼ = 0 — every term of the compiled-in model is exactly zero)
-        fjr = pv ? pjr : self_r; f0 = gather_packet(rs0, fjr, 0, T()); f1 = gather_packet(rs0, fjr, 1, T());
-        advance();
-        for (;;) {
-            work_it += 1;
-            if (more()) {
-                gjr = pv ? pjr : self_r; g0 = gather_packet(rs0, gjr, 0, T()); g1 = gather_packet(rs0, gjr, 1, T());
-                advance();
-                pair(fjr, f0, f1, plays_i(fjr));
-            } else { pair(fjr, f0, f1, plays_i(fjr)); break; }
-            work_it += 1;
-            if (more()) {
-                fjr = pv ? pjr : self_r; f0 = gather_packet(rs0, fjr, 0, T()); f1 = gather_packet(rs0, fjr, 1, T());
-                advance();
-                pair(gjr, g0, g1, plays_i(gjr));
-            } else { pair(gjr, g0, g1, plays_i(gjr)); break; }
-        }
-    };
     auto run_pairs = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         if constexpr (kPipe2) run_pairs_piped2(keep, drain);
-        else if constexpr (kDeep) run_pairs_deep(keep, drain);
-        else if constexpr (kPrefetch) run_pairs_prefetch(keep, drain);
         else if constexpr (kPipe) run_pairs_piped(keep, drain);
         else run_pairs_plain(keep, drain);
     };
@@ -1055,79 +820,12 @@ k_neighbor_force(const ForceParams<T> P) {
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
     const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
-#if SPHMI_F16_SCAN == 0
     float B0[2], B1[2], B2[2], A2;
     B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
     B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
-#endif
-#if SPHMI_F16_SCAN
-    // ---- SPHMI_F16_SCAN: the same matrix from the f16 matrix instruction (K = 16, 32 cycles) -----------------------------
-    // Tile-local coordinates scaled by sc = 16/H — or less, so that the reach of the tile stays below 192 and |c|² inside the half
-    // range; every coordinate is split into hi + lo halves (products of halves are exact in the fp32 accumulator), so that
-    // |c|² − 2c·t + |t|² − (sc·H)²·(1+ε)  is the sum of sixteen products:
-    //   lanes 0-31 (k 0…7):  cxh·m2xh  cxh·m2xl  cxl·m2xh  cxl·m2xl   cyh·m2yh  cyh·m2yl  cyl·m2yh  cyl·m2yl      (m2 = −2t)
-    //   lanes 32-63 (k 8…15): the same four for z,   cch·1   ccl·1   1·thh   1·thl                                (cc = |c|², th = |t|² − cut)
-    // ε = 3·10⁻⁴ + 2.5·10⁻⁵·R² + 0.03/(sc·H)²  (R = reach of the tile in units of H) covers the residual of the splits (2⁻²⁰ relative
-    // per value, both roundings towards zero), the fp32 accumulation and half-precision subnormals flushed by the matrix pipe (lo
-    // parts below 6·10⁻⁵ times a partner of at most 384).  An ordinary tile reaches 4–5 H: ε ≈ 10⁻³, 0.15 % more candidates for the
-    // pair loop; a tile of spray that spans 100 H gets ε ≈ 0.26.  The mask is a superset either way; the pair loop applies the exact cut.
-    constexpr bool kF16 = SPHMI_F16_SCAN != 0;
-    [[maybe_unused]] unsigned Bh[2][4] = {};
-    [[maybe_unused]] float hinv = 0.0f;
-    if constexpr (kF16) {
-        const float Hinv = __builtin_amdgcn_rsqf((float)P.H2);
-        const float Rs = fast_sqrt(wave_max(owned ? tt : 0.0f)) * Hinv + 3.0f;            // wave-uniform
-        hinv = Hinv * min_raw(16.0f, 192.0f * fast_rcp(Rs));
-        const float thr_s = (hinv * hinv) * (float)P.H2;                                  // (sc·H)²: 256 for ordinary tiles
-        const float sx = owned ? txl * hinv : 0.0f, sy = owned ? tyl * hinv : 0.0f, sz = owned ? tzl * hinv : 0.0f;
-        const float tts = sx * sx + sy * sy + sz * sz;
-        const float eps16 = 3e-4f + 2.5e-5f * (Rs * Rs) + 0.03f * fast_rcp(thr_s);
-        float cut = thr_s * (1.0f + eps16);
-        if constexpr (kMaskIO && PASS == PASS_PREDICTOR) { if (P.mstore) cut = (thr + tt) * (hinv * hinv) + thr_s * eps16; }      // (the skin of the hand-over experiment)
-        const float th = owned ? tts - cut : 60000.0f;
-        unsigned X[4], Z[4];
-        X[0] = split_hl(-2.0f * sx); X[1] = X[0]; X[2] = split_hl(-2.0f * sy); X[3] = X[2];
-        Z[0] = split_hl(-2.0f * sz); Z[1] = Z[0]; Z[2] = pk_h2(1.0f, 1.0f); Z[3] = split_hl(th);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { swap_halves(X[k], Z[k]); Bh[0][k] = X[k]; Bh[1][k] = Z[k]; }
-    }
-    auto scan_chunk16 = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
-        const int c = cb + bperm;
-        const bool cv = c < HI;
-        // (a lane beyond the row's end: coordinates 0 and |c|² far beyond the cut — every sum stays positive)
-        const float cx = cv ? (float)(cpk.x - ox) * hinv : 0.0f, cy = cv ? (float)(cpk.y - oy) * hinv : 0.0f, cz = cv ? (float)(cpk.z - oz) * hinv : 0.0f;
-        const float cc = cv ? cx * cx + cy * cy + cz * cz : 60000.0f;
-        unsigned X[4], Z[4];
-        split_hh_ll(cx, X[0], X[1]); split_hh_ll(cy, X[2], X[3]);
-        split_hh_ll(cz, Z[0], Z[1]); Z[2] = split_hl(cc); Z[3] = pk_h2(1.0f, 1.0f);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) swap_halves(X[k], Z[k]);             // X: block of candidates 0…31, Z: block of candidates 32…63
-        unsigned W[2] = {0u, 0u};
-#pragma unroll
-        for (int C = 1; C >= 0; --C) {
-            u32x4s aw; aw[0] = C ? Z[0] : X[0]; aw[1] = C ? Z[1] : X[1]; aw[2] = C ? Z[2] : X[2]; aw[3] = C ? Z[3] : X[3];
-            const f16x8 a = __builtin_bit_cast(f16x8, aw);
-#pragma unroll
-            for (int Tb = 0; Tb < 2; ++Tb) {
-                u32x4s bw; bw[0] = Bh[Tb][0]; bw[1] = Bh[Tb][1]; bw[2] = Bh[Tb][2]; bw[3] = Bh[Tb][3];
-                f32x16 d = {0};
-                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, bw), d, 0, 0, 0);
-#pragma unroll
-                for (int r = 15; r >= 0; --r)
-                    W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
-#if SPHMI_SEQ_BLOCKS
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
-        }
-        swap_halves(W[0], W[1]);
-        return ((unsigned long long)W[1] << 32) | W[0];
-    };
-#endif
     auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
-#if SPHMI_F16_SCAN == 0
     auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
         const int c = cb + bperm;
         const bool cv = c < HI;
@@ -1148,28 +846,20 @@ k_neighbor_force(const ForceParams<T> P) {
 #pragma unroll
                 for (int r = 15; r >= 0; --r)
                     W[Tb] = __builtin_amdgcn_alignbit(W[Tb], __float_as_uint(d[r]), 31);
-#if SPHMI_SEQ_BLOCKS
                 __builtin_amdgcn_sched_barrier(0);      // one 32×32 block in flight: 16 accumulator registers
-#endif
             }
         }
         swap_halves(W[0], W[1]);
         return ((unsigned long long)W[1] << 32) | W[0];
     };
-#endif
 
     int g0 = 0;                      // WPT > 1: chunks of the rows before this one, mod WPT (wave-uniform)
     auto row_offset = [&](const int seg) { return (D == 3) ? ((seg % 3) - 1) * P.nxp + ((seg / 3) - 1) * P.nxyp : (seg - 1) * P.nxp; };
     // Several waves per tile = a case too small to hide latency behind other waves: a lone wave pays the round trip of
     // every row's range look-up one after the other (≈0.8 µs each; tools/trace_small.py).  The waves of the tile need the
-    // same ranges: they fetch them TOGETHER — row s by wave s % WPT, all requests in flight at once — and share them in LDS.
-#ifndef SPHMI_RNG_MIN_WPT
-#define SPHMI_RNG_MIN_WPT 4
-#endif
-#ifndef SPHMI_RR_MIN_WPT
-#define SPHMI_RR_MIN_WPT 4
-#endif
-    constexpr bool kShareRanges = WPT >= SPHMI_RNG_MIN_WPT && WPT > 1;
+    // same ranges: with four or more waves they fetch them TOGETHER — row s by wave s % WPT, all requests in flight at once —
+    // and share them in LDS (two-wave tiles keep their own look-ups: sharing costs them 6 %).
+    constexpr bool kShareRanges = WPT >= 4;
     __shared__ int2 s_rng[kShareRanges ? NSEG * kWave : 1];
     if constexpr (kShareRanges) {
 #pragma unroll
@@ -1182,33 +872,12 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
     }
-    // masks handed from the predictor to the corrector: this tile's rows of [chunk][lane] words, and the running chunk number
-    [[maybe_unused]] unsigned long long* mrow = nullptr;
-    [[maybe_unused]] int ci = 0;
-    // (the tile number is wave-uniform: the row address stays in scalar registers, a lane adds 8·lane)
-    if constexpr (kMaskIO) { if (P.mstore) mrow = P.mstore + (size_t)__builtin_amdgcn_readfirstlane(b) * (size_t)P.mask_cap * kWave; }
-    constexpr int kPfMask = PASS == PASS_CORRECTOR ? (SPHMI_SCAN_PF_C) : (SPHMI_SCAN_PF);
-    constexpr bool kPfChunks = (kPfMask & 1) != 0 && WPT == 1 && SPHMI_LDS_STAGE == 0;
-    constexpr bool kPfRows = (kPfMask & 2) != 0 && WPT == 1 && !kShareRanges;
-    [[maybe_unused]] int lo_n = 0, hi_n = 0;
-    if constexpr (kPfRows) {
-        const int off = row_offset(0);
-        lo_n = valid ? P.cstart[key_a + off - 1] : 0;
-        hi_n = valid ? P.cstart[key_a + off + 2] : 0;
-    }
 #pragma unroll 1
     for (int seg = 0; seg < NSEG; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
         int lo_l, hi_l;
         if constexpr (kShareRanges) { const int2 rg = s_rng[seg * kWave + lane]; lo_l = rg.x; hi_l = rg.y; }
-        else if constexpr (kPfRows) {
-            lo_l = lo_n; hi_l = hi_n;
-            if (seg + 1 < NSEG) {
-                const int off = row_offset(seg + 1);
-                lo_n = valid ? P.cstart[key_a + off - 1] : 0;
-                hi_n = valid ? P.cstart[key_a + off + 2] : 0;
-            }
-        } else {
+        else {
             const int off = row_offset(seg);
             lo_l = valid ? P.cstart[key_a + off - 1] : 0;
             hi_l = valid ? P.cstart[key_a + off + 2] : 0;
@@ -1218,52 +887,31 @@ k_neighbor_force(const ForceParams<T> P) {
         const int HI = rl_i(hi_l, last_lane);
         int first = 0;
         if constexpr (WPT > 1) {
-            if constexpr (WPT >= SPHMI_RR_MIN_WPT) first = (wv - g0) & (WPT - 1);
+            // chunks dealt round-robin over ALL rows with four or more waves (counts differ by one at most); two-wave tiles keep
+            // the rotation by row
+            if constexpr (WPT >= 4) first = (wv - g0) & (WPT - 1);
             else first = (wv + WPT - seg % WPT) % WPT;
             g0 = (g0 + (HI > LO ? (HI - LO + kWave - 1) / kWave : 0)) & (WPT - 1);
         }
-        [[maybe_unused]] V4 pre;
-        if constexpr (kPfChunks) { if (LO < HI) pre = chunk_packet(LO, HI); }
 #pragma unroll 1
         for (int cb = LO + first * kWave; cb < HI; cb += kWave * WPT) {
-            V4 cpk;
-            if constexpr (kPfChunks) {
-                cpk = pre;
-                if (cb + kWave < HI) pre = chunk_packet(cb + kWave, HI);
-            }
             // A tile of a sparse region (spray, a thin sheet) spans many cells: the union range of a row is then
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
             if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;
-            // room for the entries of a chunk in every lane's queue?  Two (its 32-candidate halves); four for a chunk of the
-            // target's own row when the entries carry the role (each half split into the "i" and the "j" candidates)
-            const bool split_row = kRoleEntries && ddt != kDdtNone && seg == NSEG / 2;
-            const int need = split_row ? 4 : 2;
-            if (__builtin_amdgcn_ballot_w64(qn > QCAP - need) != 0) run_pairs(min(QCAP - 1 - SPHMI_QUEUE_SLACK, QCAP - need), false);
-            unsigned long long m = 0ull;
-            bool handed = false;                                    // (wave-uniform)
-            if constexpr (kMaskIO && PASS == PASS_CORRECTOR) {
-                // the predictor of this step has scanned this very chunk (same list, same ranges, same skips) against H + vmax·Δt
-                if (mrow != nullptr && ci < P.mask_cap) { m = mrow[(size_t)ci * kWave + lane]; handed = true; }
-            }
-            if (!handed) {
-                if constexpr (!kPfChunks) cpk = chunk_packet(cb, HI);
-#if SPHMI_F16_SCAN
-                m = scan_chunk16(cb, HI, cpk);
-#else
+            // room for the two entries of a chunk (its 32-candidate halves) in every lane's queue?
+            if (__builtin_amdgcn_ballot_w64(qn > QCAP - 2) != 0) run_pairs(QCAP - 1 - kQueueSlack, false);
+            unsigned long long m;
+            {
+                const V4 cpk = chunk_packet(cb, HI);
                 m = scan_chunk(cb, HI, cpk);
-#endif
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
                 const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
                 const int w = b1 - b0;
                 const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
                 m = (w > 0) ? (m & rm) : 0ull;
-                if constexpr (kMaskIO && PASS == PASS_PREDICTOR) {
-                    if (mrow != nullptr && ci < P.mask_cap) mrow[(size_t)ci * kWave + lane] = m;
-                }
             }
-            ci += 1;
             work_ch += 1;
 #ifdef SPHMI_STATS
             st_chunks += 1;
@@ -1291,31 +939,18 @@ k_neighbor_force(const ForceParams<T> P) {
                         mm &= mm - 1ull;
                         const V4 n0 = s_stage[2 * b], n1 = s_stage[2 * b + 1];
                         const unsigned jr = (unsigned)(cb + b) << kRecShift;
-                        pair(jr, n0, n1, (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))));
+                        pair(jr, n0, n1, plays_i(jr));
                     }
                 }
                 continue;
             }
 #endif
-            auto push = [&](const unsigned bits, const int c0, const unsigned role_bit) {
+            auto push = [&](const unsigned bits, const int c0) {
                 if (bits != 0) {
-                    const unsigned w1 = kRoleEntries ? (((unsigned)c0 << (kRecShift - 1)) | role_bit) : ((unsigned)c0 << kRecShift);
-                    *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, w1); waddr = q_next(waddr); qn += 1;
+                    *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
                 }
             };
-            if (!split_row) {
-                // rows before the target's own row hold candidates that sort before its cell (the target plays "i"), rows after it
-                // candidates that sort after its cell (the target plays "j")
-                const unsigned rb = (kRoleEntries && seg < NSEG / 2) ? 0x80000000u : 0u;
-                push((unsigned)m, cb, rb); push((unsigned)(m >> 32), cb + 32, rb);
-            } else {
-                // own row: "i" candidates = [.., cs_a) ∪ (a, ce_a), "j" candidates = [cs_a, a) ∪ [ce_a, ..)   (bit b = candidate cb + b)
-                auto below = [](const int n) -> unsigned long long { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); };
-                const unsigned long long R = below(cs_a - cb) | (below(ce_a - cb) & ~below(a + 1 - cb));
-                const unsigned long long mi = m & R, mj = m & ~R;
-                push((unsigned)mi, cb, 0x80000000u); push((unsigned)(mi >> 32), cb + 32, 0x80000000u);
-                push((unsigned)mj, cb, 0u); push((unsigned)(mj >> 32), cb + 32, 0u);
-            }
+            push((unsigned)m, cb); push((unsigned)(m >> 32), cb + 32);
         }
     }
     run_pairs(0, true);
@@ -1326,8 +961,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #endif
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
-    // (with the corrector's masks handed over a chunk costs the two passes ≈ 475 + 120 cycles: 10 per pass)
-    int tile_work = 9 * work_it + ((kMaskIO && P.mstore) ? 10 : 16) * work_ch + 16;
+    int tile_work = 9 * work_it + 16 * work_ch + 16;
     if (P.xcd_clock && lane == 0 && wv == 0) {
         // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
         // shares of the estimated cost towards equal finishing times at the next rebuild.
@@ -1455,12 +1089,6 @@ k_neighbor_force(const ForceParams<T> P) {
         // every lane holds the three maxima: lanes 0, 1, 2 serve one slot each — ONE pre-test load and ONE atomic instruction
         // per wave instead of three dependent round trips to the coherence point (a device-scope load is served beyond the
         // XCD's L2; the epilogue of a lone wave: 5.3 → 4.1 µs, tools/trace_small.py)
-        if (kMaskIO && P.vmx != nullptr) {
-            // max |v|² of the new state (particles that move): the skin of the next predictor's accept masks (ForceParams::mstore)
-            T v2 = owned ? (o1.x * o1.x + o1.y * o1.y + o1.z * o1.z) * ml : T(0);
-            v2 = wave_max(v2);
-            if (lane < 4) atomic_max_bits(lane < 3 ? &P.red[lane] : P.vmx, lane == 0 ? disp2 : (lane == 1 ? vis : (lane == 2 ? a2 : v2)));
-        } else
         if (lane < 3) atomic_max_bits(&P.red[lane], lane == 0 ? disp2 : (lane == 1 ? vis : a2));
     }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)

@@ -772,7 +772,6 @@ struct MultiEngine final : EngineBase {
                            ghost_points ? ph.data() : nullptr, mine.data());
         }
         uploaded = true; have_halo = false; dx_rate = 0.0; parity = 0;
-        if (!rank_mode) perm_ids.assign(ids, ids + N);                   // row history for sphmi_download_permutation
     }
 
     SlabPlan given_plan;               // test hook (sphmi_multi_set_cuts): start from these cuts instead of the balanced ones
@@ -1346,33 +1345,46 @@ struct MultiEngine final : EngineBase {
         packet_src = [](Engine<T>& e) -> const void* { return e.kout_d; };
         put_packets(kernel_gradient, kernel);
     }
-    // sphmi_download_permutation: the slabs exchange particles, so the row history lives on the host here — the ID column of
-    // the previous call (the upload order at first) against the merged ID column of now; one hash-free table look-up per row
-    // when the IDs are compact (every shipped layout: 1 … N), a hash map otherwise.
-    std::vector<int64_t> perm_ids;
+    // sphmi_download_permutation: every particle carries its row at the previous call (the upload order at first) as a column of
+    // its own — Engine::prow, permuted by the sorts and carried by the migration and ghost-layer records — exactly like the
+    // one-device handle.  (Round 3 matched the ID column of now against the ID column of then, which is wrong without a word when
+    // the caller's IDs repeat: the reference reads Idp per CSV file and concatenates, src/PreProcess.jl:28,71.)  Merged by order
+    // tag like a download; the slabs' columns are then re-numbered with the merged rows.  An asynchronous download in flight is
+    // not disturbed.
     void download_permutation(int64_t* prev_row) override {
         if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation before sphmi_upload");
         if (!prev_row) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_download_permutation: null array");
         if (rank_mode) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: one-process handles only (a rank-mode process holds one slab of the rows)");
-        const size_t N = (size_t)cfg.n_particles;
-        std::vector<int64_t> now(N);
-        download(nullptr, nullptr, nullptr, nullptr, nullptr, now.data(), nullptr, nullptr, nullptr, nullptr);
-        if ((size_t)n_downloaded != N || perm_ids.size() != N) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: the handle does not hold the uploaded particle set");
-        int64_t lo = perm_ids[0], hi = perm_ids[0];
-        for (auto v : perm_ids) { lo = std::min(lo, v); hi = std::max(hi, v); }
-        if ((uint64_t)(hi - lo) < 4 * (uint64_t)N + 1024) {
-            std::vector<int64_t> row((size_t)(hi - lo + 1), -1);
-            for (size_t i = 0; i < N; ++i) row[(size_t)(perm_ids[i] - lo)] = (int64_t)i;
-            for (size_t i = 0; i < N; ++i) {
-                const int64_t v = now[i];
-                prev_row[i] = (v >= lo && v <= hi) ? row[(size_t)(v - lo)] : -1;
+        if (cfg.n_particles > (int64_t)INT32_MAX) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_download_permutation: more than 2^31 - 1 rows");
+        const size_t N = (size_t)cfg.n_particles, L = R.size();
+        std::vector<std::vector<int>> rows(L); std::vector<std::vector<uint8_t>> ty(L); std::vector<std::vector<unsigned long long>> tag(L);
+        std::vector<const uint8_t*> tys(L); std::vector<const unsigned long long*> tags(L); std::vector<size_t> ns(L);
+        for (size_t q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            HC(hipStreamSynchronize(r.main));
+            const size_t n = (size_t)e.N; ns[q] = n;
+            rows[q].resize(std::max<size_t>(n, 1)); ty[q].resize(std::max<size_t>(n, 1)); tag[q].resize(std::max<size_t>(n, 1));
+            if (n) {
+                e.bounce.d2h(rows[q].data(), e.prow[e.cur], n * 4, r.main);
+                e.bounce.d2h(ty[q].data(), e.type[e.cur], n, r.main);
+                e.bounce.d2h(tag[q].data(), e.otag[e.cur], n * 8, r.main);
             }
-        } else {
-            std::unordered_map<int64_t, int64_t> row; row.reserve(N * 2);
-            for (size_t i = 0; i < N; ++i) row[perm_ids[i]] = (int64_t)i;
-            for (size_t i = 0; i < N; ++i) { auto it = row.find(now[i]); prev_row[i] = it == row.end() ? -1 : it->second; }
+            tys[q] = ty[q].data(); tags[q] = tag[q].data();
         }
-        perm_ids.swap(now);
+        std::vector<uint8_t> seen(N, 0);
+        const size_t got = merged_rows(tys, tags, ns, [&](size_t o, size_t q, size_t i) {
+            const int64_t v = rows[q][i];
+            if (v < 0 || (size_t)v >= N || seen[(size_t)v]) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: the row column of the slabs is not a permutation");
+            seen[(size_t)v] = 1;
+            prev_row[o] = v;
+            rows[q][i] = (int)o;                                        // the row NOW: what the next call hands out
+        });
+        if (got != N) throw EngineError(SPHMI_ERR_STATE, "sphmi_download_permutation: the handle does not hold the uploaded particle set");
+        for (size_t q = 0; q < L; ++q) {
+            Rank& r = R[q]; HC(hipSetDevice(r.device));
+            if (ns[q]) r.e->bounce.h2d(r.e->prow[r.e->cur], rows[q].data(), ns[q] * 4, r.main);      // (ghost copies keep a stale row: they die at the next rebuild)
+        }
     }
     void unique_cells(int64_t* out, int64_t cap, int64_t* n_out) override {
         // occupied cells of the owned particles in sort order, from the merged Cells column

@@ -449,23 +449,21 @@ template <class T>
 __global__ void __launch_bounds__(256) k_init_reduce(Half<const typename Vec4<T>::type> pk0,
                                                      Half<const typename Vec4<T>::type> pk1,
                                                      const typename Vec4<T>::type* acc, int N, T h, T eta2,
-                                                     unsigned long long* red, unsigned long long* vmx = nullptr) {
+                                                     unsigned long long* red) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    T disp2 = 0, vis = 0, a2 = 0, v2 = 0;
+    T disp2 = 0, vis = 0, a2 = 0;
     if (i < N) {
         auto x = pk0[i]; auto v = pk1[i]; auto a = acc[i];
         const T rr = x.x * x.x + x.y * x.y + x.z * x.z;
         disp2 = rr;
         vis = absT(h * (v.x * x.x + v.y * x.y + v.z * x.z) / (rr + eta2));
         a2 = a.x * a.x + a.y * a.y + a.z * a.z;
-        v2 = v.x * v.x + v.y * v.y + v.z * v.z;          // (max |v|²: the skin of the first predictor's accept masks, ForceParams::mstore)
     }
-    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2); v2 = wave_max(v2);
+    disp2 = wave_max(disp2); vis = wave_max(vis); a2 = wave_max(a2);
     if ((threadIdx.x & 63) == 0) {
         atomic_max_bits(&red[0], disp2);
         atomic_max_bits(&red[1], vis);
         atomic_max_bits(&red[2], a2);
-        if (vmx) atomic_max_bits(vmx, v2);
     }
 }
 
@@ -893,10 +891,11 @@ __global__ void __launch_bounds__(256) k_dd_column_cost(const int* key, const ui
 }
 
 // Migration record buffer for n particles:
-// [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][n×i64 id][n×u64 group][n×u64 order tag][n×u8 type]
+// [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][n×i64 id][n×u64 group][n×u64 order tag][n×i32 row at the last
+// sphmi_download_permutation, padded to 8 bytes][n×u8 type, padded to 8 bytes]
 template <class T> struct DdRecord {
     using V4 = typename Vec4<T>::type;
-    static __host__ __device__ size_t bytes(size_t n) { return n * (4 * sizeof(V4) + 24) + ((n + 7) & ~size_t(7)); }
+    static __host__ __device__ size_t bytes(size_t n) { return n * (4 * sizeof(V4) + 24) + ((4 * n + 7) & ~size_t(7)) + ((n + 7) & ~size_t(7)); }
     static __host__ __device__ V4* pk0(void* b, size_t) { return (V4*)b; }
     static __host__ __device__ V4* pk1(void* b, size_t n) { return (V4*)b + n; }
     static __host__ __device__ V4* acc(void* b, size_t n) { return (V4*)b + 2 * n; }
@@ -904,14 +903,15 @@ template <class T> struct DdRecord {
     static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + 4 * n); }
     static __host__ __device__ unsigned long long* grp(void* b, size_t n) { return (unsigned long long*)id(b, n) + n; }
     static __host__ __device__ unsigned long long* tag(void* b, size_t n) { return grp(b, n) + n; }
-    static __host__ __device__ uint8_t* type(void* b, size_t n) { return (uint8_t*)(tag(b, n) + n); }
+    static __host__ __device__ int* prow(void* b, size_t n) { return (int*)(tag(b, n) + n); }
+    static __host__ __device__ uint8_t* type(void* b, size_t n) { return (uint8_t*)prow(b, n) + ((4 * n + 7) & ~size_t(7)); }
 };
 
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                    const typename Vec4<T>::type* acc, const typename Vec4<T>::type* ghost,
                                                    const long long* id, const unsigned long long* grp,
-                                                   const unsigned long long* tag, const uint8_t* type,
+                                                   const unsigned long long* tag, const int* prow, const uint8_t* type,
                                                    const int* idx, int n, void* buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -923,13 +923,14 @@ __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::
     DdRecord<T>::id(buf, n)[k] = id[i];
     DdRecord<T>::grp(buf, n)[k] = grp[i];
     DdRecord<T>::tag(buf, n)[k] = tag[i];
+    DdRecord<T>::prow(buf, n)[k] = prow[i];
     DdRecord<T>::type(buf, n)[k] = type[i] & kTypeMask;
 }
 
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_append(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                    typename Vec4<T>::type* acc, typename Vec4<T>::type* ghost, long long* id,
-                                                   unsigned long long* grp, unsigned long long* tag, uint8_t* type, int at, int n,
+                                                   unsigned long long* grp, unsigned long long* tag, int* prow, uint8_t* type, int at, int n,
                                                    void* buf, uint8_t flag) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -940,6 +941,7 @@ __global__ void __launch_bounds__(256) k_dd_append(Half<typename Vec4<T>::type> 
     id[at + k] = DdRecord<T>::id(buf, n)[k];
     grp[at + k] = DdRecord<T>::grp(buf, n)[k];
     tag[at + k] = DdRecord<T>::tag(buf, n)[k];
+    prow[at + k] = DdRecord<T>::prow(buf, n)[k];
     type[at + k] = DdRecord<T>::type(buf, n)[k] | flag;
 }
 

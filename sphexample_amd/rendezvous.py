@@ -68,33 +68,70 @@ class Rendezvous:
         self._dist.all_gather_object(out, text)
         return out
 
-    def close(self) -> None:
+    def close(self, after_error: bool = False) -> None:
+        """`after_error`: a peer may be gone already — no barrier (it would wait for ever), just leave the group."""
         if self._own and self._dist.is_initialized():
             try:
-                self._dist.barrier()
+                if not after_error:
+                    self._dist.barrier()
             finally:
                 self._dist.destroy_process_group()
 
 
-def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSPORT"):
+def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSPORT", preflight=None, timeout: float = None):
     """One slab engine per rank with the id handed round, COLLECTIVELY: every rank learns whether all ranks succeeded.
     `make(unique_id)` builds this rank's engine (sphexample_amd.engine.make_engine(..., rank=, world=, unique_id=)).
     Returns (engine | None, list of the ranks' error texts).  The id is RCCL's (sphmi_rccl_unique_id on rank 0) unless the
-    shared-memory transport is selected in the environment, where any 128 random bytes do."""
-    from .engine import rccl_unique_id
-    uid, err = None, ""
+    shared-memory transport is selected in the environment, where any 128 random bytes do.
+
+    Two phases (round-3 advice: a rank that failed BEFORE ncclCommInitRank left its peers waiting inside it for ever):
+      1. local — everything that can fail without a peer: the library loads, RCCL binds (every rank asks for an id of its own
+         and throws it away), `preflight()` of the caller (device present, memory for the slab …).  All ranks agree on the
+         outcome (all_ok) BEFORE anyone enters the communicator set-up.
+      2. collective — `make(uid)`.  A communicator set-up that cannot reach a peer does not fail, it waits: `timeout` seconds
+         (or $SPHMI_SETUP_TIMEOUT) arm a watchdog that ends the process with a message and exit code 3."""
+    from .engine import load_library, rccl_unique_id
+    shm = os.environ.get(transport_env) == "shm"
+    err = ""
+    try:
+        load_library()
+        if not shm:
+            rccl_unique_id()                          # binds librccl in this process: a missing symbol shows here, on every rank
+        if preflight is not None:
+            preflight()
+    except Exception as exc:                          # noqa: BLE001
+        err = f"rank {rdv.rank} (local set-up): {exc}"
+    texts = rdv.gather_strings(err)
+    if not rdv.all_ok(not err):
+        return None, [t for t in texts if t]
+    uid = None
     if rdv.rank == 0:
         try:
-            uid = os.urandom(128) if os.environ.get(transport_env) == "shm" else rccl_unique_id()
-        except Exception as exc:                      # librccl missing or broken: every rank must learn it, not hang
+            uid = os.urandom(128) if shm else rccl_unique_id()
+        except Exception as exc:                      # noqa: BLE001 — every rank must learn it, not hang
             err = f"rank 0: sphmi_rccl_unique_id: {exc}"
     uid = rdv.broadcast_bytes(uid, src=0)
     eng = None
     if uid is not None:
+        watchdog = None
+        limit = timeout if timeout is not None else float(os.environ.get("SPHMI_SETUP_TIMEOUT", "0") or 0)
+        if limit > 0:
+            import sys
+            import threading
+
+            def give_up():
+                print(f"[sphmi] rank {rdv.rank}: the slab engine was not set up within {limit:.0f} s (a peer that never reached "
+                      f"ncclCommInitRank?)", file=sys.stderr, flush=True)
+                os._exit(3)
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             eng = make(uid)
-        except Exception as exc:
+        except Exception as exc:                      # noqa: BLE001
             err = f"rank {rdv.rank}: {exc}"
+        if watchdog is not None:
+            watchdog.cancel()
     texts = rdv.gather_strings(err)
     if not rdv.all_ok(eng is not None):
         if eng is not None:

@@ -3,8 +3,9 @@
   python rank_worker.py selftest <unique id, hex> <rank> <world> <bytes per message>
   python rank_worker.py run <unique id, hex> <rank> <world> <case> <steps> <float bytes> <out dir> <advance calls> <slab axis | -1>
 
-`run` creates slab `rank` of the case on GPU 0 with SPHMI_TRANSPORT=shm (the environment of the spawner), advances it and
-stores what this process owns plus the loop counters; the spawner compares the union with a one-device handle.
+`run` creates slab `rank` of the case on GPU 0 with SPHMI_TRANSPORT=shm (the environment of the spawner) — or, with
+$SPHMI_TEST_DEVICE_PER_RANK=1 (tests/test_multi_device_gpu.py on a box with several GPUs), on GPU `rank` over RCCL —
+advances it and stores what this process owns plus the loop counters; the spawner compares the union with a one-device handle.
 """
 import ctypes as C
 import os
@@ -33,7 +34,8 @@ def main():
     import conftest
     from sphexample_amd.engine import make_engine
     p, s = getattr(conftest, "load_" + case)()
-    eng = make_engine(p, s, device_float_bytes=fb, device=0, rank=rank, world=world, unique_id=uid,
+    device = rank if os.environ.get("SPHMI_TEST_DEVICE_PER_RANK") == "1" else 0
+    eng = make_engine(p, s, device_float_bytes=fb, device=device, rank=rank, world=world, unique_id=uid,
                       slab_axis=None if axis < 0 else axis)
     prog = []
     for _ in range(calls):

@@ -41,7 +41,8 @@ def test_bench_line_single_gpu():
     assert rf["bound"] == "valu_issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert j["value_excl_rebuild"] >= j["value"] and j["rebuild_ms_in_window"] >= 0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
-    assert rf["peak_measured"] > 1000.0 and rf["launches"] > 0 and rf["avg_launch_ms"] > 0
+    assert rf["peak_measured"] > 1000.0 and rf["launches"] == 2 * j["steps"] and rf["launch_time_samples"] > 0 and rf["avg_launch_ms"] > 0
+    assert j["config"]["launch"] == "one process"
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == j["unit"]
 
@@ -67,6 +68,67 @@ def test_bench_line_two_ranks_on_one_gpu(transport):
     assert ("RCCL set-up failed" in r.stderr) == (transport == "rccl")
     if transport == "rccl":                                 # the text names the slab and the call, not a bare "invalid usage"
         assert "slab" in r.stderr and "ncclCommInitRank" in r.stderr
+
+
+def test_bench_without_a_launcher_spawns_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` started like the N = 1 line (no torch.distributed.run around it, so
+    WORLD_SIZE is unset) used to leave with SystemExit and no line.  It now starts the N ranks itself — the contract's own command
+    line — and falls into the one-process multi-device handle when they fail.  CPU part: the decision and the command."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPHMI_BENCH_LAUNCH"):
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(bench, "self_spawn", lambda world, argv: calls.append((world, list(argv))) or 0)
+    bench.main()                                             # the ranks did the work: nothing else happens in this process
+    assert calls == [(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"])]
+    # the ranks failed: this process goes on as --single-process (here, without a GPU, up to the device check)
+    import torch
+    if not torch.cuda.is_available():
+        monkeypatch.setattr(bench, "self_spawn", lambda world, argv: 7)
+        with pytest.raises(SystemExit, match="no CPU path"):
+            bench.main()
+    # under a launcher (WORLD_SIZE set) nothing is spawned
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "1")
+    monkeypatch.setattr(bench, "self_spawn", lambda world, argv: (_ for _ in ()).throw(AssertionError("spawned under a launcher")))
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit, match="no CPU path"):
+            bench.main()
+
+
+def test_self_spawn_runs_the_contracts_command(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert bench.self_spawn(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert "self-spawned" in seen["env"]["SPHMI_BENCH_LAUNCH"]
+
+
+@pytest.mark.gpu
+def test_bench_line_without_a_launcher():
+    """The same on the device: `python bench.py --gpus 2 …` produces ONE line, and the line says how the ranks came to be.  On a
+    one-GPU box the two ranks share the device (shared-memory transport, labelled); with two GPUs they run over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["SPHMI_SHM_TIMEOUT"] = "60"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--dp", "0.02",
+                        "--precondition-ms", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["steps"] == 4
+    assert "self-spawned" in j["config"]["launch"] and "torch.distributed.run" in j["config"]["launch"]
 
 
 def _identity():

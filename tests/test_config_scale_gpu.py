@@ -177,6 +177,38 @@ def test_c3_slabs_match_one_device(world):
     assert fig["rho"] < TOL and fig["x"] < TOL, fig
 
 
+def test_c3_cuts_move_at_scale():
+    """The moving-cut path at the size the metric is quoted on (`recuts: 0` in every at-scale record).  Four
+    slabs at C3 whose cuts start three cell columns off the balanced plan: the collective rebuilds find max / mean work above 1.05,
+    sum the column histograms, re-cut (every cut between its old neighbours) and migrate whole columns — ≈10⁴ particles per cut —
+    and the run is still the one-device run, ID for ID."""
+    from test_multi_gpu import _plan
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP3)
+    p = flowing(dam_break_3d(DP3))
+    world = 4
+    axis, _, cuts, owned, _ = _plan(p, s, world, fb=4)
+    shifted = [c + 3 for c in cuts]
+    ref = make_engine(p, s, device_float_bytes=4)
+    dd = make_engine(p, s, device_float_bytes=4, devices=[0] * world, slab_axis=axis, cuts=shifted)
+    first = [int(x) for x in dd.multi_info().cuts[:world - 1]]
+    assert first == shifted
+    for steps in (20, 60):
+        pr, pd = ref.advance(1e9, max_steps=steps), dd.advance(1e9, max_steps=steps)
+        _same_loop(pd, pr)
+    info = dd.multi_info()
+    r, d = ref.download(FIELDS + ("Cells",)), dd.download(FIELDS + ("Cells",))
+    assert dd.owned_count() == len(p)
+    np.testing.assert_array_equal(d["ID"], r["ID"])
+    np.testing.assert_array_equal(d["Cells"], r["Cells"])
+    fig = dict(_errors(d, r, DP3), rebuilds=int(pr.n_rebuilds), recuts=int(info.n_recuts), cuts_balanced=[int(c) for c in cuts],
+               cuts_start=shifted, cuts_end=[int(x) for x in info.cuts[:world - 1]], owned_balanced=[int(x) for x in owned],
+               slab_particles=[int(x) for x in info.n_live[:world]])
+    _record("C3_4_slabs_cuts_start_3_columns_off", fig)
+    assert info.n_recuts >= 1 and fig["cuts_end"] != shifted, fig
+    assert fig["rho"] < TOL and fig["x"] < TOL, fig
+
+
 def test_c4_eight_slabs_vs_one_device_and_oracle():
     """BASELINE config 4's decomposition at its size: 7.7 M particles on 8 slabs (sharing the one GPU here): 5 steps against
     the fp64 oracle, then on to 40 steps against the one-device handle, with collective rebuilds inside the window."""

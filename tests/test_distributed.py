@@ -197,6 +197,14 @@ def _rendezvous_worker(rank, world, port, out_dir):
     ok &= eng is None and errs == [f"rank {world - 1}: no device for this rank"] and all(f.closed for f in made)
     eng, errs = create_rank_engine(rdv, lambda uid: Fake())
     ok &= isinstance(eng, Fake) and errs == []
+    # a rank that fails in its LOCAL phase (no device, no memory, library missing) is learnt by every rank BEFORE anyone enters the
+    # collective set-up: make() — where a real rank would sit in ncclCommInitRank waiting for the missing peer — is never called
+    entered = []
+    def preflight():
+        if rank == 0:
+            raise RuntimeError("no memory for this slab")
+    eng, errs = create_rank_engine(rdv, lambda uid: entered.append(1) or Fake(), preflight=preflight)
+    ok &= eng is None and errs == ["rank 0 (local set-up): no memory for this slab"] and not entered
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("1" if ok else "0")
     rdv.close()
 

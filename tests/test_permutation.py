@@ -49,7 +49,7 @@ def test_oracle_permutation_is_the_row_history(dam_break_2d):
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
 def test_engine_permutation_equals_the_oracles(dam_break_2d, devices):
     """fp64 kernels keep the oracle's order ID for ID, so the permutations must be equal interval by interval — one device
-    (the 4-byte row column that travels through the engine's sort) and multi-device handles (derived from the ID column)."""
+    (the 4-byte row column that travels through the engine's sort) and multi-device handles (the same column, riding in the migration and ghost-layer records)."""
     from conftest import perturbed
     from oracle.oracle import make_oracle
     from sphexample_amd.engine import make_engine
@@ -96,3 +96,31 @@ def test_run_simulation_keeps_the_passive_fields(dam_break_2d_mdbc):
         for k in a:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
             np.testing.assert_array_equal(c[k], b[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
+def test_permutation_does_not_depend_on_unique_ids(dam_break_2d, devices):
+    """The reference reads Idp per CSV file and concatenates the geometries (src/PreProcess.jl:28,71): IDs may repeat.  The
+    row column is a column of its own — on slabs it rides in the migration and ghost-layer records — so the permutation of a
+    set whose IDs are ALL EQUAL is the permutation of the same set with unique IDs (round-3 advice: the slab path matched
+    ID columns and returned a non-permutation without a word)."""
+    from conftest import perturbed
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_2d
+    q = perturbed(p, seed=1, vel_scale=3.0)
+    dup = q.copy()
+    dup.ID[:] = 7
+    ref = make_engine(q, s, device_float_bytes=8, devices=devices)
+    eng = make_engine(dup, s, device_float_bytes=8, devices=devices)
+    passive = np.arange(len(q))
+    for (_, pr), (ie, pe) in zip(_intervals(ref, 4, 25), _intervals(eng, 4, 25)):
+        assert (ie == 7).all()
+        np.testing.assert_array_equal(pe, pr)
+        assert sorted(pe) == list(range(len(q)))
+        passive = passive[pe]
+    # the passive column now names the upload row of every particle: its uploaded position is where that row was
+    x_now = ref.download(("Position",))["Position"]
+    x_dup = eng.download(("Position",))["Position"]
+    np.testing.assert_array_equal(x_now, x_dup)
+    ref.close(); eng.close()

@@ -7,6 +7,9 @@
 #
 # Every table of profiles/r03_pair_loop_experiments.md names the variant builds it compares; the builds are interleaved by
 # tools/bench_libs.py so that box-to-box and clock drift hit all of them alike.  Results land under gpurun_out/repro/.
+#
+# ROUND 4: most of the switches this script builds were retired from sphmi_kernels.h (profiles/r04_retired_switches.patch).
+# Run it on the round-3 tree (`git checkout c32c1f7`), or apply that patch first.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
