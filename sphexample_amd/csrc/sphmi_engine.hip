@@ -153,6 +153,10 @@ struct Engine final : EngineBase {
     Half<V4> pk0[3], pk1[3];
     int iA = 0, iH = 1, iB = 2;
     V4 *acc[2] = {}, *ghost[2] = {};
+    // fp32 handles: low words { x_lo, y_lo, z_lo, ρ_lo } of the double-float state (ForceParams::comp; $SPHMI_COMPENSATE=0: none —
+    // the round-3 arithmetic, kept for the drift comparison of tests/test_config_scale_gpu.py).  fp64 handles: none.
+    V4* comp[2] = {};
+    V4* comp_cur() const { return comp[cur]; }
     uint8_t* type[2] = {};
     long long* id[2] = {};
     unsigned long long* grp[2] = {};
@@ -180,6 +184,23 @@ struct Engine final : EngineBase {
     int fuse_ctrl = 1;                 // $SPHMI_FUSE_CTRL=0: a k_step_control launch per step for every handle (experiments)
     int same_cells = 1;                // $SPHMI_SAME_CELLS=0: every rebuild sorts, also when no particle changed its cell
     int64_t n_identity_rebuilds = 0;   // rebuilds that ended at the "nobody moved" test
+    // Device-side rebuilds (round 4).  A cell-list rebuild of the host path waits for the device three times — the bounding box
+    // sizes the grid, the run table sizes the force launches, the measured-work re-schedule sizes them again — which at the
+    // reference's own example sizes (3 k … 160 k particles, a step of 30 … 150 µs) was 112–145 µs per rebuild, 10–19 % of a run.
+    // Handles without a slab and with at most kSmallMaxTiles tiles keep the grid of their last HOST-side rebuild (its bounding box
+    // + kStickySlack cell layers) and rebuild on it without asking the host anything: k_cell_count (flags a particle that left
+    // the grid) → k_scan_single → k_scatter → k_rankfix → k_permute → k_tile_schedule_small, six launches, no round trip; the force
+    // launches run with an upper-bound grid (8 × part_bound blocks) until the next batch boundary delivers the run table.
+    // $SPHMI_DEVICE_REBUILD=0: the host path for every handle.
+    int dev_rebuild = 1;
+    bool count_clean = false;          // `count` is all zero (k_scan_single leaves it so)
+    bool part_copy_queued = false;     // a copy of the run table into part_h is in flight: read it at the next synchronisation
+    int part_bound() const { const int nt = (N + kWave - 1) / kWave; return (nt + 3) / 4 + 1; }
+    bool device_rebuild_ok() const {
+        return dev_rebuild && !dd_slab && have_grid && sticky_grid && (N + kWave - 1) / kWave <= kSmallMaxTiles;
+    }
+    bool sticky_wanted() const { return dev_rebuild && !dd_slab && (N + kWave - 1) / kWave <= kSmallMaxTiles; }
+    bool sticky_grid = false;          // the grid was chosen with slack layers (by a host-side rebuild of a handle that qualifies)
     StepCtrl* ctrl_cur() const { return ctrl_d + cpar; }
     unsigned long long* red_cur() const { return red_d + 4 * rpar; }
     // (decided once per queued batch: before the first rebuild there is no tile schedule and the predictor launch is skipped —
@@ -280,6 +301,11 @@ struct Engine final : EngineBase {
             HC(hipMalloc(&key[k], n * 4));
             HC(hipMalloc(&prow[k], n * 4));
         }
+        {
+            const char* w = getenv("SPHMI_COMPENSATE");
+            if (sizeof(T) == 4 && !(w && atoi(w) == 0))
+                for (int k = 0; k < 2; ++k) { HC(hipMalloc(&comp[k], n * sizeof(V4))); HC(hipMemset(comp[k], 0, n * sizeof(V4))); }
+        }
         HC(hipMalloc(&slot, n * 4)); HC(hipMalloc(&tmp_idx, n * 4)); HC(hipMalloc(&perm, n * 4));
         // $SPHMI_POISON=<byte>: the record sets and the accelerations start out filled with that byte (255 / 127: NaNs of either sign)
         // instead of whatever the allocation held — a row that is read before it was ever written then shows in the results of EVERY
@@ -302,6 +328,7 @@ struct Engine final : EngineBase {
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
         if (const char* w = getenv("SPHMI_FUSE_MDBC")) fuse_mdbc = atoi(w);
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
+        if (const char* w = getenv("SPHMI_DEVICE_REBUILD")) dev_rebuild = atoi(w);
         HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
         HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 8 * 8));
     }
@@ -313,7 +340,7 @@ struct Engine final : EngineBase {
         for (int k = 0; k < 3; ++k) (void)hipFree(rec[k]);
         for (int k = 0; k < 2; ++k) {
             (void)hipFree(acc[k]); (void)hipFree(ghost[k]); (void)hipFree(type[k]); (void)hipFree(id[k]); (void)hipFree(otag[k]);
-            (void)hipFree(grp[k]); (void)hipFree(key[k]); (void)hipFree(prow[k]);
+            (void)hipFree(grp[k]); (void)hipFree(key[k]); (void)hipFree(prow[k]); (void)hipFree(comp[k]);
         }
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); (void)hipEventDestroy(ev_packed); }
         for (auto& e : host_pinned) (void)hipHostUnregister(e.first);
@@ -405,7 +432,7 @@ struct Engine final : EngineBase {
         P.src0 = pk0[src]; P.src1 = pk1[src];
         P.a0 = pk0[a]; P.a1 = pk1[a];
         P.out0 = pk0[out]; P.out1 = pk1[out];
-        P.accbuf = acc[cur];
+        P.accbuf = acc[cur]; P.comp = comp[cur];
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_cur(); P.stats = red_d + 8; P.ctrl = nullptr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
@@ -533,7 +560,7 @@ struct Engine final : EngineBase {
     void progress_motion(double dt2, const StepCtrl* ctrl = nullptr) {
         if (motions.n == 0) return;
         hipLaunchKernelGGL(k_progress_motion<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA], type[cur],
-                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2, ctrl);
+                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2, ctrl, comp[cur]);
         HC(hipGetLastError());
     }
 
@@ -575,15 +602,19 @@ struct Engine final : EngineBase {
             return;
         }
         int64_t ncell = 1;
+        // (handles that rebuild on the device between host-side rebuilds: kStickySlack empty cell layers round the bounding box, so
+        // that the grid outlives the motion of the next rebuild intervals)
+        const int slack = sticky_wanted() ? kStickySlack : 0;
         for (int d = 0; d < 3; ++d) {
             if (d < D) {
                 int64_t n = (int64_t)bbox_h[3 + d] - (int64_t)bbox_h[d] + 1;
                 if (n <= 0 || n > (1ll << 30)) throw EngineError(SPHMI_ERR_NUMERIC, "non-finite particle position in cell hash");
-                grid.gmin[d] = bbox_h[d];
-                grid.np[d] = (int)n + 2;
+                grid.gmin[d] = bbox_h[d] - slack;
+                grid.np[d] = (int)n + 2 + 2 * slack;
             } else { grid.gmin[d] = 0; grid.np[d] = 1; }
             ncell *= grid.np[d];
         }
+        sticky_grid = slack > 0;
         const int64_t budget = cfg.max_cells > 0 ? cfg.max_cells : (1ll << 27);
         if (ncell > budget) {
             char buf[200];
@@ -600,8 +631,9 @@ struct Engine final : EngineBase {
         }
         HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream));
         HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream));
-        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot);
-        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot);
+        count_clean = false;
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr);
         // the scan runs over ncell + 1 entries: entry ncell is the graveyard of dead particles, so
         // cstart[ncell] = number of live particles and cstart[ncell + 1] = N
         const int nscan = (int)ncell + 1;
@@ -622,9 +654,10 @@ struct Engine final : EngineBase {
         A.key_in = key[cur]; A.key_out = key[nxt];
         A.tag_in = otag[cur]; A.tag_out = otag[nxt];
         A.prow_in = prow[cur]; A.prow_out = prow[nxt];
+        A.comp_in = comp[cur]; A.comp_out = comp[nxt];
         // (GhostPoints travel with the sort whenever the caller uploaded some — the reference permutes the column with every other,
         // :142 — not only for mDBC handles: found as uninitialised GhostPoints in a download after an odd number of rebuilds)
-        A.perm = perm; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
+        A.perm = perm; A.flags = nullptr; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
         if (otag[0]) {
             for (int d = 0; d < D; ++d)
@@ -667,6 +700,7 @@ struct Engine final : EngineBase {
             HC(hipGetLastError());
             HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
             HC(hipStreamSynchronize(stream));
+            part_copy_queued = false;
             for (int l = 0; l < 2; ++l) {
                 part_max[l] = 0;
                 list_tiles[l] = 0;
@@ -679,9 +713,84 @@ struct Engine final : EngineBase {
         end_phase(ev);
     }
 
+    // UpdateNeighbors! without the host (small handles, see `dev_rebuild`): the grid of the last host-side rebuild, six launches,
+    // no synchronisation.  `ctrl`: the control block the next queued step reads — a particle outside the grid ends the batch there
+    // with error 3 (Engine::advance then rebuilds on the host with a new grid; nothing was permuted, nothing stepped).
+    SmallSched small_sched(const int* work, int keep_if_empty, StepCtrl* ctrl) const {
+        SmallSched S{};
+        const int ntile = (N + kWave - 1) / kWave;
+        S.key = key[cur]; S.cstart = cstart; S.work = work;
+        S.N = N; S.ntile = ntile; S.nxp = grid.np[0]; S.nxyp = grid.np[0] * grid.np[1]; S.D = D; S.ncell = grid.ncell;
+        S.order = tile_order[0]; S.part = part_d;
+        for (int x = 0; x < 8; ++x) S.W.cum[x + 1] = S.W.cum[x] + (float)((work || !resched) ? xcd_w[x] : 0.125);
+        S.W.cum[8] = 1.0f;
+        S.nclass = tile_classes(ntile); S.bound = part_bound(); S.keep_if_empty = keep_if_empty;
+        S.flags = ctrl ? misc_d : nullptr; S.ctrl = ctrl;
+        return S;
+    }
+    void rebuild_device() {
+        Ev ev = begin_phase(PH_REBUILD);
+        const int nb256 = (N + 255) / 256;
+        const int ncell = grid.ncell;
+        if (!count_clean) { HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream)); HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream)); }
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d);
+        const int nscan = ncell + 1;
+        if (nscan <= kScanSingleMax) {
+            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, count, cstart, nscan, misc_d);
+            count_clean = true;
+        } else {
+            const int ntiles = (nscan + kScanTile - 1) / kScanTile;
+            HC(hipMemsetAsync(misc_d, 0, 2 * 4, stream));
+            hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(kScanThreads), 0, stream, count, cstart, nscan, tsum, misc_d);
+            hipLaunchKernelGGL(k_scan_tsums, dim3(1), dim3(1024), 0, stream, tsum, ntiles, misc_d + 1);
+            hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(kScanThreads), 0, stream, cstart, nscan, tsum, misc_d + 1);
+            count_clean = false;
+        }
+        hipLaunchKernelGGL(k_scatter, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, tmp_idx);
+        hipLaunchKernelGGL(k_rankfix, dim3(nb256), dim3(256), 0, stream, N, key[cur], slot, cstart, ncell, tmp_idx, perm);
+        PermuteArgs<T> A{};
+        const int nxt = cur ^ 1;
+        A.pk0_in = pk0[iA]; A.pk1_in = pk1[iA]; A.acc_in = acc[cur]; A.ghost_in = ghost[cur];
+        A.pk0_out = pk0[iB]; A.pk1_out = pk1[iB]; A.acc_out = acc[nxt]; A.ghost_out = ghost[nxt];
+        A.type_in = type[cur]; A.type_out = type[nxt];
+        A.id_in = id[cur]; A.id_out = id[nxt];
+        A.grp_in = grp[cur]; A.grp_out = grp[nxt];
+        A.key_in = key[cur]; A.key_out = key[nxt];
+        A.prow_in = prow[cur]; A.prow_out = prow[nxt];
+        A.comp_in = comp[cur]; A.comp_out = comp[nxt];
+        A.perm = perm; A.flags = misc_d; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
+        hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
+        std::swap(iA, iB);
+        cur = nxt;
+        HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
+        nonempty_pending = true;
+        hipLaunchKernelGGL(k_tile_schedule_small, dim3(8), dim3(1024), 0, stream, small_sched(nullptr, 0, ctrl_cur()));
+        HC(hipGetLastError());
+        HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
+        part_copy_queued = true;
+        part_max[0] = part_bound(); part_max[1] = 0;
+        list_tiles[0] = (N + kWave - 1) / kWave; list_tiles[1] = 0;
+        n_rebuilds += 1; xcd_sampled = false;
+        sched_state = 1; sched1_state = 0; resched0_pending = false; resched1_pending = false;
+        end_phase(ev);
+    }
+    // (`ctrl_ready`: the control block of the coming batch has been uploaded — a device-side rebuild reports through it)
+    void rebuild_any() { if (device_rebuild_ok()) rebuild_device(); else rebuild(); }
+
     // The schedule of list 0 from the MEASURED work of every tile (the sampled corrector launch just queued): same
     // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.
     void reschedule_from_work(int list) {
+        if (list == 0 && device_rebuild_ok()) {
+            // small handles: one launch, and nobody waits for the table (the launches keep their upper-bound grid until the next
+            // batch boundary has seen it)
+            hipLaunchKernelGGL(k_tile_schedule_small, dim3(8), dim3(1024), 0, stream, small_sched(tile_work_d, 1, nullptr));
+            HC(hipGetLastError());
+            HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
+            part_copy_queued = true;
+            part_max[0] = part_bound();
+            return;
+        }
         const int ntile = (N + kWave - 1) / kWave;
         const int sb = (ntile + kScanTile - 1) / kScanTile;
         int* work = list == 0 ? tile_work_d : tile_work1_d;
@@ -698,6 +807,7 @@ struct Engine final : EngineBase {
         // (≈30 µs every ≈40 steps); a sample whose step was cancelled left the table as it was
         HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
+        part_copy_queued = false;
         int m = 0;
         for (int x = 0; x < 8; ++x) m = std::max(m, part_h[16 * list + 8 + x]);
         if (m > 0) part_max[list] = m;
@@ -709,7 +819,7 @@ struct Engine final : EngineBase {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
         M.ctrl = ctrl;
-        M.pk0 = pk0[iA]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_cur(); M.N = N;
+        M.pk0 = pk0[iA]; M.comp = comp[cur]; M.ghost = ghost[cur]; M.type = type[cur]; M.cstart = cstart; M.g = grid; M.red = red_cur(); M.N = N;
         if (take_control) {
             M.ctrl = nullptr;
             M.ctl_in = ctrl_d + cpar; M.ctl_out = ctrl_d + (cpar ^ 1);
@@ -729,7 +839,13 @@ struct Engine final : EngineBase {
         HC(hipStreamSynchronize(stream));
         collect_events(batch_ctrl ? batch_ctrl->steps_done - steps_before : INT64_MAX);
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
-
+        if (part_copy_queued) {
+            // the run table of the last device-side (re-)schedule has arrived: the exact grid from here on
+            part_copy_queued = false;
+            int m = 0;
+            for (int x = 0; x < 8; ++x) m = std::max(m, part_h[8 + x]);
+            if (m > 0) part_max[0] = std::min(m, part_bound());
+        }
     }
 
     void fill(sphmi_progress* out, int64_t steps) {
@@ -788,8 +904,13 @@ struct Engine final : EngineBase {
         c.delta_x = delta_x; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
         c.max_steps = max_steps; c.last_dt = last_dt;
         try {
+            // The first iteration of the loop always rebuilds (Δx = 1 + h ≥ h, :739,758): when there will BE a first iteration the
+            // rebuild is run now and the control is told (StepCtrl::pre_rebuilt) — not a one-step batch that the control cancels.
+            const bool pre = total_time <= t_target && max_steps != 0;
+            if (pre) { c.pre_rebuilt = 1; delta_x = 0.0; }
             *ctrl_h = c;
             HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+            if (pre) rebuild_any();                                               // (behind the upload: a device-side rebuild reports through the block)
             for (;;) {
                 const int a0 = iA, b0 = iB;
                 const int rpar0 = rpar;
@@ -823,6 +944,15 @@ struct Engine final : EngineBase {
                     if (grown > 0 && dx0 < cfg.h && c.delta_x > dx0) dx_rate = (c.delta_x - dx0) / (double)grown;
                 }
                 if (c.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
+                if (c.error == 3) {
+                    // a particle left the grid of the last device-side rebuild: that rebuild copied instead of permuting and the
+                    // control cancelled every step behind it — the same rebuild again, on the host, with a new grid
+                    rebuild();
+                    c.error = 0;
+                    *ctrl_h = c;
+                    HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+                    continue;
+                }
                 if (c.error) {
                     char buf[160];
                     snprintf(buf, sizeof(buf), "non-positive or NaN dt (%g) at iteration %lld (visc %g, |a|max %g, Δx %g)",
@@ -830,10 +960,10 @@ struct Engine final : EngineBase {
                     throw EngineError(SPHMI_ERR_NUMERIC, buf);
                 }
                 if (c.need_rebuild) {                                             // :758-762
-                    rebuild();
                     c.delta_x = 0.0; c.need_rebuild = 0; delta_x = 0.0;           // resume stays set: the queued step re-uses its Δt
                     *ctrl_h = c;
                     HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+                    rebuild_any();
                     continue;
                 }
                 if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) {
@@ -852,7 +982,7 @@ struct Engine final : EngineBase {
     // ---- upload / download --------------------------------------------------------------------
     template <class H> void pack_host(const void* position, const void* velocity, const void* acceleration,
                                       const void* density, const uint8_t* ty, const void* ghost_points,
-                                      std::vector<V4>& h0, std::vector<V4>& h1, std::vector<V4>& ha, std::vector<V4>& hg) {
+                                      std::vector<V4>& h0, std::vector<V4>& h1, std::vector<V4>& ha, std::vector<V4>& hg, std::vector<V4>& hc) {
         const H* x = (const H*)position; const H* v = (const H*)velocity; const H* a = (const H*)acceleration;
         const H* r = (const H*)density; const H* g = (const H*)ghost_points;
         for (int i = 0; i < N; ++i) {
@@ -868,6 +998,14 @@ struct Engine final : EngineBase {
                 pg.w = nz ? T(1) : T(0);
             }
             h0[i] = p0; h1[i] = p1; ha[i] = pa; hg[i] = pg;
+            if (!hc.empty()) {
+                // what the caller's value holds beyond the fp32 record (zero for a Float32 caller)
+                V4 c{};
+                c.x = (T)((double)x[i * D] - (double)p0.x); c.y = (T)((double)x[i * D + 1] - (double)p0.y);
+                c.z = D == 3 ? (T)((double)x[i * D + 2] - (double)p0.z) : T(0);
+                c.w = (T)((double)r[i] - (double)(T)r[i]);
+                hc[i] = c;
+            }
         }
     }
 
@@ -878,9 +1016,9 @@ struct Engine final : EngineBase {
         for (int i = 0; i < N; ++i) {
             if (ty[i] < 1 || ty[i] > 3) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: ParticleType must be 1, 2 or 3");
         }
-        std::vector<V4> h0(N), h1(N), ha(N), hg(N);
-        if (cfg.host_float_bytes == 8) pack_host<double>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg);
-        else pack_host<float>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg);
+        std::vector<V4> h0(N), h1(N), ha(N), hg(N), hc(comp[0] ? N : 0);
+        if (cfg.host_float_bytes == 8) pack_host<double>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg, hc);
+        else pack_host<float>(position, velocity, acceleration, density, ty, ghost_points, h0, h1, ha, hg, hc);
         for (int i = 0; i < N; ++i)
             if (!(std::fabs((double)h0[i].w) > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
         iA = 0; iH = 1; iB = 2; cur = 0;
@@ -891,6 +1029,7 @@ struct Engine final : EngineBase {
         bounce.h2d(rec[iA], hrec.data(), 2 * n * sizeof(V4), stream);
         bounce.h2d(acc[cur], ha.data(), n * sizeof(V4), stream);
         bounce.h2d(ghost[cur], hg.data(), n * sizeof(V4), stream);
+        if (comp[cur]) bounce.h2d(comp[cur], hc.data(), n * sizeof(V4), stream);
         bounce.h2d(type[cur], ty, n, stream);
         bounce.h2d(id[cur], ids, n * 8, stream);
         if (groups) bounce.h2d(grp[cur], groups, n * 8, stream);
@@ -947,13 +1086,13 @@ struct Engine final : EngineBase {
                 bounce.d2h(tot, tot_d, 8, stream);
                 if ((long long)base + tot[1] + nf > cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: n_particles of the handle is smaller than the lattice (sphmi_dam_break_3d_count)");
                 hipLaunchKernelGGL(k_gen_boundary<T>, dim3(nbM), dim3(256), 0, stream, G, M, (const int*)flag, (const int*)pos, base, pk0[iA], pk1[iA],
-                                   type[cur], id[cur], grp[cur]);
+                                   type[cur], id[cur], grp[cur], comp[cur]);
                 HC(hipGetLastError());
                 base += tot[1];
             }
             if ((long long)base + nf != (long long)cap) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_generate_dam_break_3d: n_particles of the handle differs from the lattice (sphmi_dam_break_3d_count)");
             N = cap;
-            hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur]);
+            hipLaunchKernelGGL(k_gen_fluid<T>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, G, base, (int)nf, pk0[iA], pk1[iA], type[cur], id[cur], grp[cur], comp[cur]);
             const size_t n = (size_t)N;
             HC(hipMemsetAsync(acc[cur], 0, n * sizeof(V4), stream)); HC(hipMemsetAsync(ghost[cur], 0, n * sizeof(V4), stream));
             HC(hipMemsetAsync(key[cur], 0, n * 4, stream)); HC(hipMemsetAsync(red_d, 0, 8 * 8, stream)); cpar = 0; rpar = 0;
@@ -1031,7 +1170,7 @@ struct Engine final : EngineBase {
         char* a_id = take(ids, n * 8); char* a_ty = take(ty, n); char* a_grp = take(groups, n * 8);
         char* a_tag = take(dl_tags_host != nullptr && otag[0], n * 8);
         hipLaunchKernelGGL((k_pack_output<T, H>), dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA],
-                           stepped ? Half<const V4>(pk0[iH]) : Half<const V4>(), acc[cur], ghost[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
+                           stepped ? Half<const V4>(pk0[iH]) : Half<const V4>(), acc[cur], ghost[cur], comp[cur], key[cur], N, D, out_comp, grid, have_grid ? 1 : 0,
                            (T)cfg.rho0, (T)(1.0 / cfg.rho0), (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0), o);
         HC(hipGetLastError());
         if (a_id) HC(hipMemcpyAsync(a_id, id[cur], n * 8, hipMemcpyDeviceToDevice, stream));
@@ -1228,7 +1367,7 @@ struct Engine final : EngineBase {
         if (n <= 0) return;
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_gather<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           ghost[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], idx_dev, (int)n, buf_dev);
+                           ghost[cur], comp[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], idx_dev, (int)n, buf_dev);
         HC(hipGetLastError());
     }
     void dd_kill(const int32_t* idx_dev, int64_t n) {
@@ -1247,7 +1386,7 @@ struct Engine final : EngineBase {
         if ((int64_t)N + n > cap) throw EngineError(SPHMI_ERR_DOMAIN, "domain decomposition: rank capacity exceeded (too many arrivals)");
         HC(hipSetDevice(cfg.device));
         hipLaunchKernelGGL(k_dd_append<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pk0[iA], pk1[iA], acc[cur],
-                           ghost[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
+                           ghost[cur], comp[cur], id[cur], grp[cur], otag[cur], prow[cur], type[cur], N, (int)n, const_cast<void*>(buf_dev), (uint8_t)flag);
         HC(hipGetLastError());
         N += (int)n;
     }
@@ -1263,10 +1402,10 @@ struct Engine final : EngineBase {
     // ---- device-side step control for the slab driver: same k_step_control as Engine::advance, fed with the
     // MAX-allreduced reduction slots, so the host looks at the flags once per batch of queued steps --------------
     bool dd_ctrl_on = false; int dd_a0 = 0, dd_b0 = 0; int64_t dd_steps_at_sync = 0;
-    void dd_ctrl_init(double dx0, double t_target, int64_t max_steps) {
+    void dd_ctrl_init(double dx0, double t_target, int64_t max_steps, bool pre_rebuilt) {
         HC(hipSetDevice(cfg.device));
         StepCtrl c{};
-        c.delta_x = dx0; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
+        c.delta_x = dx0; c.pre_rebuilt = pre_rebuilt ? 1 : 0; c.total_time = total_time; c.t_step_start = total_time; c.t_target = t_target;
         c.max_steps = max_steps; c.last_dt = last_dt;
         *ctrl_h = c;
         HC(hipMemcpyAsync(ctrl_d, ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));

@@ -98,8 +98,10 @@ struct StepCtrl {
     int need_rebuild;          // Δx ≥ h: the host rebuilds the cell list, clears the flag and re-queues the step
     int resume;                // the step after a rebuild re-uses the Δt already computed
     int stop;                  // TotalTime > t_target or max_steps reached
-    int error;                 // 1: non-positive / NaN Δt, 2: non-positive density
-    int pad;
+    int error;                 // 1: non-positive / NaN Δt, 2: non-positive density, 3: a particle left the cell grid of a device-side rebuild
+    int pre_rebuilt;           // the rebuild this control is about to ask for has been served already: every SimulationLoop call opens
+                               // with one (Δx re-armed to 1 + h, src/SPHCellList.jl:739,758-762), so the host runs it BEFORE queueing the
+                               // first step instead of queueing a one-step batch for the control to cancel (≈60 µs per call)
 };
 
 // one thread: the per-step decisions of Δt (src/TimeStepping.jl:30-43) and update_delta_x! on the reduction slots the
@@ -128,7 +130,10 @@ __device__ __forceinline__ bool step_control_decide(unsigned long long r0, unsig
         c.last_visc = visc; c.last_amax = amax;
         c.dt = dt; c.dt2 = dt * 0.5;
         if (!(dt > 0.0) || dt != dt || c.delta_x != c.delta_x) { c.error = 1; c.active = 0; return false; }
-        if (c.delta_x >= h) { c.need_rebuild = 1; c.resume = 1; c.active = 0; return false; }
+        if (c.delta_x >= h) {
+            if (c.pre_rebuilt) { c.pre_rebuilt = 0; c.delta_x = 0.0; }          // :760-761, served before it was asked for
+            else { c.need_rebuild = 1; c.resume = 1; c.active = 0; return false; }
+        }
     }
     c.resume = 0;
     c.t_step_start = c.total_time;
@@ -160,6 +165,12 @@ struct ForceParams {
     Half<V4> out0;       // H (predictor) or B (corrector)
     Half<V4> out1;
     V4* accbuf;          // { a, dρ/dt }
+    // fp32 handles: the low words of the double-float state, { x_lo, y_lo, z_lo, ρ_lo } per particle (state A / B: x = pk0.xyz + lo,
+    // ρ = |pk0.w| + lo).  The record sets hold what the NEIGHBOURS see — the state rounded to fp32, an error of half an ulp that
+    // does not accumulate; the corrector epilogue integrates the full value, so that the state no longer loses one fp32 rounding of
+    // ρ ≈ 1000 and of x per step (round 3: ρ error 5.9e-6 after 100 steps at 1 M particles, linear in the step count).  In place:
+    // only the lane of a particle ever touches its entry.  Null: fp64 handles (and $SPHMI_COMPENSATE=0).
+    V4* comp;
     const int* key;      // padded linear cell id of every sorted particle
     const int* cstart;   // exclusive scan of cell counts, ncell+1 entries
     const uint8_t* type;
@@ -1048,10 +1059,24 @@ k_neighbor_force(const ForceParams<T> P) {
         // (src/SPHCellList.jl:794-798, 640-652; src/SimulationEquations.jl:28-33)
         const V4 s0 = P.a0[ac];
         const V4 s1 = P.a1[ac];
-        T rho_n = absT(s0.w);
-        if (!fluid_a && rho_n < P.rho0) rho_n = P.rho0;
+        // fp32 handles integrate ρ and x as double-floats (ForceParams::comp): state = what the record holds + the low word
+        constexpr bool kComp = sizeof(T) == 4;
+        const bool comp_on = kComp && P.comp != nullptr;
+        V4 lo4; lo4.x = lo4.y = lo4.z = lo4.w = T(0);
+        if (comp_on) lo4 = P.comp[ac];
         const T epsi = -(drho / rho_a) * step_dt;
-        const T rho_new = rho_n * ((T(2) - epsi) / (T(2) + epsi));
+        T rho_new;
+        [[maybe_unused]] double rho_new_d = 0.0;
+        if (comp_on) {
+            double rho_n_d = (double)absT(s0.w) + (double)lo4.w;
+            if (!fluid_a && rho_n_d < (double)P.rho0) rho_n_d = (double)P.rho0;
+            rho_new_d = rho_n_d * ((2.0 - (double)epsi) / (2.0 + (double)epsi));
+            rho_new = (T)rho_new_d;
+        } else {
+            T rho_n = absT(s0.w);
+            if (!fluid_a && rho_n < P.rho0) rho_n = P.rho0;
+            rho_new = rho_n * ((T(2) - epsi) / (T(2) + epsi));
+        }
         if constexpr (D == 3) az += P.g * gf; else ay += P.g * gf;
         const T adx = ax * step_dt * ml, ady = ay * step_dt * ml, adz = az * step_dt * ml;
         V4 o0, o1, oa;
@@ -1065,15 +1090,23 @@ k_neighbor_force(const ForceParams<T> P) {
                 sx = k * gcx; sy = k * gcy; sz = k * gcz;
             }
         }
-        o0.x = s0.x + (((o1.x + (o1.x - adx)) / T(2)) * step_dt + sx) * ml;
-        o0.y = s0.y + (((o1.y + (o1.y - ady)) / T(2)) * step_dt + sy) * ml;
-        o0.z = s0.z + (((o1.z + (o1.z - adz)) / T(2)) * step_dt + sz) * ml;
+        const T ix = (((o1.x + (o1.x - adx)) / T(2)) * step_dt + sx) * ml;
+        const T iy = (((o1.y + (o1.y - ady)) / T(2)) * step_dt + sy) * ml;
+        const T iz = (((o1.z + (o1.z - adz)) / T(2)) * step_dt + sz) * ml;
+        if (comp_on) {
+            const double xd = ((double)s0.x + (double)lo4.x) + (double)ix, yd = ((double)s0.y + (double)lo4.y) + (double)iy,
+                         zd = ((double)s0.z + (double)lo4.z) + (double)iz;
+            o0.x = (T)xd; o0.y = (T)yd; o0.z = (T)zd;
+            lo4.x = (T)(xd - (double)o0.x); lo4.y = (T)(yd - (double)o0.y); lo4.z = (T)(zd - (double)o0.z);
+            lo4.w = (T)(rho_new_d - (double)rho_new);
+        } else { o0.x = s0.x + ix; o0.y = s0.y + iy; o0.z = s0.z + iz; }
         o0.w = fluid_a ? rho_new : -rho_new;
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;
         if (owned) {
             if (MODEL < 0 && P.kout) { V4 ko; ko.x = kgx; ko.y = kgy; ko.z = kgz; ko.w = kw; P.kout[a] = ko; }
             P.out0[a] = o0; P.out1[a] = o1; P.accbuf[a] = oa;
+            if (comp_on) P.comp[a] = lo4;
             // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive
             if (!(rho_new > T(0))) atomicOr(&P.red[3], 1ull);
         }

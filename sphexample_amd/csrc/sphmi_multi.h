@@ -1121,17 +1121,20 @@ struct MultiEngine final : EngineBase {
         if (!uploaded) throw EngineError(SPHMI_ERR_STATE, "sphmi_advance before sphmi_upload");
         double dxl = 1.0 + cfg.h;                                        // :739
         int64_t steps = 0;
-        for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->total_time = total_time; r.e->last_dt = last_dt; r.e->dd_ctrl_init(dxl, t_target, max_steps); }
-        bool first = true;
+        // the first iteration of the loop always rebuilds (:758): run it now when there will be one (StepCtrl::pre_rebuilt) instead of
+        // a one-step batch — allreduce, four messages — that the control cancels
+        const bool pre = total_time <= t_target && max_steps != 0;
         sphmi_dd_control st{};
         try {
+            if (pre) rebuild_collective();
+            for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->total_time = total_time; r.e->last_dt = last_dt; r.e->dd_ctrl_init(dxl, t_target, max_steps, pre); }
+            if (pre) dxl = 0.0;
             for (;;) {
                 // A step that asks for a rebuild cancels the rest of its batch, and a cancelled step still pays its allreduce
                 // and its messages: queue up to the step EXPECTED to ask (Δx grows by 4·max|Δx| a step, slowly changing).
                 int batch = kBatch;
                 if (dx_rate > 0.0) batch = std::max(1, std::min(batch, (int)((cfg.h - dxl) / dx_rate) + 1));
                 if (max_steps >= 0) batch = (int)std::max<int64_t>(1, std::min<int64_t>(batch, max_steps - steps));
-                if (first) { batch = 1; first = false; }                 // Δx re-armed: the first control of a call always asks
                 const double dx0 = dxl; const int64_t steps0 = steps;
                 for (int k = 0; k < batch; ++k) {
                     reductions_and_control();

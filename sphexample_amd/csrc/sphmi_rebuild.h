@@ -83,9 +83,14 @@ __global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::
     }
 }
 
+// `flags` (device-side rebuilds, Engine::rebuild_device): the grid is the one the LAST host-side rebuild chose — the bounding box of
+// then plus kStickySlack cell layers — so a particle may have left it: flags[kFlagOverflow] is raised and the cell is clamped
+// (the launches that follow stay memory-safe; their results are discarded: k_permute copies instead of permuting, the step control
+// stops with error 3 and the host rebuilds on a new grid).
+constexpr int kStickySlack = 2, kFlagOverflow = 7, kFlagOverflowSeen = 6;
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_count(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
-                                                    T inv_cutoff, GridDesc g, int* count, int* key, int* slot) {
+                                                    T inv_cutoff, GridDesc g, int* count, int* key, int* slot, int* flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int k = -1;                               // lanes past the end: a key no particle has
@@ -94,6 +99,14 @@ __global__ void __launch_bounds__(256) k_cell_count(Half<const typename Vec4<T>:
         int cx = map_floor<T>(p.x, inv_cutoff) - g.gmin[0] + 1;
         int cy = map_floor<T>(p.y, inv_cutoff) - g.gmin[1] + 1;
         int cz = D == 3 ? map_floor<T>(p.z, inv_cutoff) - g.gmin[2] + 1 : 0;
+        if (flags) {
+            const bool out = cx < 1 || cx > g.np[0] - 2 || cy < 1 || cy > g.np[1] - 2 || (D == 3 && (cz < 1 || cz > g.np[2] - 2));
+            if (out && type[i] != 0) {
+                atomicOr(&flags[kFlagOverflow], 1);
+                cx = min(max(cx, 1), g.np[0] - 2); cy = min(max(cy, 1), g.np[1] - 2);
+                if (D == 3) cz = min(max(cz, 1), g.np[2] - 2);
+            }
+        }
         k = cx + g.np[0] * (cy + g.np[1] * cz);
         if (type[i] == 0) k = g.ncell;        // dead particles sort behind every cell ("graveyard" key)
         key[i] = k;
@@ -206,6 +219,39 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_add_nototal(int* out, int
         int idx = base + k;
         if (idx < n) out[idx] += off;
     }
+}
+
+// The same scan in ONE launch of one workgroup, for the cell histograms of the small handles (≤ kScanSingleMax entries: every stock
+// example of the reference): three launches → one.  Consumes `in` — it is left zeroed for the next rebuild's k_cell_count — and
+// leaves the number of non-empty entries in misc[0] and the total in misc[1] and out[n].
+constexpr int kScanSingleMax = 1 << 16;
+__global__ void __launch_bounds__(1024) k_scan_single(int* in, int* out, int n, int* misc) {
+    __shared__ int s_w[16], s_nz[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0, nonempty = 0;
+    for (int b0 = 0; b0 < n; b0 += 4096) {
+        const int base = b0 + (int)threadIdx.x * 4;
+        int v[4], sum = 0, nz = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = base + k; const int x = idx < n ? in[idx] : 0; if (idx < n) in[idx] = 0; v[k] = sum; sum += x; nz += x != 0; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) nz += __shfl_xor(nz, o, 64);
+        if (lane == 63) s_w[w] = inc;
+        if (lane == 0) s_nz[w] = nz;
+        __syncthreads();
+        int woff = 0, tot = 0, tnz = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int t = s_w[k]; if (k < w) woff += t; tot += t; tnz += s_nz[k]; }
+        const int excl = carry + woff + inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = base + k; if (idx < n) out[idx] = v[k] + excl; }
+        carry += tot; nonempty += tnz;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[n] = carry; misc[0] = nonempty; misc[1] = carry; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -343,6 +389,116 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
     if (threadIdx.x == 0) { part[x] = out0; part[8 + x] = s_off - out0; }    // run start in order[], tiles in the run
 }
 
+// The tile schedule of a SMALL handle (≤ kSmallMaxTiles tiles, no slab) in ONE launch: k_tile_cost + the three scan launches +
+// k_tile_order, every one of the eight workgroups (one per XCD run) repeating the costs and their scan in LDS.  `work`: the
+// measured work of the tiles instead of the estimate (Engine::reschedule_from_work).  `bound`: no run may be longer — the host
+// launches 8 × bound blocks until it has seen the table (it no longer waits for it), so the run boundaries are clamped to it.
+constexpr int kSmallMaxTiles = 4096;
+struct SmallSched {
+    const int* key; const int* cstart; const int* work;
+    int N, ntile, nxp, nxyp, D, ncell;
+    int* order; int* part;
+    XcdShares W;
+    int nclass, bound, keep_if_empty;
+    int* flags; StepCtrl* ctrl;      // block 0 hands a grid overflow of this rebuild to the step control (error 3) and re-arms the flag
+};
+__global__ void __launch_bounds__(1024) k_tile_schedule_small(const SmallSched S) {
+    __shared__ int s_cost[kSmallMaxTiles], s_scan[kSmallMaxTiles + 1], s_w[16], s_b[9], s_min, s_max, s_wsum[16], s_off;
+    const int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntile = S.ntile;
+    if (x == 0 && tid == 0 && S.flags) {
+        if (S.flags[kFlagOverflow]) { if (S.ctrl) S.ctrl->error = 3; S.flags[kFlagOverflowSeen] = 1; S.flags[kFlagOverflow] = 0; }
+    }
+    for (int t = tid; t < ntile; t += 1024) {
+        int c;
+        if (S.work) c = S.work[t];
+        else {
+            const int kf = S.key[t * 64], kl0 = S.key[min(t * 64 + 63, S.N - 1)];
+            const int nseg = S.D == 3 ? 9 : 3;
+            const int kl = min(kl0, S.ncell - 1);
+            c = 64;
+            for (int seg = 0; seg < nseg && kf < S.ncell; ++seg) {
+                const int off = S.D == 3 ? ((seg % 3) - 1) * S.nxp + ((seg / 3) - 1) * S.nxyp : (seg - 1) * S.nxp;
+                c += S.cstart[min(kl + off + 2, S.ncell)] - S.cstart[max(kf + off - 1, 0)];
+            }
+            if (kf >= S.ncell) c = 0;
+        }
+        s_cost[t] = c;
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int b0 = 0; b0 < ntile; b0 += 1024) {
+        const int idx = b0 + tid;
+        const int v = idx < ntile ? s_cost[idx] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int t = s_w[k]; if (k < w) woff += t; tot += t; }
+        if (idx < ntile) s_scan[idx] = carry + woff + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+    const long long total = carry;
+    if (tid == 0) s_scan[ntile] = carry;
+    if (total <= 0) {
+        if (!S.keep_if_empty && tid == 0) { S.part[x] = 0; S.part[8 + x] = 0; }
+        return;
+    }
+    __syncthreads();
+    if (tid <= 8) {
+        // run boundaries by cost share (first t with scan[t] >= share), as k_tile_order finds them
+        const long long v = (long long)((double)total * (double)S.W.cum[tid]);
+        int lo = 0, hi = ntile;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_scan[mid] < v) lo = mid + 1; else hi = mid; }
+        s_b[tid] = tid == 0 ? 0 : (tid == 8 ? ntile : lo);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // no run longer than `bound` (8 × bound ≥ ntile): one forward pass
+        int s = 0;
+        for (int r = 0; r < 8; ++r) {
+            int e = s_b[r + 1];
+            e = min(e, s + S.bound); e = max(e, ntile - (7 - r) * S.bound); e = max(e, s); e = min(e, ntile);
+            s_b[r] = s; s = e;
+        }
+        s_b[8] = ntile;
+        s_min = INT32_MAX; s_max = INT32_MIN;
+    }
+    __syncthreads();
+    const int beg = s_b[x], end = s_b[x + 1];
+    if (tid == 0) s_off = beg;
+    int mn = INT32_MAX, mx = INT32_MIN;
+    for (int t = beg + tid; t < end; t += 1024) { const int c = s_cost[t]; if (c > 0) { mn = min(mn, c); mx = max(mx, c); } }
+    if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    const int cmin = s_min;
+    const float scale = s_max > cmin ? (float)S.nclass / (float)(s_max - cmin + 1) : 0.f;
+    auto cls_of = [&](int c) { return S.nclass - 1 - min(S.nclass - 1, (int)((float)(c - cmin) * scale)); };
+    for (int cls = 0; cls < S.nclass; ++cls) {
+        for (int t0 = beg; t0 < end; t0 += 1024) {
+            const int t = t0 + tid;
+            const int c = t < end ? s_cost[t] : 0;
+            const bool in = c > 0 && cls_of(c) == cls;
+            const unsigned long long bal = __ballot(in);
+            const int below = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wsum[w] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int q = 0; q < 16; ++q) { const int v = s_wsum[q]; if (q < w) woff += v; tot += v; }
+            const int base = s_off;
+            if (in) S.order[base + woff + below] = t;
+            __syncthreads();
+            if (tid == 0) s_off = base + tot;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { S.part[x] = beg; S.part[8 + x] = s_off - beg; }
+}
+
 __global__ void __launch_bounds__(256) k_scatter(int N, const int* key, const int* slot, const int* cstart,
                                                  int* tmp_idx) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,8 +563,10 @@ struct PermuteArgs {
     const unsigned long long* grp_in; unsigned long long* grp_out;
     const int* key_in; int* key_out;
     const unsigned long long* tag_in; unsigned long long* tag_out;     // order tags (domain decomposition only)
-    const int* prow_in; int* prow_out;                                 // row at the last sphmi_download_permutation (single-device handles)
+    const int* prow_in; int* prow_out;                                 // row at the last sphmi_download_permutation
+    const V4* comp_in; V4* comp_out;                                   // low words of the double-float state (fp32 handles; else null)
     const int* perm;
+    const int* flags;          // device-side rebuilds: flags[kFlagOverflow] set → copy instead of permuting (the order stays what it was)
     int N, has_ghost;
 };
 
@@ -416,7 +574,7 @@ template <class T>
 __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.N) return;
-    const int i = A.perm[p];
+    const int i = (A.flags && A.flags[kFlagOverflow]) ? p : A.perm[p];
     A.pk0_out[p] = A.pk0_in[i];
     A.pk1_out[p] = A.pk1_in[i];
     A.acc_out[p] = A.acc_in[i];
@@ -427,6 +585,7 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     A.key_out[p] = A.key_in[i];
     if (A.tag_in) A.tag_out[p] = A.tag_in[i];
     if (A.prow_in) A.prow_out[p] = A.prow_in[i];
+    if (A.comp_in) A.comp_out[p] = A.comp_in[i];
 }
 __global__ void __launch_bounds__(256) k_iota(int* out, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,6 +630,7 @@ __global__ void __launch_bounds__(256) k_init_reduce(Half<const typename Vec4<T>
 template <class T> struct MdbcParams {
     using V4 = typename Vec4<T>::type;
     Half<V4> pk0;          // state A: ρ of boundary particles is rewritten in place
+    V4* comp;              // fp32 handles: the low word of the rewritten ρ goes with it (ForceParams::comp); else null
     const V4* ghost;       // { g, flag }  flag != 0 ⇔ !iszero(GhostPoint)
     const uint8_t* type;   // ghost-copy bits (domain decomposition)
     const int* cstart;
@@ -696,8 +856,10 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
             if (M.type[i] & kGhostMask) return;
             atomicOr(&M.red[3], 1ull);
         }
-        me.w = me.w > T(0) ? (T)newrho : (T)(-newrho);
+        const T hi = (T)newrho;
+        me.w = me.w > T(0) ? hi : -hi;
         M.pk0[i] = me;
+        if (sizeof(T) == 4 && M.comp) M.comp[i].w = (T)(newrho - (R)hi);
     }
 }
 
@@ -711,7 +873,8 @@ template <class H> struct OutFields {
 template <class T, class H>
 __global__ void __launch_bounds__(256) k_pack_output(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                      Half<const typename Vec4<T>::type> half0, const typename Vec4<T>::type* accv,
-                                                     const typename Vec4<T>::type* ghostv, const int* key, int N, int D, int C,
+                                                     const typename Vec4<T>::type* ghostv, const typename Vec4<T>::type* comp,
+                                                     const int* key, int N, int D, int C,
                                                      GridDesc g, int have_grid, T rho0, T inv_rho0, T Cbe, OutFields<H> o) {
     // C: components per vector in the output (D, or 3 for the VTKHDF point layout: 2-D handles keep z = 0)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,8 +882,15 @@ __global__ void __launch_bounds__(256) k_pack_output(Half<const typename Vec4<T>
     const size_t b = (size_t)i * C;
     if (o.pos || o.rho) {
         const auto q = pk0[i];
-        if (o.pos) { o.pos[b] = (H)q.x; o.pos[b + 1] = (H)q.y; if (C == 3) o.pos[b + 2] = (H)q.z; }
-        if (o.rho) o.rho[i] = (H)(q.w < T(0) ? -q.w : q.w);
+        if (sizeof(T) == 4 && comp) {
+            // fp32 handles: the state is the record + its low word (ForceParams::comp) — a Float64 caller gets both
+            const auto c = comp[i];
+            if (o.pos) { o.pos[b] = (H)((double)q.x + (double)c.x); o.pos[b + 1] = (H)((double)q.y + (double)c.y); if (C == 3) o.pos[b + 2] = (H)((double)q.z + (double)c.z); }
+            if (o.rho) o.rho[i] = (H)((double)(q.w < T(0) ? -q.w : q.w) + (double)c.w);
+        } else {
+            if (o.pos) { o.pos[b] = (H)q.x; o.pos[b + 1] = (H)q.y; if (C == 3) o.pos[b + 2] = (H)q.z; }
+            if (o.rho) o.rho[i] = (H)(q.w < T(0) ? -q.w : q.w);
+        }
     }
     if (o.vel || (o.press && !half0)) {
         const auto q = pk1[i];
@@ -784,7 +954,7 @@ __global__ void __launch_bounds__(256) k_gen_flags(DamBreakGrid G, long long M, 
 template <class T>
 __global__ void __launch_bounds__(256) k_gen_boundary(DamBreakGrid G, long long M, const int* flag, const int* pos, int base,
                                                       Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1, uint8_t* type,
-                                                      long long* id, unsigned long long* grp) {
+                                                      long long* id, unsigned long long* grp, typename Vec4<T>::type* comp) {
 #pragma clang fp contract(off)        // o + dp·i rounded twice, as the host generator (and GenCase's files) have it
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= M || !flag[s]) return;
@@ -792,25 +962,38 @@ __global__ void __launch_bounds__(256) k_gen_boundary(DamBreakGrid G, long long 
     const int p = base + pos[s];
     typename Vec4<T>::type q0, q1;
     const double o = G.dp / 2;
-    q0.x = (T)(o + G.dp * (double)i); q0.y = (T)(o + G.dp * (double)j); q0.z = (T)(o + G.dp * (double)k);
+    const double xd = o + G.dp * (double)i, yd = o + G.dp * (double)j, zd = o + G.dp * (double)k;
+    q0.x = (T)xd; q0.y = (T)yd; q0.z = (T)zd;
     q0.w = -(T)G.rho0;                                  // Fixed: MotionLimiter 0 → negative sign
     q1.x = q1.y = q1.z = q1.w = T(0);
     pk0[p] = q0; pk1[p] = q1; type[p] = 2; id[p] = p + 1; grp[p] = 1;
+    if (comp) {                                         // what the Float64 layout holds beyond the fp32 record (sphmi_upload does the same)
+        typename Vec4<T>::type c;
+        c.x = (T)(xd - (double)q0.x); c.y = (T)(yd - (double)q0.y); c.z = (T)(zd - (double)q0.z); c.w = (T)(G.rho0 - (double)(T)G.rho0);
+        comp[p] = c;
+    }
 }
 template <class T>
 __global__ void __launch_bounds__(256) k_gen_fluid(DamBreakGrid G, int nb, int nf, Half<typename Vec4<T>::type> pk0,
-                                                   Half<typename Vec4<T>::type> pk1, uint8_t* type, long long* id, unsigned long long* grp) {
+                                                   Half<typename Vec4<T>::type> pk1, uint8_t* type, long long* id, unsigned long long* grp,
+                                                   typename Vec4<T>::type* comp) {
 #pragma clang fp contract(off)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
     const int k = f % G.fk + 1, j = (f / G.fk) % G.fj + 1, i = f / (G.fk * G.fj) + 1;
     const double o = G.dp / 2, z = o + G.dp * (double)k, ztop = o + G.dp * (double)G.fk;
     typename Vec4<T>::type q0, q1;
-    q0.x = (T)(o + G.dp * (double)i); q0.y = (T)(o + G.dp * (double)j); q0.z = (T)z;
-    q0.w = (T)(G.rho0 * pow(1.0 + G.rho0 * G.g * (ztop - z) / G.B, 1.0 / 7.0));
+    const double xd = o + G.dp * (double)i, yd = o + G.dp * (double)j, rd = G.rho0 * pow(1.0 + G.rho0 * G.g * (ztop - z) / G.B, 1.0 / 7.0);
+    q0.x = (T)xd; q0.y = (T)yd; q0.z = (T)z;
+    q0.w = (T)rd;
     q1.x = q1.y = q1.z = q1.w = T(0);
     const int p = nb + f;
     pk0[p] = q0; pk1[p] = q1; type[p] = 1; id[p] = p + 1; grp[p] = 2;
+    if (comp) {
+        typename Vec4<T>::type c;
+        c.x = (T)(xd - (double)q0.x); c.y = (T)(yd - (double)q0.y); c.z = (T)(z - (double)q0.z); c.w = (T)(rd - (double)q0.w);
+        comp[p] = c;
+    }
 }
 
 // UniqueCells (src/SPHCellList.jl:148-157) on the device: heads of the runs of equal keys → compacted cell coordinates
@@ -839,7 +1022,8 @@ struct MotionTable {
 template <class T>
 __global__ void __launch_bounds__(256) k_progress_motion(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                          const uint8_t* type, const unsigned long long* group, int N,
-                                                         MotionTable M, double total_time, double dt2, const StepCtrl* ctrl) {
+                                                         MotionTable M, double total_time, double dt2, const StepCtrl* ctrl,
+                                                         typename Vec4<T>::type* comp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (ctrl) { if (!ctrl->active) return; total_time = ctrl->t_step_start; dt2 = ctrl->dt2; }
     if (i >= N || (type[i] & 0x3F) != 3) return;
@@ -850,7 +1034,15 @@ __global__ void __launch_bounds__(256) k_progress_motion(Half<typename Vec4<T>::
         auto q0 = pk0[i]; auto q1 = pk1[i];
         const T vx = (T)(M.vel[m] * M.dir[m][0] * on), vy = (T)(M.vel[m] * M.dir[m][1] * on), vz = (T)(M.vel[m] * M.dir[m][2] * on);
         q1.x = vx; q1.y = vy; q1.z = vz;
-        q0.x += vx * (T)dt2; q0.y += vy * (T)dt2; q0.z += vz * (T)dt2;
+        if (sizeof(T) == 4 && comp) {
+            // a prescribed motion is integrated twice per step, in place: as a double-float like the corrector's (ForceParams::comp)
+            auto c = comp[i];
+            const double xd = ((double)q0.x + (double)c.x) + (double)vx * dt2, yd = ((double)q0.y + (double)c.y) + (double)vy * dt2,
+                         zd = ((double)q0.z + (double)c.z) + (double)vz * dt2;
+            q0.x = (T)xd; q0.y = (T)yd; q0.z = (T)zd;
+            c.x = (T)(xd - (double)q0.x); c.y = (T)(yd - (double)q0.y); c.z = (T)(zd - (double)q0.z);
+            comp[i] = c;
+        } else { q0.x += vx * (T)dt2; q0.y += vy * (T)dt2; q0.z += vz * (T)dt2; }
         pk0[i] = q0; pk1[i] = q1;
         return;
     }
@@ -891,16 +1083,18 @@ __global__ void __launch_bounds__(256) k_dd_column_cost(const int* key, const ui
 }
 
 // Migration record buffer for n particles:
-// [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][n×i64 id][n×u64 group][n×u64 order tag][n×i32 row at the last
+// [n×V4 pk0][n×V4 pk1][n×V4 acc][n×V4 mDBC ghost node][fp32 records only: n×V4 low words of the state][n×i64 id][n×u64 group][n×u64 order tag][n×i32 row at the last
 // sphmi_download_permutation, padded to 8 bytes][n×u8 type, padded to 8 bytes]
 template <class T> struct DdRecord {
     using V4 = typename Vec4<T>::type;
-    static __host__ __device__ size_t bytes(size_t n) { return n * (4 * sizeof(V4) + 24) + ((4 * n + 7) & ~size_t(7)) + ((n + 7) & ~size_t(7)); }
+    static constexpr size_t kPackets = sizeof(T) == 4 ? 5 : 4;
+    static __host__ __device__ size_t bytes(size_t n) { return n * (kPackets * sizeof(V4) + 24) + ((4 * n + 7) & ~size_t(7)) + ((n + 7) & ~size_t(7)); }
     static __host__ __device__ V4* pk0(void* b, size_t) { return (V4*)b; }
     static __host__ __device__ V4* pk1(void* b, size_t n) { return (V4*)b + n; }
     static __host__ __device__ V4* acc(void* b, size_t n) { return (V4*)b + 2 * n; }
     static __host__ __device__ V4* ghost(void* b, size_t n) { return (V4*)b + 3 * n; }
-    static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + 4 * n); }
+    static __host__ __device__ V4* comp(void* b, size_t n) { return (V4*)b + 4 * n; }                  // (fp32 records)
+    static __host__ __device__ long long* id(void* b, size_t n) { return (long long*)((V4*)b + kPackets * n); }
     static __host__ __device__ unsigned long long* grp(void* b, size_t n) { return (unsigned long long*)id(b, n) + n; }
     static __host__ __device__ unsigned long long* tag(void* b, size_t n) { return grp(b, n) + n; }
     static __host__ __device__ int* prow(void* b, size_t n) { return (int*)(tag(b, n) + n); }
@@ -910,7 +1104,7 @@ template <class T> struct DdRecord {
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
                                                    const typename Vec4<T>::type* acc, const typename Vec4<T>::type* ghost,
-                                                   const long long* id, const unsigned long long* grp,
+                                                   const typename Vec4<T>::type* comp, const long long* id, const unsigned long long* grp,
                                                    const unsigned long long* tag, const int* prow, const uint8_t* type,
                                                    const int* idx, int n, void* buf) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -920,6 +1114,7 @@ __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::
     DdRecord<T>::pk1(buf, n)[k] = pk1[i];
     DdRecord<T>::acc(buf, n)[k] = acc[i];
     DdRecord<T>::ghost(buf, n)[k] = ghost[i];
+    if constexpr (sizeof(T) == 4) { typename Vec4<T>::type c; c.x = c.y = c.z = c.w = T(0); DdRecord<T>::comp(buf, n)[k] = comp ? comp[i] : c; }
     DdRecord<T>::id(buf, n)[k] = id[i];
     DdRecord<T>::grp(buf, n)[k] = grp[i];
     DdRecord<T>::tag(buf, n)[k] = tag[i];
@@ -929,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::
 
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_append(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
-                                                   typename Vec4<T>::type* acc, typename Vec4<T>::type* ghost, long long* id,
+                                                   typename Vec4<T>::type* acc, typename Vec4<T>::type* ghost, typename Vec4<T>::type* comp, long long* id,
                                                    unsigned long long* grp, unsigned long long* tag, int* prow, uint8_t* type, int at, int n,
                                                    void* buf, uint8_t flag) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -938,6 +1133,7 @@ __global__ void __launch_bounds__(256) k_dd_append(Half<typename Vec4<T>::type> 
     pk1[at + k] = DdRecord<T>::pk1(buf, n)[k];
     acc[at + k] = DdRecord<T>::acc(buf, n)[k];
     ghost[at + k] = DdRecord<T>::ghost(buf, n)[k];
+    if constexpr (sizeof(T) == 4) { if (comp) comp[at + k] = DdRecord<T>::comp(buf, n)[k]; }
     id[at + k] = DdRecord<T>::id(buf, n)[k];
     grp[at + k] = DdRecord<T>::grp(buf, n)[k];
     tag[at + k] = DdRecord<T>::tag(buf, n)[k];

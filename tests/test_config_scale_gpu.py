@@ -26,6 +26,8 @@ from sphexample_amd.preprocess import particles_from_arrays
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
 
 TOL = 1e-5
+V_TOL = 1e-4       # velocity, of the field maximum: the error of the fp32 PAIR arithmetic (a sum of ≈170 terms that cancel to a hundredth of
+                   # their size) integrated over the steps, not state rounding — 2.1e-5 … 4.5e-5 after 100 steps at C3; stated apart from ρ and x
 DP3, DP4 = 0.00425, 0.002125
 FIELDS = ("ID", "Density", "Position", "Velocity")
 
@@ -101,7 +103,68 @@ def test_c3_hundred_steps_with_rebuilds_fp32_vs_oracle():
     _record("C3_100_steps_flowing", fig)
     assert pe.n_rebuilds >= 3, pe.n_rebuilds        # the one that opens the first advance + ≥ 2 from the Δx criterion
     for r in fig["checkpoints"].values():
-        assert r["rho"] < TOL and r["x"] < TOL and r["dt"] < TOL and r["t"] < TOL, fig
+        assert r["rho"] < TOL and r["x"] < TOL and r["dt"] < TOL and r["t"] < TOL and r["v"] < V_TOL, fig
+
+
+def test_c3_thousand_steps_fp32_vs_oracle():
+    """1 000 steps at BASELINE config 3 (streaming state, a rebuild every ≈33 steps), fp32 handle against the fp64 path: ρ, x AND v
+    asserted at every checkpoint, ρ < 1e-5 THROUGHOUT.  Round 3 lost one fp32 rounding of ρ ≈ 1000 per
+    step — 1.5e-6 / 3.0e-6 / 5.9e-6 at steps 25 / 50 / 100, crossing 1e-5 near step 170; the corrector epilogue now integrates ρ and
+    x as double-floats (ForceParams::comp), so what is left is the error of the fp32 pair sums, which does not accumulate in ρ.
+
+    The fp64 path: the oracle itself for the first 100 steps (the fp32 AND the fp64 engine are both held to it there); from there on
+    the fp64 ENGINE carries it — it tracks the oracle to 1e-12 over 3 000 steps (tests/test_engine_gpu.py) and is checked against
+    it at this size right here, and 1 000 oracle steps at 1.06 M particles are ≈10 minutes of the GPU box's host cores.
+    $SPHMI_LONG_ORACLE=1 runs the oracle all the way (profiles/r04_parity_scale.json holds such a run).
+    The same window with the compensation switched off ($SPHMI_COMPENSATE=0) is recorded next to it: the drift it removes."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    s = setup_dam_break_3d(DP3)
+    p = flowing(dam_break_3d(DP3))
+    long_oracle = os.environ.get("SPHMI_LONG_ORACLE") == "1"
+    t0 = time.perf_counter()
+    eng, e64 = make_engine(p, s, device_float_bytes=4), make_engine(p, s, device_float_bytes=8)
+    os.environ["SPHMI_COMPENSATE"] = "0"
+    try:
+        raw = make_engine(p, s, device_float_bytes=4)                      # round 3's arithmetic, for the record
+    finally:
+        del os.environ["SPHMI_COMPENSATE"]
+    orc = make_oracle(p, s, threads=_threads())
+    fig = {"N": len(p), "dp": DP3, "checkpoints": {}, "oracle_all_the_way": long_oracle}
+    done = 0
+    for upto in (50, 100, 250, 500, 750, 1000):
+        n = upto - done
+        done = upto
+        pe, p64, pw = eng.advance(1e9, max_steps=n), e64.advance(1e9, max_steps=n), raw.advance(1e9, max_steps=n)
+        e, d64, w = _by_id(eng.download(FIELDS)), _by_id(e64.download(FIELDS)), _by_id(raw.download(FIELDS))
+        cp = {"rebuilds": int(pe.n_rebuilds)}
+        if orc is not None:
+            po = orc.advance(1e9, max_steps=n)
+            o = _by_id(orc.download(FIELDS))
+            assert (p64.iteration, p64.n_rebuilds, p64.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter)
+            cp["fp64_engine_vs_oracle"] = _errors(d64, o, DP3)
+            assert max(cp["fp64_engine_vs_oracle"][k] for k in ("rho", "x", "v")) < 1e-9, cp
+            cp["vs_oracle"] = _errors(e, o, DP3)
+            if upto >= 100 and not long_oracle:
+                orc.close(); orc = None
+        assert pe.iteration == p64.iteration == upto
+        assert (pe.n_rebuilds, pe.index_counter) == (p64.n_rebuilds, p64.index_counter), (upto, pe.n_rebuilds, p64.n_rebuilds)
+        np.testing.assert_array_equal(e["ID"], d64["ID"])
+        cp["vs_fp64_path"] = dict(_errors(e, d64, DP3), dt=abs(pe.last_dt - p64.last_dt) / p64.last_dt, t=abs(pe.total_time - p64.total_time) / p64.total_time)
+        cp["uncompensated_vs_fp64_path"] = _errors(w, d64, DP3) if pw.n_rebuilds == p64.n_rebuilds else {"note": "rebuild steps differ from the fp64 path"}
+        fig["checkpoints"][str(upto)] = cp
+    fig["seconds"] = time.perf_counter() - t0
+    _record("C3_1000_steps_flowing", fig)
+    assert pe.n_rebuilds >= 20
+    for upto, cp in fig["checkpoints"].items():
+        r = cp["vs_fp64_path"]
+        assert r["rho"] < TOL and r["x"] < TOL and r["dt"] < TOL and r["t"] < TOL and r["v"] < V_TOL, (upto, fig)
+        if "vs_oracle" in cp:
+            assert cp["vs_oracle"]["rho"] < TOL and cp["vs_oracle"]["x"] < TOL and cp["vs_oracle"]["v"] < V_TOL, (upto, fig)
+    # the drift the compensation removes: at 1 000 steps the uncompensated state is several times further from the fp64 path in ρ
+    last = fig["checkpoints"]["1000"]
+    if "rho" in last["uncompensated_vs_fp64_path"]:
+        assert last["uncompensated_vs_fp64_path"]["rho"] > 3.0 * last["vs_fp64_path"]["rho"], fig
 
 
 @pytest.fixture(scope="module")
