@@ -95,7 +95,7 @@ struct HostBounce {
 };
 
 // Phase labels follow the reference's TimerOutputs sections (src/SPHCellList.jl:748-800).
-enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT, PH_PASS1_EDGE, PH_PASS2_EDGE };
+enum Phase { PH_TIMESTEP = 0, PH_REBUILD, PH_MDBC, PH_PASS1, PH_PASS2, PH_COUNT, PH_PASS1_EDGE, PH_PASS2_EDGE, PH_REBUILD_DEVICE };
 static const char* kPhaseNames[PH_COUNT] = {
     "01 Update TimeStep", "02a Actual Calculate IndexCounter", "04 Apply MDBC before Half TimeStep",
     "05 First NeighborLoop", "08 Second NeighborLoop"};      // (05 holds the fused 06 / 07 half step, 08 the fused 09 / 10 / 11 full step)
@@ -174,7 +174,14 @@ struct Engine final : EngineBase {
     unsigned long long* trace_d = nullptr;
     V4* kout_d = nullptr;              // StoreKernelOutput: { Σ∇W, ΣW } per particle
     MotionTable motions{};
-    StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control (two blocks) + its pinned mirror
+    StepCtrl* ctrl_d = nullptr; StepCtrl* ctrl_h = nullptr;     // device-side step control (two blocks) + a pinned staging block (uploads; the slab driver's read-back)
+    // the block of small control data on the device and its page-locked mirror: [2 × StepCtrl | 16 reduction slots | 8 rebuild counters / flags | 2 × 16 run-table words]
+    static constexpr size_t kCtlRed = 256, kCtlMisc = kCtlRed + 16 * 8, kCtlPart = kCtlMisc + 16 * 4, kCtlBytes = kCtlPart + 32 * 4;
+    // mDBC: the rows that carry a ghost node (k_permute appends them at every rebuild; their number is fixed at the upload), so that
+    // k_mdbc launches one wave per ghost node instead of one per particle.  Slab engines (ghost copies come and go) look at every row.
+    int* mdbc_list_d = nullptr; int mdbc_n_list = 0; bool mdbc_list_valid = false;
+    int* mdbc_cnt_d() const { return misc_d + 8; }
+    char* ctl_d = nullptr; char* ctl_m = nullptr;
     // Which of the two control blocks / two sets of reduction slots is current.  Plain handles take the control inside the
     // predictor (ForceParams::ctl_in): every queued step reads one block / set and writes the other, so both indices flip
     // per step at queue time; after a batch the control index is the last one written and the slot index the one the last
@@ -193,6 +200,7 @@ struct Engine final : EngineBase {
     // launches run with an upper-bound grid (8 × part_bound blocks) until the next batch boundary delivers the run table.
     // $SPHMI_DEVICE_REBUILD=0: the host path for every handle.
     int dev_rebuild = 1;
+    int64_t n_device_rebuilds = 0, n_grid_overflows = 0; double dev_rebuild_secs = 0;
     bool count_clean = false;          // `count` is all zero (k_scan_single leaves it so)
     bool part_copy_queued = false;     // a copy of the run table into part_h is in flight: read it at the next synchronisation
     int part_bound() const { const int nt = (N + kWave - 1) / kWave; return (nt + 3) / 4 + 1; }
@@ -211,10 +219,12 @@ struct Engine final : EngineBase {
         // (every wave of k_mdbc that has a ghost node repeats the decisions — ≈0.15 µs of fp64 arithmetic: worth the 6 µs launch
         // it replaces on the 2-D layouts, 37.5 against 40 µs per step; DucklingMDBC, 54 817 particles, loses 2 µs with it)
         const bool mdbc_ok = fuse_mdbc && cfg.mdbc == SPHMI_MDBC_SIMPLE && N <= fuse_mdbc_max_n;
-        return fuse_ctrl && (cfg.mdbc == SPHMI_MDBC_NONE || mdbc_ok) && motions.n == 0 && !dd_slab && have_grid && part_max[0] > 0;
+        // (moving bodies: inside the first k_progress_motion of the step — MovingSquare2d 53 → 49 µs per step; with mDBC as well, the
+        // one-thread launch stays)
+        return fuse_ctrl && (cfg.mdbc == SPHMI_MDBC_NONE || (mdbc_ok && motions.n == 0)) && !dd_slab && have_grid && part_max[0] > 0;
     }
     bool batch_fused = false;
-    static constexpr int kBatch = 16;  // most steps queued between two looks at the control flags
+    static constexpr int kBatch = 32;  // most steps queued between two looks at the control flags
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
@@ -322,15 +332,21 @@ struct Engine final : EngineBase {
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         HC(hipMalloc(&trace_d, nt * 32 * 9)); HC(hipMemset(trace_d, 0, nt * 32 * 9));     // per tile 4 stamps + (-DSPHMI_TRACE_WAVES) 8 waves × 4
 #endif
-        HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4)); HC(hipMalloc(&part_d, 32 * 4)); HC(hipHostMalloc(&part_h, 32 * 4));
-        HC(hipMalloc(&ctrl_d, 2 * sizeof(StepCtrl))); HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
-        HC(hipMemset(ctrl_d, 0, 2 * sizeof(StepCtrl)));
+        HC(hipMalloc(&tile_tsum, (nt / kScanTile + 2) * 4));
+        // ONE small block holds everything the host looks at after a batch of queued steps — the two control blocks, the two sets of
+        // reduction slots, the rebuild's counters and flags, the run tables of the tile schedules — so that ONE device → host copy
+        // per batch boundary brings all of it (round 3: two copies per boundary plus two per rebuild, ≈5 µs each on a 30 µs step)
+        static_assert(2 * sizeof(StepCtrl) <= kCtlRed, "control block layout");
+        HC(hipMalloc(&ctl_d, kCtlBytes)); HC(hipMemset(ctl_d, 0, kCtlBytes)); HC(hipHostMalloc(&ctl_m, kCtlBytes)); memset(ctl_m, 0, kCtlBytes);
+        ctrl_d = (StepCtrl*)ctl_d; red_d = (unsigned long long*)(ctl_d + kCtlRed); misc_d = (int*)(ctl_d + kCtlMisc); part_d = (int*)(ctl_d + kCtlPart);
+        red_h = (unsigned long long*)(ctl_m + kCtlRed); misc_h = (int*)(ctl_m + kCtlMisc); part_h = (int*)(ctl_m + kCtlPart);
+        HC(hipHostMalloc(&ctrl_h, sizeof(StepCtrl)));
         if (const char* w = getenv("SPHMI_FUSE_CTRL")) fuse_ctrl = atoi(w);
         if (const char* w = getenv("SPHMI_FUSE_MDBC")) fuse_mdbc = atoi(w);
         if (const char* w = getenv("SPHMI_SAME_CELLS")) same_cells = atoi(w);
         if (const char* w = getenv("SPHMI_DEVICE_REBUILD")) dev_rebuild = atoi(w);
-        HC(hipMalloc(&bbox_d, 8 * 4)); HC(hipMalloc(&misc_d, 8 * 4)); HC(hipMalloc(&red_d, 16 * 8)); HC(hipMemset(red_d, 0, 16 * 8));
-        HC(hipHostMalloc(&bbox_h, 8 * 4)); HC(hipHostMalloc(&misc_h, 8 * 4)); HC(hipHostMalloc(&red_h, 8 * 8));
+        HC(hipMalloc(&bbox_d, 8 * 4));
+        HC(hipHostMalloc(&bbox_h, 8 * 4));
     }
     ~Engine() override {
         (void)hipSetDevice(cfg.device);
@@ -348,7 +364,7 @@ struct Engine final : EngineBase {
         (void)hipFree(slot); (void)hipFree(tmp_idx); (void)hipFree(perm);
         for (int k = 0; k < 2; ++k) { (void)hipFree(tile_cost[k]); (void)hipFree(tile_order[k]); }
         (void)hipFree(kout_d); (void)hipFree(tile_work_d); (void)hipFree(tile_work1_d); (void)hipFree(xcd_clock_d); (void)hipHostFree(xcd_clock_h);
-        (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum); (void)hipFree(part_d); (void)hipHostFree(part_h);
+        (void)hipFree(tile_scan); (void)hipFree(tile_cls); (void)hipFree(tile_tsum);
         (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
         if (trace_d) {   // experiment build: start / end clock of every tile of the LAST launch → $SPHMI_TRACE_FILE
@@ -369,9 +385,9 @@ struct Engine final : EngineBase {
                         st[8], st[9], st[10], st[11], st[12], st[13]);
         }
 #endif
-        (void)hipFree(ctrl_d); (void)hipHostFree(ctrl_h);
-        (void)hipFree(bbox_d); (void)hipFree(misc_d); (void)hipFree(red_d);
-        (void)hipHostFree(bbox_h); (void)hipHostFree(misc_h); (void)hipHostFree(red_h);
+        (void)hipFree(ctl_d); (void)hipHostFree(ctl_m); (void)hipHostFree(ctrl_h); (void)hipFree(mdbc_list_d);
+        (void)hipFree(bbox_d);
+        (void)hipHostFree(bbox_h);
         (void)hipFree(cellx_d); (void)hipFree(uc_tsum);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
@@ -384,7 +400,7 @@ struct Engine final : EngineBase {
     Ev begin_phase(int phase) {
         Ev e{};
         e.phase = phase; e.bstep = batch_step;
-        e.weight = (phase == PH_REBUILD || iteration < ev_always_until) ? 1 : ((iteration % kEvSample) == 0 ? kEvSample : 0);
+        e.weight = (phase == PH_REBUILD || phase == PH_REBUILD_DEVICE || iteration < ev_always_until) ? 1 : ((iteration % kEvSample) == 0 ? kEvSample : 0);
         if (e.weight == 0) return e;
         if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; e.bstep = batch_step; }
         else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
@@ -401,7 +417,8 @@ struct Engine final : EngineBase {
             if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
                 // the edge-tile launch of a split pass is part of that pass: its time is added, it is not a call
                 const bool edge = e.phase == PH_PASS1_EDGE || e.phase == PH_PASS2_EDGE;
-                const int ph = e.phase == PH_PASS1_EDGE ? PH_PASS1 : (e.phase == PH_PASS2_EDGE ? PH_PASS2 : e.phase);
+                const int ph = e.phase == PH_PASS1_EDGE ? PH_PASS1 : (e.phase == PH_PASS2_EDGE ? PH_PASS2 : (e.phase == PH_REBUILD_DEVICE ? PH_REBUILD : e.phase));
+                if (e.phase == PH_REBUILD_DEVICE) dev_rebuild_secs += ms * 1e-3;
                 ph_secs[ph] += ms * 1e-3 * e.weight;
                 ph_calls[ph] += edge ? 0 : e.weight;
                 if (ph == PH_PASS1 || ph == PH_PASS2) { force_ms += ms * e.weight; force_launches += edge ? 0 : e.weight; }
@@ -557,10 +574,19 @@ struct Engine final : EngineBase {
         for (int d = 0; d < 3; ++d) motions.dir[m][d] = d < D ? dir[d] : 0.0;
     }
     // ProgressMotion (src/SPHCellList.jl:765,787) on state set A
-    void progress_motion(double dt2, const StepCtrl* ctrl = nullptr) {
+    void progress_motion(double dt2, const StepCtrl* ctrl = nullptr, bool take_control = false) {
         if (motions.n == 0) return;
+        MotionCtl mc{};
+        if (take_control) {
+            // reads control block `cpar` and slot set `rpar`, writes block cpar ^ 1, zeroes the set this step's corrector fills; the
+            // caller flips both indices afterwards
+            mc.ctl_in = ctrl_d + cpar; mc.ctl_out = ctrl_d + (cpar ^ 1);
+            mc.red_in = red_d + 4 * rpar; mc.red_zero = red_d + 4 * (rpar ^ 1);
+            mc.h = cfg.h; mc.c0 = cfg.c0; mc.CFL = cfg.CFL;
+            ctrl = nullptr;
+        }
         hipLaunchKernelGGL(k_progress_motion<T>, dim3((N + 255) / 256), dim3(256), 0, stream, pk0[iA], pk1[iA], type[cur],
-                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2, ctrl, comp[cur]);
+                           (const unsigned long long*)grp[cur], N, motions, total_time, dt2, ctrl, comp[cur], mc);
         HC(hipGetLastError());
     }
 
@@ -632,8 +658,9 @@ struct Engine final : EngineBase {
         HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream));
         HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream));
         count_clean = false;
-        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr);
-        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr);
+        CtrlPatch zero_only{}; zero_only.zero = mdbc_cnt_d();
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr, zero_only);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, (int*)nullptr, zero_only);
         // the scan runs over ncell + 1 entries: entry ncell is the graveyard of dead particles, so
         // cstart[ncell] = number of live particles and cstart[ncell + 1] = N
         const int nscan = (int)ncell + 1;
@@ -658,6 +685,7 @@ struct Engine final : EngineBase {
         // (GhostPoints travel with the sort whenever the caller uploaded some — the reference permutes the column with every other,
         // :142 — not only for mDBC handles: found as uninitialised GhostPoints in a download after an odd number of rebuilds)
         A.perm = perm; A.flags = nullptr; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
+        A.mdbc_list = mdbc_list_ready() ? mdbc_list_d : nullptr; A.mdbc_cnt = mdbc_cnt_d(); mdbc_list_valid = A.mdbc_list != nullptr;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
         if (otag[0]) {
             for (int d = 0; d < D; ++d)
@@ -728,13 +756,13 @@ struct Engine final : EngineBase {
         S.flags = ctrl ? misc_d : nullptr; S.ctrl = ctrl;
         return S;
     }
-    void rebuild_device() {
-        Ev ev = begin_phase(PH_REBUILD);
+    void rebuild_device(const CtrlPatch& patch) {
+        Ev ev = begin_phase(PH_REBUILD_DEVICE);
         const int nb256 = (N + 255) / 256;
         const int ncell = grid.ncell;
         if (!count_clean) { HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream)); HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream)); }
-        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d);
-        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d);
+        if (D == 3) hipLaunchKernelGGL((k_cell_count<T, 3>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d, patch);
+        else        hipLaunchKernelGGL((k_cell_count<T, 2>), dim3(nb256), dim3(256), 0, stream, pk0[iA], type[cur], N, (T)cfg.H_inv, grid, count, key[cur], slot, misc_d, patch);
         const int nscan = ncell + 1;
         if (nscan <= kScanSingleMax) {
             hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, count, cstart, nscan, misc_d);
@@ -760,23 +788,33 @@ struct Engine final : EngineBase {
         A.prow_in = prow[cur]; A.prow_out = prow[nxt];
         A.comp_in = comp[cur]; A.comp_out = comp[nxt];
         A.perm = perm; A.flags = misc_d; A.N = N; A.has_ghost = cfg.mdbc == SPHMI_MDBC_SIMPLE || ghost_given;
+        A.mdbc_list = mdbc_list_ready() ? mdbc_list_d : nullptr; A.mdbc_cnt = mdbc_cnt_d(); mdbc_list_valid = A.mdbc_list != nullptr;
         hipLaunchKernelGGL(k_permute<T>, dim3(nb256), dim3(256), 0, stream, A);
         std::swap(iA, iB);
         cur = nxt;
-        HC(hipMemcpyAsync(misc_h, misc_d, 2 * 4, hipMemcpyDeviceToHost, stream));
-        nonempty_pending = true;
+        nonempty_pending = true;               // (misc_d[0] and the run table travel with the copy of the control block at the next batch boundary)
         hipLaunchKernelGGL(k_tile_schedule_small, dim3(8), dim3(1024), 0, stream, small_sched(nullptr, 0, ctrl_cur()));
         HC(hipGetLastError());
-        HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
         part_copy_queued = true;
         part_max[0] = part_bound(); part_max[1] = 0;
         list_tiles[0] = (N + kWave - 1) / kWave; list_tiles[1] = 0;
-        n_rebuilds += 1; xcd_sampled = false;
+        n_rebuilds += 1; n_device_rebuilds += 1; xcd_sampled = false;
         sched_state = 1; sched1_state = 0; resched0_pending = false; resched1_pending = false;
         end_phase(ev);
     }
-    // (`ctrl_ready`: the control block of the coming batch has been uploaded — a device-side rebuild reports through it)
-    void rebuild_any() { if (device_rebuild_ok()) rebuild_device(); else rebuild(); }
+    // The rebuild in front of the next queued step, with what the host has to tell the control block `c` (mode 1: all of it, a new
+    // call; mode 2: "served").  Device-side: the rebuild's first launch writes it; host-side: an upload, then the rebuild.
+    void rebuild_any(const StepCtrl& c, int mode) {
+        if (device_rebuild_ok()) {
+            CtrlPatch p{}; p.dst = ctrl_cur(); p.mode = mode; if (mode == 1) p.value = c;
+            p.zero = mdbc_cnt_d();
+            rebuild_device(p);
+            return;
+        }
+        *ctrl_h = c;
+        HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
+        rebuild();
+    }
 
     // The schedule of list 0 from the MEASURED work of every tile (the sampled corrector launch just queued): same
     // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.
@@ -786,7 +824,6 @@ struct Engine final : EngineBase {
             // batch boundary has seen it)
             hipLaunchKernelGGL(k_tile_schedule_small, dim3(8), dim3(1024), 0, stream, small_sched(tile_work_d, 1, nullptr));
             HC(hipGetLastError());
-            HC(hipMemcpyAsync(part_h, part_d, 16 * 4, hipMemcpyDeviceToHost, stream));
             part_copy_queued = true;
             part_max[0] = part_bound();
             return;
@@ -815,6 +852,11 @@ struct Engine final : EngineBase {
 
     // take_control: the kernel takes the decisions of the step itself (MdbcParams::ctl_in): reads control block `cpar` and slot set
     // `rpar`, writes block cpar ^ 1; its flag goes to the set the coming corrector fills.  The caller flips both indices afterwards.
+    bool mdbc_list_ready() {
+        if (cfg.mdbc != SPHMI_MDBC_SIMPLE || dd_slab || mdbc_n_list <= 0) return false;
+        if (!mdbc_list_d) HC(hipMalloc(&mdbc_list_d, (size_t)mdbc_n_list * 4));
+        return true;
+    }
     void run_mdbc(const StepCtrl* ctrl = nullptr, bool take_control = false) {
         Ev ev = begin_phase(PH_MDBC);
         MdbcParams<T> M{};
@@ -828,14 +870,20 @@ struct Engine final : EngineBase {
         }
         M.H_inv = (T)cfg.H_inv; M.H2 = cfg.H2; M.h_inv = cfg.h_inv; M.h = cfg.h;
         M.alphaD = cfg.alphaD; M.m0 = cfg.m0; M.rho0 = cfg.rho0; M.eta2 = cfg.eta2; M.kernel = cfg.kernel;
-        dim3 g((N + 3) / 4), b(256);               // one wave per particle, four per block
+        M.gfac = cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h);
+        const bool listed = mdbc_list_valid && !dd_slab;
+        if (listed) { M.list = mdbc_list_d; M.n_list = mdbc_n_list; }
+        dim3 g(((listed ? mdbc_n_list : N) + 3) / 4), b(256);       // one wave per ghost node (per particle without the list), four per block
         if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
         else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
         HC(hipGetLastError());
         end_phase(ev);
     }
 
-    void sync_and_collect(const StepCtrl* batch_ctrl = nullptr, int64_t steps_before = 0) {
+    void sync_and_collect(const StepCtrl* batch_ctrl = nullptr, int64_t steps_before = 0, bool mirror_fresh = false) {
+        // (the counters and the run table of a device-side rebuild live in the control block: fetch them unless the caller just did)
+        if (!mirror_fresh && (nonempty_pending || part_copy_queued))
+            HC(hipMemcpyAsync(ctl_m + kCtlMisc, ctl_d + kCtlMisc, kCtlBytes - kCtlMisc, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
         collect_events(batch_ctrl ? batch_ctrl->steps_done - steps_before : INT64_MAX);
         if (nonempty_pending) { index_counter = (int64_t)misc_h[0] + 1; nonempty_pending = false; }
@@ -868,12 +916,15 @@ struct Engine final : EngineBase {
             hipLaunchKernelGGL(k_step_control<T>, dim3(1), dim3(1), 0, stream, red_cur(), ctrl_cur(), cfg.h, cfg.c0, cfg.CFL);
             end_phase(ev);
         }
-        progress_motion(0.0, ctrl_cur());                                      // :765
+        const bool fused_in_motion = fused && motions.n > 0;
+        if (fused_in_motion) { progress_motion(0.0, nullptr, true); cpar ^= 1; rpar ^= 1; }      // :765, and the decisions of the step with it
+        else progress_motion(0.0, ctrl_cur());                                 // :765
         const bool fused_in_mdbc = fused && cfg.mdbc == SPHMI_MDBC_SIMPLE;
         if (fused_in_mdbc) { run_mdbc(nullptr, true); cpar ^= 1; rpar ^= 1; }   // :772, and the decisions of the step with it
         else if (cfg.mdbc == SPHMI_MDBC_SIMPLE) run_mdbc(ctrl_cur());           // :772
         ForceParams<T> P1 = force_params(iA, iA, iH, 0.0);
-        if (fused_in_mdbc) {
+        if (fused_in_motion) P1.ctrl = ctrl_cur();                              // decided by k_progress_motion, which also zeroed the corrector's slots
+        else if (fused_in_mdbc) {
             // decided by k_mdbc: the predictor reads the block it wrote and zeroes what that kernel could not
             P1.ctrl = ctrl_cur();
             P1.mdbc_zero = red_cur(); P1.mdbc_flag_zero = red_d + 4 * (rpar ^ 1) + 3;
@@ -907,27 +958,32 @@ struct Engine final : EngineBase {
             // The first iteration of the loop always rebuilds (Δx = 1 + h ≥ h, :739,758): when there will BE a first iteration the
             // rebuild is run now and the control is told (StepCtrl::pre_rebuilt) — not a one-step batch that the control cancels.
             const bool pre = total_time <= t_target && max_steps != 0;
-            if (pre) { c.pre_rebuilt = 1; delta_x = 0.0; }
-            *ctrl_h = c;
-            HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
-            if (pre) rebuild_any();                                               // (behind the upload: a device-side rebuild reports through the block)
+            if (pre) { c.pre_rebuilt = 1; delta_x = 0.0; rebuild_any(c, 1); }
+            else { *ctrl_h = c; HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream)); }
+            bool fresh = pre;            // the first queued step follows a rebuild: it runs with Δx = 0 and adds nothing to it
             for (;;) {
                 const int a0 = iA, b0 = iB;
                 const int rpar0 = rpar;
                 batch_fused = fused_control();
                 const int64_t before = steps;
                 const double dx0 = delta_x;
-                // queue up to the step that is expected to ask for the rebuild (Δx grows by 4·max|Δx| a step, slowly
-                // changing), not beyond: what follows it in a batch is cancelled.  The first control of a call always asks.
+                // Queue up to the step that is expected to ask for the rebuild (Δx grows by 4·max|Δx| a step, slowly changing): the
+                // n-th control that ADDS finds Δx = dx0 + n·rate, so the asking one is n* = ⌈(h − dx0) / rate⌉ — one later when the
+                // batch opens behind a rebuild, whose step adds nothing (round 3 stopped one short there: every rebuild was asked for
+                // by the lone first step of the next batch, a second synchronisation).  One spare step on top: a step queued behind
+                // the asking one is cancelled and costs a few empty launches, a batch that ends before it a whole round trip.
                 int batch = kBatch;
                 if (dx0 >= cfg.h) batch = 1;
-                else if (dx_rate > 0.0) batch = (int)std::max(1.0, std::min((double)kBatch, std::floor((cfg.h - dx0) / dx_rate) + 1.0));
+                else if (dx_rate > 0.0) batch = (int)std::max(1.0, std::min((double)kBatch, std::ceil((cfg.h - dx0) / dx_rate) + (fresh ? 2.0 : 1.0)));
                 if (max_steps >= 0) batch = (int)std::min<int64_t>(batch, std::max<int64_t>(max_steps - steps, 1));
                 for (int k = 0; k < batch; ++k) { batch_step = k; enqueue_step(); iteration += 1; }      // iteration: provisional (event sampling)
                 batch_step = -1;
-                HC(hipMemcpyAsync(ctrl_h, ctrl_cur(), sizeof(StepCtrl), hipMemcpyDeviceToHost, stream));      // the block the last queued step wrote
-                HC(hipMemcpyAsync(red_h, red_d, 8 * 8, hipMemcpyDeviceToHost, stream));                        // both sets of slots (below: the bad-ρ flag)
-                sync_and_collect(ctrl_h, before);
+                // the block the last queued step wrote, both sets of slots (below: the bad-ρ flag), the counters and the run table of a
+                // device-side rebuild: one copy
+                HC(hipMemcpyAsync(ctl_m, ctl_d, kCtlBytes, hipMemcpyDeviceToHost, stream));
+                HC(hipStreamSynchronize(stream));
+                *ctrl_h = ((const StepCtrl*)ctl_m)[cpar];
+                sync_and_collect(ctrl_h, before, /*mirror_fresh=*/true);
                 c = *ctrl_h;
                 steps = c.steps_done;
                 const int64_t executed = steps - before;
@@ -940,13 +996,15 @@ struct Engine final : EngineBase {
                 if (executed > 0) stepped = true;
                 total_time = c.total_time; last_dt = c.last_dt; delta_x = c.delta_x;
                 {
-                    const int64_t grown = executed + (c.need_rebuild ? 1 : 0);    // controls that added their 4·max|Δx|
+                    const int64_t grown = executed + (c.need_rebuild ? 1 : 0) - (fresh && executed > 0 ? 1 : 0);    // controls that added their 4·max|Δx|
                     if (grown > 0 && dx0 < cfg.h && c.delta_x > dx0) dx_rate = (c.delta_x - dx0) / (double)grown;
                 }
+                if (executed > 0) fresh = false;
                 if (c.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced (sign of ρ carries the MotionLimiter flag)");
                 if (c.error == 3) {
                     // a particle left the grid of the last device-side rebuild: that rebuild copied instead of permuting and the
                     // control cancelled every step behind it — the same rebuild again, on the host, with a new grid
+                    n_rebuilds -= 1; n_device_rebuilds -= 1; n_grid_overflows += 1;      // (one UpdateNeighbors! call of the reference)
                     rebuild();
                     c.error = 0;
                     *ctrl_h = c;
@@ -961,9 +1019,8 @@ struct Engine final : EngineBase {
                 }
                 if (c.need_rebuild) {                                             // :758-762
                     c.delta_x = 0.0; c.need_rebuild = 0; delta_x = 0.0;           // resume stays set: the queued step re-uses its Δt
-                    *ctrl_h = c;
-                    HC(hipMemcpyAsync(ctrl_cur(), ctrl_h, sizeof(StepCtrl), hipMemcpyHostToDevice, stream));
-                    rebuild_any();
+                    rebuild_any(c, 2);
+                    fresh = true;
                     continue;
                 }
                 if (c.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) {
@@ -1023,6 +1080,12 @@ struct Engine final : EngineBase {
             if (!(std::fabs((double)h0[i].w) > 0.0)) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_upload: density must be positive");
         iA = 0; iH = 1; iB = 2; cur = 0;
         ghost_given = ghost_points != nullptr;
+        {
+            int ng = 0;
+            for (int i = 0; i < N; ++i) ng += hg[i].w != T(0) ? 1 : 0;
+            if (ng != mdbc_n_list) { (void)hipFree(mdbc_list_d); mdbc_list_d = nullptr; }
+            mdbc_n_list = ng; mdbc_list_valid = false;
+        }
         const size_t n = (size_t)N;
         std::vector<V4> hrec(2 * n);                                     // the two packets of a particle side by side
         for (size_t i = 0; i < n; ++i) { hrec[2 * i] = h0[i]; hrec[2 * i + 1] = h1[i]; }
@@ -1073,7 +1136,7 @@ struct Engine final : EngineBase {
         HC(hipMalloc(&flag, (size_t)M * 4)); HC(hipMalloc(&pos, (size_t)M * 4)); HC(hipMalloc(&tsum, (size_t)(ntiles + 2) * 4)); HC(hipMalloc(&tot_d, 16));
         auto release = [&]() { (void)hipFree(flag); (void)hipFree(pos); (void)hipFree(tsum); (void)hipFree(tot_d); };
         try {
-            iA = 0; iH = 1; iB = 2; cur = 0; ghost_given = false;
+            iA = 0; iH = 1; iB = 2; cur = 0; ghost_given = false; mdbc_n_list = 0; mdbc_list_valid = false;
             int base = 0;
             const unsigned nbM = (unsigned)((M + 255) / 256);
             for (int which = 1; which <= 2; ++which) {              // the tank first, then the pillar object
@@ -1462,7 +1525,7 @@ struct Engine final : EngineBase {
         }
     }
     void timers(int32_t cap, const char** names, double* secs, int64_t* calls, int32_t* n) override {
-        if (n) *n = PH_COUNT + 1;
+        if (n) *n = PH_COUNT + 3;
         for (int i = 0; i < PH_COUNT && i < cap; ++i) {
             if (names) names[i] = kPhaseNames[i];
             if (secs) secs[i] = ph_secs[i];
@@ -1472,6 +1535,16 @@ struct Engine final : EngineBase {
             if (names) names[PH_COUNT] = "02b UpdateNeighbors calls that were the identity (no sort)";
             if (secs) secs[PH_COUNT] = 0.0;
             if (calls) calls[PH_COUNT] = n_identity_rebuilds;
+        }
+        if (PH_COUNT + 1 < cap) {
+            if (names) names[PH_COUNT + 1] = "02c UpdateNeighbors calls served on the device (no host round trip)";
+            if (secs) secs[PH_COUNT + 1] = dev_rebuild_secs;
+            if (calls) calls[PH_COUNT + 1] = n_device_rebuilds;
+        }
+        if (PH_COUNT + 2 < cap) {
+            if (names) names[PH_COUNT + 2] = "02d device-side rebuilds repeated on the host (a particle left the sticky grid)";
+            if (secs) secs[PH_COUNT + 2] = 0.0;
+            if (calls) calls[PH_COUNT + 2] = n_grid_overflows;
         }
     }
     void force_stats(int reset, double* avg_ms, int64_t* launches) override {

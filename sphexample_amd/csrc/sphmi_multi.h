@@ -1129,11 +1129,12 @@ struct MultiEngine final : EngineBase {
             if (pre) rebuild_collective();
             for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->total_time = total_time; r.e->last_dt = last_dt; r.e->dd_ctrl_init(dxl, t_target, max_steps, pre); }
             if (pre) dxl = 0.0;
+            bool fresh = pre;            // the first queued step follows a rebuild: it adds nothing to Δx (Engine::advance)
             for (;;) {
                 // A step that asks for a rebuild cancels the rest of its batch, and a cancelled step still pays its allreduce
                 // and its messages: queue up to the step EXPECTED to ask (Δx grows by 4·max|Δx| a step, slowly changing).
                 int batch = kBatch;
-                if (dx_rate > 0.0) batch = std::max(1, std::min(batch, (int)((cfg.h - dxl) / dx_rate) + 1));
+                if (dx_rate > 0.0) batch = std::max(1, std::min(batch, (int)std::ceil((cfg.h - dxl) / dx_rate) + (fresh ? 1 : 0)));
                 if (max_steps >= 0) batch = (int)std::max<int64_t>(1, std::min<int64_t>(batch, max_steps - steps));
                 const double dx0 = dxl; const int64_t steps0 = steps;
                 for (int k = 0; k < batch; ++k) {
@@ -1155,7 +1156,8 @@ struct MultiEngine final : EngineBase {
                 }
                 steps = st.steps_done;
                 total_time = st.total_time; last_dt = st.last_dt; dxl = st.delta_x;
-                const int64_t grown = (steps - steps0) + (st.need_rebuild ? 1 : 0);
+                const int64_t grown = (steps - steps0) + (st.need_rebuild ? 1 : 0) - (fresh && steps > steps0 ? 1 : 0);
+                if (steps > steps0) fresh = false;
                 if (grown > 0 && dx0 < cfg.h && st.delta_x > dx0) dx_rate = (st.delta_x - dx0) / (double)grown;
                 if (st.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced on some slab");
                 if (st.error) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive or NaN dt");
@@ -1163,6 +1165,7 @@ struct MultiEngine final : EngineBase {
                     rebuild_collective();
                     dxl = 0.0;
                     for (auto& r : R) { HC(hipSetDevice(r.device)); r.e->dd_ctrl_resume(); }
+                    fresh = true;
                     continue;
                 }
                 if (st.stop || !(total_time <= t_target) || (max_steps >= 0 && steps >= max_steps)) break;

@@ -88,11 +88,20 @@ __global__ void __launch_bounds__(256) k_cell_bbox(Half<const typename Vec4<T>::
 // (the launches that follow stay memory-safe; their results are discarded: k_permute copies instead of permuting, the step control
 // stops with error 3 and the host rebuilds on a new grid).
 constexpr int kStickySlack = 2, kFlagOverflow = 7, kFlagOverflowSeen = 6;
+// What the host would upload into the control block before the steps behind this rebuild (a 112-byte copy costs more than this
+// launch's share of a small rebuild): mode 1 — the whole block (a new sphmi_advance call), mode 2 — the request has been served
+// (Δx := 0, need_rebuild := 0; `resume` stays: the queued step re-uses its Δt).  Written by the first thread of the rebuild's first launch.
+struct CtrlPatch { StepCtrl* dst; int mode; StepCtrl value; int* zero; };      // zero: a counter of the rebuild cleared for the launches behind (k_permute's list of ghost-bearing rows)
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_cell_count(Half<const typename Vec4<T>::type> pk0, const uint8_t* type, int N,
-                                                    T inv_cutoff, GridDesc g, int* count, int* key, int* slot, int* flags) {
+                                                    T inv_cutoff, GridDesc g, int* count, int* key, int* slot, int* flags, const CtrlPatch cp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (i == 0) {
+        if (cp.zero) *cp.zero = 0;
+        if (cp.mode == 1) *cp.dst = cp.value;
+        else if (cp.mode == 2) { cp.dst->delta_x = 0.0; cp.dst->need_rebuild = 0; }
+    }
     int k = -1;                               // lanes past the end: a key no particle has
     if (i < N) {
         auto p = pk0[i];
@@ -403,7 +412,7 @@ struct SmallSched {
     int* flags; StepCtrl* ctrl;      // block 0 hands a grid overflow of this rebuild to the step control (error 3) and re-arms the flag
 };
 __global__ void __launch_bounds__(1024) k_tile_schedule_small(const SmallSched S) {
-    __shared__ int s_cost[kSmallMaxTiles], s_scan[kSmallMaxTiles + 1], s_w[16], s_b[9], s_min, s_max, s_wsum[16], s_off;
+    __shared__ int s_cost[kSmallMaxTiles], s_scan[kSmallMaxTiles + 1], s_w[16], s_b[9], s_min, s_max, s_cbase[16], s_cnt[16][16], s_off;
     const int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ntile = S.ntile;
     if (x == 0 && tid == 0 && S.flags) {
@@ -470,31 +479,40 @@ __global__ void __launch_bounds__(1024) k_tile_schedule_small(const SmallSched S
     }
     __syncthreads();
     const int beg = s_b[x], end = s_b[x + 1];
-    if (tid == 0) s_off = beg;
     int mn = INT32_MAX, mx = INT32_MIN;
     for (int t = beg + tid; t < end; t += 1024) { const int c = s_cost[t]; if (c > 0) { mn = min(mn, c); mx = max(mx, c); } }
-    if (mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    mn = wave_min_i(mn); mx = wave_max_i(mx);
+    if (lane == 0 && mn <= mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    if (tid < 16) s_cbase[tid] = 0;
     __syncthreads();
-    const int cmin = s_min;
-    const float scale = s_max > cmin ? (float)S.nclass / (float)(s_max - cmin + 1) : 0.f;
-    auto cls_of = [&](int c) { return S.nclass - 1 - min(S.nclass - 1, (int)((float)(c - cmin) * scale)); };
-    for (int cls = 0; cls < S.nclass; ++cls) {
-        for (int t0 = beg; t0 < end; t0 += 1024) {
-            const int t = t0 + tid;
-            const int c = t < end ? s_cost[t] : 0;
-            const bool in = c > 0 && cls_of(c) == cls;
-            const unsigned long long bal = __ballot(in);
-            const int below = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wsum[w] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, tot = 0;
-            for (int q = 0; q < 16; ++q) { const int v = s_wsum[q]; if (q < w) woff += v; tot += v; }
-            const int base = s_off;
-            if (in) S.order[base + woff + below] = t;
-            __syncthreads();
-            if (tid == 0) s_off = base + tot;
-            __syncthreads();
+    const int cmin = s_min, nclass = S.nclass;
+    const float scale = s_max > cmin ? (float)nclass / (float)(s_max - cmin + 1) : 0.f;
+    auto cls_of = [&](int c) { return nclass - 1 - min(nclass - 1, (int)((float)(c - cmin) * scale)); };
+    // stable partition of the run into cost classes, most expensive first (k_tile_order walks the run once per class; here: the
+    // class sizes first, then one pass that places every tile — three barriers per 1024 tiles instead of three per class)
+    for (int t = beg + tid; t < end; t += 1024) { const int c = s_cost[t]; if (c > 0) atomicAdd(&s_cbase[cls_of(c)], 1); }
+    __syncthreads();
+    if (tid == 0) { int off = beg; for (int k = 0; k < 16; ++k) { const int n = s_cbase[k]; s_cbase[k] = off; off += n; } s_off = off; }
+    __syncthreads();
+    for (int t0 = beg; t0 < end; t0 += 1024) {
+        const int t = t0 + tid;
+        const int c = t < end ? s_cost[t] : 0;
+        const int cls = c > 0 ? cls_of(c) : -1;
+        int below = 0;
+        for (int k = 0; k < nclass; ++k) {
+            const unsigned long long bal = __ballot(cls == k);
+            if (lane == 0) s_cnt[w][k] = __popcll(bal);
+            if (cls == k) below = __popcll(bal & ((1ull << lane) - 1ull));
         }
+        __syncthreads();
+        if (cls >= 0) {
+            int off = s_cbase[cls];
+            for (int q = 0; q < w; ++q) off += s_cnt[q][cls];
+            S.order[off + below] = t;
+        }
+        __syncthreads();
+        if (tid < nclass) { int tot = 0; for (int q = 0; q < 16; ++q) tot += s_cnt[q][tid]; s_cbase[tid] += tot; }
+        __syncthreads();
     }
     if (tid == 0) { S.part[x] = beg; S.part[8 + x] = s_off - beg; }
 }
@@ -567,6 +585,7 @@ struct PermuteArgs {
     const V4* comp_in; V4* comp_out;                                   // low words of the double-float state (fp32 handles; else null)
     const int* perm;
     const int* flags;          // device-side rebuilds: flags[kFlagOverflow] set → copy instead of permuting (the order stays what it was)
+    int* mdbc_list; int* mdbc_cnt;     // mDBC handles: the rows that carry a ghost node, appended in any order (*mdbc_cnt zeroed by k_cell_count)
     int N, has_ghost;
 };
 
@@ -578,7 +597,22 @@ __global__ void __launch_bounds__(256) k_permute(const PermuteArgs<T> A) {
     A.pk0_out[p] = A.pk0_in[i];
     A.pk1_out[p] = A.pk1_in[i];
     A.acc_out[p] = A.acc_in[i];
-    if (A.has_ghost) A.ghost_out[p] = A.ghost_in[i];
+    if (A.has_ghost) {
+        const auto gq = A.ghost_in[i];
+        A.ghost_out[p] = gq;
+        if (A.mdbc_list) {
+            // one counter bump per wave: the waves' lists of ghost-bearing rows, in whatever order the waves arrive
+            const bool has = gq.w != T(0);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+            if (bal) {
+                const int lane = threadIdx.x & 63, first = __builtin_ctzll(bal);
+                int base = 0;
+                if (lane == first) base = atomicAdd(A.mdbc_cnt, __builtin_popcountll(bal));
+                base = __shfl(base, first, 64);
+                if (has) A.mdbc_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = p;
+            }
+        }
+    }
     A.type_out[p] = A.type_in[i];
     A.id_out[p] = A.id_in[i];
     A.grp_out[p] = A.grp_in[i];
@@ -633,12 +667,14 @@ template <class T> struct MdbcParams {
     V4* comp;              // fp32 handles: the low word of the rewritten ρ goes with it (ForceParams::comp); else null
     const V4* ghost;       // { g, flag }  flag != 0 ⇔ !iszero(GhostPoint)
     const uint8_t* type;   // ghost-copy bits (domain decomposition)
+    const int* list; int n_list;   // the ghost-bearing particles (any order), rebuilt with the cell list by k_permute; null: every particle is looked at
     const int* cstart;
     GridDesc g;
     unsigned long long* red;   // red[3]: non-positive density flag
     int N;
     T H_inv;               // the cell hash stays in the handle's precision (same cells as the particles)
     double H2, h_inv, h, alphaD, m0, rho0, eta2;
+    double gfac;           // αD·5 / (8h²): the Wendland gradient factor (src/SPHKernels.jl:85-86)
     int kernel;            // 0 WendlandC2, 1 CubicSpline
     const StepCtrl* ctrl;  // device-side step control (null: always run)
     // Control taken INSIDE this kernel (mDBC handles without moving bodies or slabs; the same scheme as ForceParams::ctl_in of
@@ -659,47 +695,55 @@ template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10,
 // All arithmetic of the moment matrix and its solve is fp64 in BOTH builds: the (D+1)×(D+1) systems of thin
 // boundary layers are ill-conditioned, and fp32 accumulation flipped the |det| ≥ 1e-3 branch for a handful
 // of particles of example/Dambreak2dMDBC.jl (density off by 3e-3); the kernel is a negligible part of a step.
+//
+// ONE WAVE per ghost node (round 4: per GHOST-BEARING particle — `list`, rebuilt with the cell list — not per particle: two
+// thirds of the 54 820 waves of DucklingMDBC had nothing to do), in two phases, because what the round-2 counters showed was a
+// LATENCY-bound kernel (vector ALU 38 % busy, ≈17 dependent load round trips per wave):
+//   1. who is within H — the 3^(D-1) candidate rows of the node's cell neighbourhood in 64-candidate chunks, FOUR chunk loads in
+//      flight per lane (nothing else is live yet: 16 registers), a cheap test in the handle's precision (a superset: the exact
+//      fp64 test follows), and the records that pass are parked densely in LDS (ballot + prefix count);
+//   2. the moments — every lane takes one parked record per round (two or three rounds instead of seventeen mostly-idle ones),
+//      fp64 as before; the 64 partial sums of each of the (D+1)² + (D+1) moments are added in a FIXED order through LDS (one
+//      half-fold with v_permlane32_swap, then lane v adds the 32 values of moment v: ≈150 instructions against ≈360 for a
+//      shuffle tree over doubles); lane 0 solves.
 template <class T, int D>
 __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
-    // ONE WAVE per boundary particle: the lanes split the candidates of the ghost node's 3^D cells, the partial
-    // moment sums are combined with a fixed shuffle tree (deterministic), lane 0 solves.  One thread per particle
-    // ran the ≈300-candidate loop serially in fp64: 206 of the 288 µs of a DucklingMDBC step.
-    constexpr int P = D + 1;
+    constexpr int P = D + 1, NV = P * P + P;
+    constexpr int NROW = D == 3 ? 9 : 3;
+    constexpr int U = sizeof(T) == 4 ? 4 : 2;              // chunk loads in flight (16 registers either way)
+    constexpr int kStash = 64 * U + (sizeof(T) == 4 ? 128 : 64);      // records a wave can park: a full group of chunks on top of what is
+                                                           // allowed to wait (24 KB per block either way); a typical node parks 100-170
     using R = double;
+    using V4 = typename Vec4<T>::type;
+    // (per wave: the stash of phase 1 / 2, and — once the last record has been worked off — the transpose buffer of the final sums)
+    constexpr size_t kWaveLds = kStash * sizeof(V4) > NV * 33 * sizeof(double) ? kStash * sizeof(V4) : NV * 33 * sizeof(double);
+    __shared__ __attribute__((aligned(16))) char s_lds[4][kWaveLds];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    bool have;
+    int i;
+    if (M.list) { have = wid < M.n_list; i = have ? M.list[wid] : 0; }
+    else { have = wid < M.N; i = have ? wid : 0; if (have && M.ghost[i].w == T(0)) have = false; }
     if (M.ctl_in != nullptr) {
         // (a wave without a ghost node has nothing to decide for — except the one that stores the decisions)
-        const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        const bool idle = i0 >= M.N || M.ghost[i0 < M.N ? i0 : 0].w == T(0);
-        if (idle && !(blockIdx.x == 0 && threadIdx.x < 64)) return;
+        if (!have && !(blockIdx.x == 0 && threadIdx.x < 64)) return;
         StepCtrl c = *M.ctl_in;
         const unsigned long long r0 = M.red_in[0], r1 = M.red_in[1], r2 = M.red_in[2], r3 = M.red_in[3];
         (void)step_control_decide<T>(r0, r1, r2, r3, c, M.ctl_h, M.ctl_c0, M.ctl_CFL);
         if (blockIdx.x == 0 && threadIdx.x == 0) *M.ctl_out = c;
         if (!c.active) return;
     } else if (M.ctrl && !M.ctrl->active) return;
-    const int lane = threadIdx.x & 63;
-    int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= M.N) return;
+    if (!have) return;
     const auto gq = M.ghost[i];
-    if (gq.w == T(0)) return;
     const T gT[3] = {gq.x, gq.y, gq.z};
     const R g[3] = {(R)gq.x, (R)gq.y, (R)gq.z};
     int gc[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) gc[d] = d < D ? map_floor<T>(gT[d], M.H_inv) - M.g.gmin[d] + 1 : 0;
-    R b[P], A[P][P];   // A[r][c]
-#pragma unroll
-    for (int r = 0; r < P; ++r) { b[r] = 0;
-#pragma unroll
-        for (int c = 0; c < P; ++c) A[r][c] = 0; }
-    // The 3^(D-1) rows of the ghost node's neighbourhood are flattened into ONE candidate list: lane r < NROW
-    // looks up row r's range, a wave scan gives every row its offset, and every lane then strides through the
-    // whole list — a handful of independent loads per lane instead of one dependent load chain per row.
-    constexpr int NROW = D == 3 ? 9 : 3;
-    int rs = 0, rc = 0;                                    // start / count of "my" row (lanes ≥ NROW: empty)
+    // row r of the neighbourhood: the three x-adjacent cells are one contiguous range, clipped to the padded grid (lane r < NROW)
+    int rs = 0, rc = 0;
     if (lane < NROW) {
         const int sy = lane % 3, sz = lane / 3;
-        // the three x-adjacent cells of a row are one contiguous range; clip to the padded grid
         const int cy = gc[1] + sy - 1, cz = D == 3 ? gc[2] + sz - 1 : 0;
         int x0 = gc[0] - 1, x1 = gc[0] + 1;
         if (x0 < 0) x0 = 0;
@@ -710,72 +754,138 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
             rc = M.cstart[row + x1 + 1] - rs;
         }
     }
-    int incl = rc;                                         // inclusive scan of the row counts
+    // the chunks ("jobs") of all rows, numbered through: row r holds jobs [jb[r], jb[r + 1])
+    int jincl = (rc + 63) >> 6;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-    const int total = __shfl(incl, NROW - 1, 64);
-    const int excl = incl - rc, shift = rs - excl;         // candidate g of row r is particle g + shift_r
-        {
-            // the row table goes to SGPRs HERE, with every lane active: the compiler is free to sink the
-            // computation of `excl` / `shift` into the divergent loop below, where the lanes of the later rows
-            // may be switched off (lane ≥ total) — a readlane in there returned garbage for them
-            int ex[NROW], sf[NROW];
+    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(jincl, o, 64); if (lane >= o) jincl += u; }
+    const int njobs = __builtin_amdgcn_readlane(jincl, NROW - 1);
+    // job table: lane l describes job l of the current block of 64 jobs — first record and records left in its row — so that the
+    // loop below fetches a job's description with two v_readlane (a row look-up per chunk was a chain of 58 vector selects)
+    const int jexcl = jincl - ((rc + 63) >> 6);
+    int job_first = 0, job_left = 0;
+    auto describe_jobs = [&](const int jbase) __attribute__((always_inline)) {
+        const int jb = jbase + lane;
+        job_first = 0; job_left = 0;
 #pragma unroll
-            for (int r = 0; r < NROW; ++r) { ex[r] = __builtin_amdgcn_readlane(excl, r); sf[r] = __builtin_amdgcn_readlane(shift, r); }
-            for (int gidx = lane; gidx < total; gidx += 64) {
-                int sh = sf[0];
+        for (int r = 0; r < NROW; ++r) {
+            const int e = __builtin_amdgcn_readlane(jexcl, r), st = __builtin_amdgcn_readlane(rs, r), cn = __builtin_amdgcn_readlane(rc, r);
+            const int o = (jb - e) << 6;
+            if (jb >= e && o < cn) { job_first = st + o; job_left = cn - o; }
+        }
+    };
+    R b[P], A[P][P];   // A[r][c]
 #pragma unroll
-                for (int r = 1; r < NROW; ++r) sh = gidx >= ex[r] ? sf[r] : sh;
-                const int j = gidx + sh;
-                const auto n0 = M.pk0[j];
-                if (!(n0.w > T(0))) continue;                 // ParticleType[j] == Fluid
-                const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
-                const R r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
-                if (!(r2 <= M.H2)) continue;
-                R q = sqrt(r2) * M.h_inv;
-                q = q > R(2) ? R(2) : q;
-                const R tq = q - R(2);
-                R Wij, fac;
-                if (M.kernel == 1) {                                         // CubicSpline, src/SPHKernels.jl:89-106
-                    Wij = q <= R(1) ? M.alphaD * (R(1) - R(1.5) * q * q + R(0.75) * q * q * q) : M.alphaD * R(0.25) * (-(tq * tq * tq));
-                    const R dWdq = q <= R(1) ? M.alphaD * (R(-3) * q + R(2.25) * q * q) : M.alphaD * R(-0.75) * (tq * tq);
-                    fac = dWdq * M.h_inv / (sqrt(r2) + M.eta2);
-                } else {
-                    const R t1 = R(1) - q / R(2);
-                    const R t2 = t1 * t1;
-                    Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));          // src/SPHKernels.jl:75-78
-                    fac = M.alphaD * R(5) * (tq * tq * tq) / (R(8) * M.h * M.h);
-                }
-                const R Vj = M.m0 / (R)n0.w;
-                R fc[P];
-                fc[0] = Vj * Wij;
-                b[0] += M.m0 * Wij;
+    for (int r = 0; r < P; ++r) { b[r] = 0;
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const R gw = fac * xij[d];
-                    fc[d + 1] = Vj * gw;
-                    b[d + 1] += M.m0 * gw;
-                }
+        for (int c = 0; c < P; ++c) A[r][c] = 0; }
+    V4* const stash = reinterpret_cast<V4*>(s_lds[wv]);
+    const T H2t = sizeof(T) == 4 ? (T)(M.H2 * (1.0 + 1e-5)) : (T)M.H2;       // fp32: a superset of what the fp64 test accepts
+    int job0 = 0;
+    do {
+        // phase 1: U chunk loads in flight, test, park — until the rows are through or the stash could not take another group
+        int npend = 0;
+        for (; job0 < njobs && npend <= kStash - 64 * U; job0 += U) {
+            if ((job0 & 63) == 0) describe_jobs(job0);                         // (U divides 64: a group never straddles two blocks of jobs)
+            V4 v[U];
+            bool ok[U];
 #pragma unroll
-                for (int r = 0; r < P; ++r) {
-                    A[r][0] += fc[r];
+            for (int u = 0; u < U; ++u) {
+                const int jl = __builtin_amdgcn_readfirstlane((job0 & 63) + u);
+                const int first = __builtin_amdgcn_readlane(job_first, jl), left = __builtin_amdgcn_readlane(job_left, jl);
+                ok[u] = lane < left;                                            // (a job beyond the last one has nothing left)
+                v[u] = M.pk0[ok[u] ? first + lane : i];
+            }
 #pragma unroll
-                    for (int k = 0; k < D; ++k) A[r][k + 1] += (-xij[k]) * fc[r];
-                }
+            for (int u = 0; u < U; ++u) {
+                const T dx = gT[0] - v[u].x, dy = gT[1] - v[u].y, dz = D == 3 ? gT[2] - v[u].z : T(0);
+                const bool pass = ok[u] && v[u].w > T(0) && (dx * dx + dy * dy + dz * dz) <= H2t;       // ParticleType[j] == Fluid, within H
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) stash[npend + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = v[u];
+                npend += __builtin_popcountll(bal);
             }
         }
-    // combine the 64 partial sums (xor tree: every lane ends with the same totals)
+        // phase 2 on the parked records
+        const int n = npend;
+        wave_sync();
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            if (k0 + lane >= n) continue;
+            const V4 n0 = stash[k0 + lane];
+            const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
+            const R r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
+            if (!(r2 <= M.H2)) continue;                                     // the exact test (src/SPHCellList.jl:336)
+            // |xᵢⱼ| from the fp32 reciprocal square root + two Newton steps in fp64 (≈2⁻²⁴ → 2⁻⁴⁸ → below an ulp; the library's
+            // correctly rounded sqrt is ≈25 instructions of a kernel that is bound by their number)
+            R rr;
+            {
+                R y = (R)__builtin_amdgcn_rsqf((float)r2);
+                y = y * (R(1.5) - R(0.5) * r2 * y * y);
+                y = y * (R(1.5) - R(0.5) * r2 * y * y);
+                rr = r2 > R(1e-30) ? r2 * y : sqrt(r2);                     // (the float conversion underflows below 1e-38)
+            }
+            R q = rr * M.h_inv;
+            q = q > R(2) ? R(2) : q;
+            const R tq = q - R(2);
+            R Wij, fac;
+            if (M.kernel == 1) {                                         // CubicSpline, src/SPHKernels.jl:89-106
+                Wij = q <= R(1) ? M.alphaD * (R(1) - R(1.5) * q * q + R(0.75) * q * q * q) : M.alphaD * R(0.25) * (-(tq * tq * tq));
+                const R dWdq = q <= R(1) ? M.alphaD * (R(-3) * q + R(2.25) * q * q) : M.alphaD * R(-0.75) * (tq * tq);
+                fac = dWdq * M.h_inv / (rr + M.eta2);
+            } else {
+                const R t1 = R(1) - q * R(0.5);
+                const R t2 = t1 * t1;
+                Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));          // src/SPHKernels.jl:75-78
+                fac = M.gfac * (tq * tq * tq);                           // αD·5/(8h²)·(q − 2)³, :85-86
+            }
+            const R Vj = M.m0 * fast_rcp((R)n0.w);
+            R fc[P];
+            fc[0] = Vj * Wij;
+            b[0] += M.m0 * Wij;
 #pragma unroll
-    for (int r = 0; r < P; ++r) {
+            for (int d = 0; d < D; ++d) {
+                const R gw = fac * xij[d];
+                fc[d + 1] = Vj * gw;
+                b[d + 1] += M.m0 * gw;
+            }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) b[r] += __shfl_xor(b[r], o, 64);
+            for (int r = 0; r < P; ++r) {
+                A[r][0] += fc[r];
 #pragma unroll
-        for (int c = 0; c < P; ++c) {
+                for (int k = 0; k < D; ++k) A[r][k + 1] += (-xij[k]) * fc[r];
+            }
+        }
+        wave_sync();
+    } while (job0 < njobs);
+    // the 64 partial sums of every moment, added in a fixed order: upper half onto lower half, then lane v adds row v
+    {
+        double (*red)[33] = reinterpret_cast<double (*)[33]>(s_lds[wv]);
+        auto fold = [&](R x) -> R {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+            unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32), lo2 = lo, hi2 = hi;
+            swap_halves(lo, lo2); swap_halves(hi, hi2);      // lo2 / hi2: lanes 0-31 now hold the words of lanes 32-63
+            return x + __longlong_as_double((long long)(((unsigned long long)hi2 << 32) | lo2));
+        };
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) A[r][c] += __shfl_xor(A[r][c], o, 64);
+        for (int r = 0; r < P; ++r) {
+            const R fb = fold(b[r]);
+            if (lane < 32) red[r][lane] = fb;
+#pragma unroll
+            for (int c = 0; c < P; ++c) { const R fa = fold(A[r][c]); if (lane < 32) red[P + r * P + c][lane] = fa; }
+        }
+        wave_sync();
+        if (lane < NV) {
+            R s = 0;
+            for (int k = 0; k < 32; ++k) s += red[lane][k];
+            red[lane][32] = s;
+        }
+        wave_sync();
+        if (lane != 0) return;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            b[r] = red[r][32];
+#pragma unroll
+            for (int c = 0; c < P; ++c) A[r][c] = red[P + r * P + c][32];
         }
     }
-    if (lane != 0) return;
     // ApplyMDBCCorrection, src/SPHCellList.jl:598-622
     R det;
     if constexpr (P == 3) {
@@ -802,7 +912,7 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
     bool write = false;
     if (fabs(det) >= R(1e-3)) {
         // Gaussian elimination with partial pivoting on [A | b] (same order as the oracle)
-        R Mx[P][P + 1];
+        R Mx[P][P + 1], ipiv[P];
 #pragma unroll
         for (int r = 0; r < P; ++r) {
 #pragma unroll
@@ -822,9 +932,12 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
                     for (int c = 0; c <= P; ++c) { R t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
                 }
             }
+            // (one reciprocal per pivot instead of a division per row — ten IEEE divisions of ≈15 instructions each on the one lane
+            // the wave waits for; 1/pivot to 2⁻⁵², the system is solved to its conditioning either way)
+            ipiv[k] = fast_rcp(Mx[k][k]);
 #pragma unroll
             for (int r = k + 1; r < P; ++r) {
-                const R f = Mx[r][k] / Mx[k][k];
+                const R f = Mx[r][k] * ipiv[k];
 #pragma unroll
                 for (int c = k; c <= P; ++c) Mx[r][c] -= f * Mx[k][c];
             }
@@ -835,7 +948,7 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
             R acc = Mx[r][P];
 #pragma unroll
             for (int c = r + 1; c < P; ++c) acc -= Mx[r][c] * s[c];
-            s[r] = acc / Mx[r][r];
+            s[r] = acc * ipiv[r];
         }
         const R xi[3] = {(R)me.x, (R)me.y, (R)me.z};
         R v1 = s[0];
@@ -1019,14 +1132,30 @@ struct MotionTable {
     unsigned long long group[16];
     double vel[16], start[16], dur[16], dir[16][3];
 };
+// the step control taken inside the first k_progress_motion of a step (the scheme of ForceParams::ctl_in); ctl_in = null: not
+struct MotionCtl { const StepCtrl* ctl_in; StepCtrl* ctl_out; const unsigned long long* red_in; unsigned long long* red_zero; double h, c0, CFL; };
 template <class T>
 __global__ void __launch_bounds__(256) k_progress_motion(Half<typename Vec4<T>::type> pk0, Half<typename Vec4<T>::type> pk1,
                                                          const uint8_t* type, const unsigned long long* group, int N,
                                                          MotionTable M, double total_time, double dt2, const StepCtrl* ctrl,
-                                                         typename Vec4<T>::type* comp) {
+                                                         typename Vec4<T>::type* comp, const MotionCtl mc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ctrl) { if (!ctrl->active) return; total_time = ctrl->t_step_start; dt2 = ctrl->dt2; }
-    if (i >= N || (type[i] & 0x3F) != 3) return;
+    const bool mine = i < N && (type[i] & 0x3F) == 3;
+    if (mc.ctl_in != nullptr) {
+        // the control of the step taken HERE (handles with moving bodies and nothing else in front of their predictor): the Moving
+        // particles need the decisions — Δt/2, the clock — and the first thread stores them for the kernels behind
+        if (!mine && i != 0) return;
+        StepCtrl c = *mc.ctl_in;
+        const unsigned long long r0 = mc.red_in[0], r1 = mc.red_in[1], r2 = mc.red_in[2], r3 = mc.red_in[3];
+        const bool consumed = step_control_decide<T>(r0, r1, r2, r3, c, mc.h, mc.c0, mc.CFL);
+        if (i == 0) {
+            *mc.ctl_out = c;
+            if (consumed) { mc.red_zero[0] = 0; mc.red_zero[1] = 0; mc.red_zero[2] = 0; mc.red_zero[3] = 0; }
+        }
+        if (!c.active) return;
+        total_time = c.t_step_start; dt2 = c.dt2;
+    } else if (ctrl) { if (!ctrl->active) return; total_time = ctrl->t_step_start; dt2 = ctrl->dt2; }
+    if (!mine) return;
     const unsigned long long g = group[i];
     for (int m = 0; m < M.n; ++m) {
         if (M.group[m] != g) continue;
@@ -1114,7 +1243,11 @@ __global__ void __launch_bounds__(256) k_dd_gather(Half<const typename Vec4<T>::
     DdRecord<T>::pk1(buf, n)[k] = pk1[i];
     DdRecord<T>::acc(buf, n)[k] = acc[i];
     DdRecord<T>::ghost(buf, n)[k] = ghost[i];
-    if constexpr (sizeof(T) == 4) { typename Vec4<T>::type c; c.x = c.y = c.z = c.w = T(0); DdRecord<T>::comp(buf, n)[k] = comp ? comp[i] : c; }
+    if constexpr (sizeof(T) == 4) {
+        typename Vec4<T>::type c; c.x = c.y = c.z = c.w = T(0);
+        if (comp) c = comp[i];
+        DdRecord<T>::comp(buf, n)[k] = c;
+    }
     DdRecord<T>::id(buf, n)[k] = id[i];
     DdRecord<T>::grp(buf, n)[k] = grp[i];
     DdRecord<T>::tag(buf, n)[k] = tag[i];

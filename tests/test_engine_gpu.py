@@ -836,6 +836,7 @@ def test_identity_rebuilds_change_nothing(case, fb, request, monkeypatch):
     from sphexample_amd.engine import make_engine
     p, s = request.getfixturevalue(case)
     out = {}
+    monkeypatch.setenv("SPHMI_DEVICE_REBUILD", "0")     # (the short cut belongs to the host-side rebuild; handles as small as these rebuild on the device by default)
     for flag in ("1", "0"):
         monkeypatch.setenv("SPHMI_SAME_CELLS", flag)
         eng = make_engine(p, s, device_float_bytes=fb)
@@ -871,3 +872,88 @@ def test_ghost_points_follow_the_sort_without_mdbc(dam_break_2d):
         d = eng.download(("ID", "GhostPoints"))
         np.testing.assert_array_equal(d["GhostPoints"], np.stack([d["ID"] * 1.5, -d["ID"] * 0.25], axis=1), err_msg=f"after {pr.n_rebuilds} rebuilds")
     assert pr.n_rebuilds >= 5
+
+
+# ---- device-side rebuilds (round 4): small handles rebuild their cell list without asking the host ---------------------------------
+def _counter(eng, prefix):
+    return next(v[1] for k, v in eng.timers().items() if k.startswith(prefix))
+
+
+@pytest.mark.parametrize("case,fb,vel", [("dam_break_2d", 8, 3.0), ("dam_break_2d", 4, 3.0), ("dam_break_3d_shipped", 8, 3.0), ("dam_break_3d_shipped", 4, 3.0),
+                                         ("dam_break_2d_mdbc", 8, 2.0), ("moving_square", 8, 0.0), ("duckling", 4, 1.0)])
+def test_device_side_rebuild_is_the_host_side_rebuild(case, fb, vel, request, monkeypatch):
+    """UpdateNeighbors! (src/SPHCellList.jl:138-163) on the device's own say-so — the grid of the last host-side rebuild plus two
+    cell layers, k_cell_count → k_scan_single → k_scatter → k_rankfix → k_permute → k_tile_schedule_small, the force launches on an
+    upper-bound grid until the run table has been seen — against the host path ($SPHMI_DEVICE_REBUILD=0: bounding box, exact grid,
+    three synchronisations): BIT FOR BIT the same state, order, cells and loop counters, call after call, and the oracle's
+    rebuild steps and IndexCounter."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    if vel:
+        p = perturbed(p, seed=3, vel_scale=vel)               # fast enough for several Δx-triggered rebuilds in the window
+    dev = make_engine(p, s, device_float_bytes=fb)
+    monkeypatch.setenv("SPHMI_DEVICE_REBUILD", "0")
+    host = make_engine(p, s, device_float_bytes=fb)
+    monkeypatch.delenv("SPHMI_DEVICE_REBUILD")
+    orc = make_oracle(p, s)
+    for e in (dev, host):
+        if hasattr(p, "geometries"):
+            e.set_motions(p.geometries)
+    if hasattr(p, "geometries"):
+        orc.set_motions(p.geometries)
+    for steps in (1, 40, 37, 2, 60):
+        pd, ph, po = dev.advance(1e9, max_steps=steps), host.advance(1e9, max_steps=steps), orc.advance(1e9, max_steps=steps)
+        assert (pd.iteration, pd.steps_done, pd.n_rebuilds, pd.index_counter, pd.total_time, pd.last_dt) == \
+               (ph.iteration, ph.steps_done, ph.n_rebuilds, ph.index_counter, ph.total_time, ph.last_dt)
+        assert (pd.iteration, pd.n_rebuilds) == (po.iteration, po.n_rebuilds)
+        if fb == 8:
+            assert pd.index_counter == po.index_counter
+        d, h = dev.download(), host.download()
+        for k in d:
+            np.testing.assert_array_equal(d[k], h[k], err_msg=k)
+        np.testing.assert_array_equal(dev.unique_cells(), host.unique_cells())
+    assert pd.n_rebuilds >= 5
+    assert _counter(dev, "02c") >= pd.n_rebuilds - 1 - _counter(dev, "02d") and _counter(host, "02c") == 0
+    for e in (dev, host, orc):
+        e.close()
+
+
+@pytest.mark.parametrize("dims,fb", [(2, 8), (3, 8), (3, 4)])
+def test_a_particle_leaving_the_sticky_grid_sends_the_rebuild_to_the_host(dims, fb, monkeypatch):
+    """A free blob of fluid flying apart: the bounding box grows with every rebuild interval, so a device-side rebuild sooner or later
+    finds a particle outside the grid it was given.  That rebuild must change NOTHING (it copies instead of permuting), the control
+    must cancel every step queued behind it (error 3, never seen by the caller), and the host-side rebuild that follows must leave
+    exactly what a handle that always rebuilds on the host has: same order (the in-cell order is a history, Q4), same state."""
+    from oracle.oracle import make_oracle
+    from sphexample_amd import (ArtificialViscosity, LinearDensityDiffusion, SimulationConstants, SimulationMetaData, SPHKernelInstance,
+                                WendlandC2, particles_from_arrays)
+    from sphexample_amd.cases import CaseSetup
+    from sphexample_amd.engine import make_engine
+    rng = np.random.default_rng(7)
+    dx = 0.02
+    m = 18 if dims == 2 else 9
+    g = np.stack(np.meshgrid(*[np.arange(m)] * dims, indexing="ij"), -1).reshape(-1, dims) * dx + rng.uniform(-1e-3, 1e-3, size=(m ** dims, dims))
+    n = len(g)
+    p = particles_from_arrays(dims, g, np.full(n, 1000.0), np.ones(n, np.uint8), np.ones(n, np.int64), np.arange(n) + 1)
+    c = g - g.mean(0)
+    p.Velocity[:] = (60.0 if dims == 3 else 150.0) * c / np.abs(c).max()      # outwards: a cell of H = 0.08 every ≈15 (3-D) / ≈6 (2-D) steps
+    sc = SimulationConstants(dx=dx, m0=1000 * dx ** dims, c0=80.0, alpha=0.01, g=0.0, CFL=0.2)
+    s = CaseSetup("blob", sc, SPHKernelInstance(dims, WendlandC2(), dx=dx, k=2.0), SimulationMetaData(Dimensions=dims), ArtificialViscosity(), LinearDensityDiffusion())
+    dev = make_engine(p, s, device_float_bytes=fb)
+    monkeypatch.setenv("SPHMI_DEVICE_REBUILD", "0")
+    host = make_engine(p, s, device_float_bytes=fb)
+    monkeypatch.delenv("SPHMI_DEVICE_REBUILD")
+    orc = make_oracle(p, s)
+    for steps in (60, 1, 90):
+        pd, ph, po = dev.advance(1e9, max_steps=steps), host.advance(1e9, max_steps=steps), orc.advance(1e9, max_steps=steps)
+        assert (pd.iteration, pd.n_rebuilds, pd.index_counter, pd.total_time) == (ph.iteration, ph.n_rebuilds, ph.index_counter, ph.total_time)
+        assert (pd.iteration, pd.n_rebuilds) == (po.iteration, po.n_rebuilds)
+        d, h = dev.download(), host.download()
+        for k in d:
+            np.testing.assert_array_equal(d[k], h[k], err_msg=k)
+    assert _counter(dev, "02d") >= 1 and _counter(dev, "02c") >= 2, dev.timers()
+    if fb == 8:
+        o = orc.download()
+        np.testing.assert_array_equal(d["ID"], o["ID"])
+        assert relmax(d["Density"], o["Density"]) < 1e-9 and np.abs(d["Position"] - o["Position"]).max() < 1e-9 * np.abs(o["Position"]).max()
