@@ -49,23 +49,47 @@ __global__ void __launch_bounds__(256) k_dd_compact(const int* flag, const int* 
     if (i < N && flag[i]) out[pos[i]] = i;
 }
 // min / max of cx over the listed particles (slab-skip check) and over owned particles (re-cut extent)
+// (grid-stride over at most 512 blocks: one pair of atomics per WAVE of a 1 M-row launch — 16 k of them on one cache line — was 0.19–0.37 ms)
 __global__ void __launch_bounds__(256) k_dd_minmax(const int* cx, const uint8_t* type, const int* idx, int n, int* mm) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     int lo = INT32_MAX, hi = INT32_MIN;
-    if (k < n) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int i = idx ? idx[k] : k;
-        if (idx || (type[i] != 0 && !(type[i] & kGhostMask))) lo = hi = cx[i];
+        if (idx || (type[i] != 0 && !(type[i] & kGhostMask))) { const int c = cx[i]; lo = min(lo, c); hi = max(hi, c); }
     }
+    __shared__ int s_lo[4], s_hi[4];
     lo = wave_min_i(lo); hi = wave_max_i(hi);
-    if ((threadIdx.x & 63) == 0) { if (lo != INT32_MAX) atomicMin(&mm[0], lo); if (hi != INT32_MIN) atomicMax(&mm[1], hi); }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+        if (lo != INT32_MAX) atomicMin(&mm[0], lo);
+        if (hi != INT32_MIN) atomicMax(&mm[1], hi);
+    }
 }
 // cells that hold owned particles (a cell is wholly owned or wholly ghost: the cuts run along cell columns)
 __global__ void __launch_bounds__(256) k_dd_count_owned_cells(const int* key, const uint8_t* type, int N, int ncell, int* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool head = false;
-    if (i < N) { const int k = key[i]; head = k < ncell && type[i] != 0 && !(type[i] & kGhostMask) && (i == 0 || key[i - 1] != k); }
-    const unsigned long long b = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
+    // (grid-stride, one atomic per block: see k_dd_minmax)
+    int n = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int k = key[i];
+        n += (k < ncell && type[i] != 0 && !(type[i] & kGhostMask) && (i == 0 || key[i - 1] != k)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    __shared__ int s_n[4];
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) { const int t = s_n[0] + s_n[1] + s_n[2] + s_n[3]; if (t) atomicAdd(out, t); }
+}
+// a stream-ordered copy between two buffers this process can address — the slabs of one handle on one device, or on devices with
+// peer access: `hipMemcpyAsync` device → device moved a 4.4 MB halo at ≈40 GB/s (110 µs a message, four messages per step and slab:
+// a third of the step of two slabs sharing a GPU — profiles/r04_slab_overhead.md)
+__global__ void __launch_bounds__(256) k_dd_copy(const void* src, void* dst, size_t bytes) {
+    const size_t n16 = bytes >> 4;
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) d[k] = s[k];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) reinterpret_cast<char*>(dst)[(n16 << 4) + threadIdx.x] = reinterpret_cast<const char*>(src)[(n16 << 4) + threadIdx.x];
 }
 struct RedPtrs { const unsigned long long* p[16]; int n; };
 // The per-step decisions of a slab (one wave): M = max(M, T_0, …) over four uint64 bit patterns — T_0 this slab's slots after the
@@ -485,6 +509,7 @@ struct MultiEngine final : EngineBase {
     std::vector<Rank> R;               // the LOCAL ones (all of them in one-process mode, one in rank mode)
     bool rank_mode = false;            // one local slab, peers in other processes
     bool use_rccl = false;
+    bool peer_ok = true;               // every pair of this process's devices has peer access: the local transport copies with a kernel
     std::unique_ptr<ShmWorld> shm;     // rank mode with SPHMI_TRANSPORT=shm: peers behind a shared-memory segment instead of RCCL
     HostBuf stage_s, stage_r;
     unsigned long long* red_h = nullptr;
@@ -574,7 +599,8 @@ struct MultiEngine final : EngineBase {
             for (auto& a : R) for (auto& b : R) if (a.device != b.device) {
                 HC(hipSetDevice(a.device));
                 int can = 0; (void)hipDeviceCanAccessPeer(&can, a.device, b.device);
-                if (can) { hipError_t e = hipDeviceEnablePeerAccess(b.device, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+                if (can) { hipError_t e = hipDeviceEnablePeerAccess(b.device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { can = 0; } (void)hipGetLastError(); }
+                if (!can) peer_ok = false;
             }
         }
         for (auto& r : R) {
@@ -709,7 +735,13 @@ struct MultiEngine final : EngineBase {
             hipStream_t q = side ? d->side : d->main;
             HC(hipSetDevice(d->device));
             HC(hipStreamWaitEvent(q, s->ev_pack, 0));
-            if (m.bytes) HC(hipMemcpyAsync(m.rbuf, m.sbuf, m.bytes, hipMemcpyDeviceToDevice, q));
+            if (m.bytes) {
+                // (sbuf / rbuf are 16-byte aligned device allocations; across devices the kernel needs peer access — else the runtime's copy)
+                if (s->device == d->device || peer_ok) {
+                    hipLaunchKernelGGL(k_dd_copy, dim3((unsigned)std::min<size_t>((m.bytes / 16 + 255) / 256 + 1, 2048)), dim3(256), 0, q, m.sbuf, m.rbuf, m.bytes);
+                    HC(hipGetLastError());
+                } else HC(hipMemcpyAsync(m.rbuf, m.sbuf, m.bytes, hipMemcpyDeviceToDevice, q));
+            }
             if (m.slot >= 0) {       // the sender must not refill this buffer before the copy has read it
                 HC(hipEventRecord(s->ev_consumed[m.slot], q));
                 s->consumed_valid[m.slot] = true;
@@ -831,7 +863,7 @@ struct MultiEngine final : EngineBase {
                 Rank& r = R[q]; HC(hipSetDevice(r.device));
                 r.mm_h[0] = INT32_MAX; r.mm_h[1] = INT32_MIN;
                 HC(hipMemcpyAsync(r.mm_d, r.mm_h, 8, hipMemcpyHostToDevice, r.main));
-                hipLaunchKernelGGL(k_dd_minmax, dim3((r.e->N + 255) / 256), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)nullptr, r.e->N, r.mm_d);
+                hipLaunchKernelGGL(k_dd_minmax, dim3(std::min((r.e->N + 255) / 256, 512)), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)nullptr, r.e->N, r.mm_d);
                 HC(hipMemcpyAsync(r.mm_h, r.mm_d, 8, hipMemcpyDeviceToHost, r.main));
                 HC(hipStreamSynchronize(r.main));
                 ext[(size_t)q * 2] = -(long long)r.mm_h[0]; ext[(size_t)q * 2 + 1] = r.mm_h[1];
@@ -880,7 +912,7 @@ struct MultiEngine final : EngineBase {
                 if (!n) continue;
                 r.mm_h[0] = INT32_MAX; r.mm_h[1] = INT32_MIN;
                 HC(hipMemcpyAsync(r.mm_d, r.mm_h, 8, hipMemcpyHostToDevice, r.main));
-                hipLaunchKernelGGL(k_dd_minmax, dim3((n + 255) / 256), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)(s == 0 ? go_l[q] : go_r[q]), n, r.mm_d);
+                hipLaunchKernelGGL(k_dd_minmax, dim3(std::min((n + 255) / 256, 512)), dim3(256), 0, r.main, (const int*)r.cx.p, (const uint8_t*)r.e->type[r.e->cur], (const int*)(s == 0 ? go_l[q] : go_r[q]), n, r.mm_d);
                 HC(hipMemcpyAsync(r.mm_h, r.mm_d, 8, hipMemcpyDeviceToHost, r.main));
                 HC(hipStreamSynchronize(r.main));
                 if ((s == 0 && r.mm_h[0] < plan.lo[r.rank - 1]) || (s == 1 && r.mm_h[1] > plan.hi[r.rank + 1]))
@@ -1014,7 +1046,14 @@ struct MultiEngine final : EngineBase {
     }
     void pass(int which) {
         const int set = which - 1;
-        const bool serial = !overlap || (cfg.mdbc == SPHMI_MDBC_SIMPLE && which == 1);
+        bool serial = !overlap || (cfg.mdbc == SPHMI_MDBC_SIMPLE && which == 1);
+        // (no local slab sends or receives anything — a one-slab world: the whole pass is one launch on the main stream, without the
+        // event hand-overs to the side stream, each of which is a bubble of ≈6 µs in the main stream)
+        {
+            bool any = false;
+            for (auto& r : R) { const Halo& h = r.halo[set]; any |= (h.n_send_l + h.n_send_r + h.n_slot_l + h.n_slot_r) != 0; }
+            if (!any && world == 1) serial = true;
+        }
         std::vector<Msg> msgs;
         for (auto& r : R) {
             HC(hipSetDevice(r.device));
@@ -1190,7 +1229,7 @@ struct MultiEngine final : EngineBase {
             Engine<T>& e = *r.e;
             if (!e.have_grid) continue;
             HC(hipMemsetAsync(r.mm_d, 0, 4, r.main));
-            hipLaunchKernelGGL(k_dd_count_owned_cells, dim3((e.N + 255) / 256), dim3(256), 0, r.main, (const int*)e.key[e.cur], (const uint8_t*)e.type[e.cur], e.N, e.grid.ncell, r.mm_d);
+            hipLaunchKernelGGL(k_dd_count_owned_cells, dim3(std::min((e.N + 255) / 256, 512)), dim3(256), 0, r.main, (const int*)e.key[e.cur], (const uint8_t*)e.type[e.cur], e.N, e.grid.ncell, r.mm_d);
             HC(hipMemcpyAsync(r.mm_h, r.mm_d, 4, hipMemcpyDeviceToHost, r.main));
             HC(hipStreamSynchronize(r.main));
             index_counter += r.mm_h[0];

@@ -1191,24 +1191,43 @@ __global__ void __launch_bounds__(256) k_dd_cellx(Half<const typename Vec4<T>::t
 // Load balance by WORK, not by particle count: the cost of a particle in the neighbour kernel goes with the candidates of
 // its 3^D cells (a dry wall particle has a tenth of an interior fluid particle's).  Per cell column along the slab axis:
 // Σ over OWNED particles of that candidate count, from the cell list of the last rebuild.
+// (One device-scope 64-bit atomic per particle on a few hundred counters was 2.6 ms at 0.5 M particles and 5 ms at 1 M — round 4's
+// trace of two slabs on one GPU, profiles/r04_slab_overhead.md: the lanes of a wave hold a handful of columns, so equal neighbours
+// are merged by a segmented scan first — one atomic per run of equal columns in a wave, ≈60 µs.)
 __global__ void __launch_bounds__(256) k_dd_column_cost(const int* key, const uint8_t* type, const int* cstart, int N, GridDesc g,
                                                         int D, int axis, long long col0, int ncols, unsigned long long* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint8_t t = type[i];
-    if (t == 0 || (t & kGhostMask)) return;
-    const int k = key[i];
-    if (k >= g.ncell) return;
-    const int nxp = g.np[0], nxyp = g.np[0] * g.np[1];
-    const int nseg = D == 3 ? 9 : 3;
+    const int lane = threadIdx.x & 63;
+    long long col = -1;
     int c = 0;
-    for (int seg = 0; seg < nseg; ++seg) {
-        const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
-        c += cstart[k + off + 2] - cstart[k + off - 1];
+    if (i < N) {
+        const uint8_t t = type[i];
+        const int k = key[i];
+        if (t != 0 && !(t & kGhostMask) && k < g.ncell) {
+            const int nxp = g.np[0], nxyp = g.np[0] * g.np[1];
+            const int nseg = D == 3 ? 9 : 3;
+            for (int seg = 0; seg < nseg; ++seg) {
+                const int off = D == 3 ? ((seg % 3) - 1) * nxp + ((seg / 3) - 1) * nxyp : (seg - 1) * nxp;
+                c += cstart[k + off + 2] - cstart[k + off - 1];
+            }
+            const int cc[3] = {k % nxp, (k / nxp) % g.np[1], k / nxyp};
+            col = (long long)cc[axis] - 1 + g.gmin[axis] - col0;
+            if (col < 0 || col >= ncols) col = -1;
+        }
     }
-    const int cc[3] = {k % nxp, (k / nxp) % g.np[1], k / nxyp};
-    const long long col = (long long)cc[axis] - 1 + g.gmin[axis] - col0;
-    if (col >= 0 && col < ncols) atomicAdd(&out[col], (unsigned long long)c);
+    // runs of equal columns inside the wave (the particles are cell-sorted): the head of a run adds the run's sum
+    const int icol = (int)col;
+    const int prev = __shfl_up(icol, 1, 64);
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(lane == 0 || icol != prev);
+    unsigned long long sum = (unsigned long long)c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_down(sum, o, 64);
+        // lanes lane+1 … lane+o belong to my run iff no head sits in (lane, lane+o]
+        const unsigned long long between = lane + o < 64 ? (heads >> (lane + 1)) & ((o >= 64 ? ~0ull : ((1ull << o) - 1ull))) : 1ull;
+        if (lane + o < 64 && between == 0) sum += u;
+    }
+    if (((heads >> lane) & 1ull) && icol >= 0 && sum) atomicAdd(&out[icol], sum);
 }
 
 // Migration record buffer for n particles:

@@ -20,6 +20,21 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+class _StdoutToStderr:
+    """gloo announces its connections on the C++ side's stdout ("[Gloo] Rank 0 is connected to …"); bench.py's stdout is ONE JSON
+    line.  File descriptor 1 points at stderr while the process group is set up."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class Rendezvous:
     def __init__(self, rank: int, world: int, master_addr: Optional[str] = None, master_port: Optional[int] = None):
         import torch.distributed as dist
@@ -27,6 +42,11 @@ class Rendezvous:
         self._own = not dist.is_initialized()
         if not self._own:
             return
+        with _StdoutToStderr():
+            self._init(rank, world, master_addr, master_port)
+
+    def _init(self, rank, world, master_addr, master_port):
+        dist = self._dist
         if master_port is None and os.environ.get("MASTER_PORT"):
             # under a launcher (torch.distributed.run exports MASTER_ADDR / MASTER_PORT and may host the store itself):
             # the launcher's own rendezvous, untouched
