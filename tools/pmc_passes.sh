@@ -18,7 +18,7 @@ while read -r line; do
   echo "### pass $i: $line"
   case "$line" in
     FETCH_SIZE*|WRITE_SIZE*|TCC_*) python $R/tools/pmc_summary.py "$db" "sphmi::k_" ;;
-    *) python $R/tools/pmc_summary.py "$db" "k_neighbor_force" ;;
+    *) python $R/tools/pmc_summary.py "$db" "${PMC_FILTER:-k_neighbor_force}" ;;
   esac
   rm -rf $R/gpurun_out/$out/p$i
 done <<'LIST'
