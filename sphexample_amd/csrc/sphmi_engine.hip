@@ -203,7 +203,17 @@ struct Engine final : EngineBase {
     int64_t n_device_rebuilds = 0, n_grid_overflows = 0; double dev_rebuild_secs = 0;
     bool count_clean = false;          // `count` is all zero (k_scan_single leaves it so)
     bool part_copy_queued = false;     // a copy of the run table into part_h is in flight: read it at the next synchronisation
-    int part_bound() const { const int nt = (N + kWave - 1) / kWave; return (nt + 3) / 4 + 1; }
+    // The longest XCD run a device-side (re-)schedule may produce — the force launches use 8 × this many blocks until the host has
+    // seen the run table.  One and a half times the longest run of the last table the host HAS seen: the clamp then hardly ever binds
+    // (a bound of twice the mean run cut the long run of cheap bottom-plate tiles short and cost the 159 k-particle fp64 case 5 %),
+    // and the launches of one batch carry half as many empty blocks again as they need.
+    int part_seen = 0;                 // longest run of the last run table the host has read
+    static constexpr int kExactGridFromTiles = 1024;
+    int ntile_now() const { return (N + kWave - 1) / kWave; }
+    int part_bound() const {
+        const int nt = (N + kWave - 1) / kWave;
+        return std::min(nt, std::max(part_seen + part_seen / 2 + 1, nt / 8 + 1));
+    }
     bool device_rebuild_ok() const {
         return dev_rebuild && !dd_slab && have_grid && sticky_grid && (N + kWave - 1) / kWave <= kSmallMaxTiles;
     }
@@ -526,7 +536,9 @@ struct Engine final : EngineBase {
         const int ntile = list_tiles[list];        // fixed at the rebuild: the choice must not follow the measured run lengths
         const int wpt = waves_per_tile(ntile, MODEL < 0);
         bool resched_after = false;
-        if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && batch_step == 0) {
+        // (the XCD finishing times may also be taken by the SECOND step of the batch whose first step measured the work — the schedule made
+        // from that work is in place by then — so that a handle knows its XCD shares after ONE batch, not after its second rebuild interval)
+        if (PASS == PASS_CORRECTOR && list == 0 && sched_state != 0 && wpt <= 2 && (batch_step == 0 || (batch_step == 1 && sched_state == 2))) {
             // (the first step of a batch executes unless the batch starts with a rebuild request; then nothing is
             // written and the sample is void: all-zero work keeps the schedule, all-zero ends are ignored)
             if (sched_state == 1 && resched) {
@@ -590,6 +602,24 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
     }
 
+    // finishing time of every XCD in the sampled launch (xcd_clock_h, copied and synchronised by the caller) → its share of the
+    // estimated cost moves towards the speed it showed (damped; shares stay within ±20 % of an eighth)
+    void apply_xcd_feedback() {
+        xcd_sampled = false;
+        const unsigned long long t0 = xcd_clock_h[8];
+        double Tx[8], mean = 0; bool ok = t0 != ~0ull;
+        for (int x = 0; x < 8 && ok; ++x) { ok = xcd_clock_h[x] > t0; Tx[x] = ok ? (double)(xcd_clock_h[x] - t0) : 0.0; mean += Tx[x] / 8; }
+        if (ok && xcd_feedback) {
+            double sum = 0;
+            for (int x = 0; x < 8; ++x) { xcd_w[x] *= std::sqrt(mean / Tx[x]); xcd_w[x] = std::min(0.15, std::max(0.10, xcd_w[x])); sum += xcd_w[x]; }
+            for (int x = 0; x < 8; ++x) xcd_w[x] /= sum;
+            // the schedule in use was cut with the OLD shares: cut it again from the same measured work (when that still describes the
+            // order the particles are in) — otherwise the new shares would wait for the next rebuild that sorts, which a column at rest never has
+            if (work_valid && resched && !dd_slab) resched0_pending = true;
+        }
+    }
+    bool work_valid = false;           // tile_work_d holds the measured work of the tiles in their PRESENT order
+
     // ---- UpdateNeighbors! -------------------------------------------------------------------
     void rebuild() {
         Ev ev = begin_phase(PH_REBUILD);
@@ -609,19 +639,7 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
         HC(hipMemcpyAsync(bbox_h, bbox_d, 7 * 4, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
-        if (xcd_sampled) {
-            xcd_sampled = false;
-            // finishing time of every XCD in the sampled launch → its share of the estimated cost moves towards the
-            // speed it showed (damped; shares stay within ±20 % of an eighth)
-            const unsigned long long t0 = xcd_clock_h[8];
-            double Tx[8], mean = 0; bool ok = t0 != ~0ull;
-            for (int x = 0; x < 8 && ok; ++x) { ok = xcd_clock_h[x] > t0; Tx[x] = ok ? (double)(xcd_clock_h[x] - t0) : 0.0; mean += Tx[x] / 8; }
-            if (ok && xcd_feedback) {
-                double sum = 0;
-                for (int x = 0; x < 8; ++x) { xcd_w[x] *= std::sqrt(mean / Tx[x]); xcd_w[x] = std::min(0.15, std::max(0.10, xcd_w[x])); sum += xcd_w[x]; }
-                for (int x = 0; x < 8; ++x) xcd_w[x] /= sum;
-            }
-        }
+        if (xcd_sampled) apply_xcd_feedback();
         if (check_same && bbox_h[6] == 0) {
             n_rebuilds += 1; n_identity_rebuilds += 1;
             end_phase(ev);
@@ -734,10 +752,11 @@ struct Engine final : EngineBase {
                 list_tiles[l] = 0;
                 if (l < nlist) for (int x = 0; x < 8; ++x) { part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]); list_tiles[l] += part_h[16 * l + 8 + x]; }
             }
+            part_seen = part_max[0];
         }
         have_grid = true;
         n_rebuilds += 1;
-        sched_state = 1; sched1_state = dd_slab ? 1 : 0; resched0_pending = false; resched1_pending = false;
+        sched_state = 1; sched1_state = dd_slab ? 1 : 0; resched0_pending = false; resched1_pending = false; work_valid = false;
         end_phase(ev);
     }
 
@@ -798,8 +817,8 @@ struct Engine final : EngineBase {
         part_copy_queued = true;
         part_max[0] = part_bound(); part_max[1] = 0;
         list_tiles[0] = (N + kWave - 1) / kWave; list_tiles[1] = 0;
-        n_rebuilds += 1; n_device_rebuilds += 1; xcd_sampled = false;
-        sched_state = 1; sched1_state = 0; resched0_pending = false; resched1_pending = false;
+        n_rebuilds += 1; n_device_rebuilds += 1;
+        sched_state = 1; sched1_state = 0; resched0_pending = false; resched1_pending = false; work_valid = false;
         end_phase(ev);
     }
     // The rebuild in front of the next queued step, with what the host has to tell the control block `c` (mode 1: all of it, a new
@@ -819,6 +838,7 @@ struct Engine final : EngineBase {
     // The schedule of list 0 from the MEASURED work of every tile (the sampled corrector launch just queued): same
     // segments, classes and XCD shares as k_tile_order of the rebuild, true costs instead of candidate counts.
     void reschedule_from_work(int list) {
+        if (list == 0) work_valid = true;
         if (list == 0 && device_rebuild_ok()) {
             // small handles: one launch, and nobody waits for the table (the launches keep their upper-bound grid until the next
             // batch boundary has seen it)
@@ -826,6 +846,17 @@ struct Engine final : EngineBase {
             HC(hipGetLastError());
             part_copy_queued = true;
             part_max[0] = part_bound();
+            if (ntile_now() >= kExactGridFromTiles) {
+                // From ≈64 k particles on the exact grid is worth one round trip per rebuild interval: an upper-bound grid (half as many
+                // blocks again, all of them returning at once) made the fp64 corrector of the 159 k-particle case 17 % longer for the
+                // rest of the batch (341 against 331 µs per step over 200 steps; the small cases gain more from not waiting)
+                HC(hipMemcpyAsync(ctl_m + kCtlPart, ctl_d + kCtlPart, 16 * 4, hipMemcpyDeviceToHost, stream));
+                HC(hipStreamSynchronize(stream));
+                part_copy_queued = false;
+                int m = 0;
+                for (int x = 0; x < 8; ++x) m = std::max(m, part_h[8 + x]);
+                if (m > 0) { part_max[0] = std::min(m, part_bound()); part_seen = part_max[0]; }
+            }
             return;
         }
         const int ntile = (N + kWave - 1) / kWave;
@@ -848,6 +879,7 @@ struct Engine final : EngineBase {
         int m = 0;
         for (int x = 0; x < 8; ++x) m = std::max(m, part_h[16 * list + 8 + x]);
         if (m > 0) part_max[list] = m;
+        if (list == 0) part_seen = part_max[0];
     }
 
     // take_control: the kernel takes the decisions of the step itself (MdbcParams::ctl_in): reads control block `cpar` and slot set
@@ -892,7 +924,7 @@ struct Engine final : EngineBase {
             part_copy_queued = false;
             int m = 0;
             for (int x = 0; x < 8; ++x) m = std::max(m, part_h[8 + x]);
-            if (m > 0) part_max[0] = std::min(m, part_bound());
+            if (m > 0) { part_max[0] = std::min(m, part_bound()); part_seen = part_max[0]; }
         }
     }
 
@@ -981,7 +1013,13 @@ struct Engine final : EngineBase {
                 // the block the last queued step wrote, both sets of slots (below: the bad-ρ flag), the counters and the run table of a
                 // device-side rebuild: one copy
                 HC(hipMemcpyAsync(ctl_m, ctl_d, kCtlBytes, hipMemcpyDeviceToHost, stream));
+                // (the XCD finishing times of a sampled launch: the host-side rebuild reads them at its own synchronisation; handles that
+                // rebuild on the device have none — the shares of the next measured-work schedule would never move: 3 % on the 159 k-particle
+                // LaminarSPS case)
+                const bool clocks = xcd_sampled;
+                if (clocks) HC(hipMemcpyAsync(xcd_clock_h, xcd_clock_d, 16 * 8, hipMemcpyDeviceToHost, stream));
                 HC(hipStreamSynchronize(stream));
+                if (clocks) apply_xcd_feedback();
                 *ctrl_h = ((const StepCtrl*)ctl_m)[cpar];
                 sync_and_collect(ctrl_h, before, /*mirror_fresh=*/true);
                 c = *ctrl_h;
