@@ -224,7 +224,7 @@ struct Engine final : EngineBase {
     // (decided once per queued batch: before the first rebuild there is no tile schedule and the predictor launch is skipped —
     // nobody would take the decisions)
     // (plain handles take the control inside the predictor; mDBC handles inside k_mdbc, which runs first — $SPHMI_FUSE_MDBC=0: not)
-    int fuse_mdbc = 1, fuse_mdbc_max_n = 32768;
+    int fuse_mdbc = 1, fuse_mdbc_max_n = 1 << 30;
     bool fused_control() const {
         // (every wave of k_mdbc that has a ghost node repeats the decisions — ≈0.15 µs of fp64 arithmetic: worth the 6 µs launch
         // it replaces on the 2-D layouts, 37.5 against 40 µs per step; DucklingMDBC, 54 817 particles, loses 2 µs with it)
@@ -450,9 +450,9 @@ struct Engine final : EngineBase {
     T kv2() const { return (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h); }
     bool kv2_foldable() const { const T k = kv2(); return std::isnormal(k) && std::isfinite(T(1) / k) && std::isnormal(T(1) / k); }
     bool compiled_in_model() const {
-        // the models of the stock examples AND a kernel that vanishes at the cut-off (k = 2)
+        // the models of the stock examples; a kernel cut off before it vanishes (k < 2) takes the variant with the per-pair cut
         return cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR && cfg.shifting == SPHMI_SHIFT_NONE &&
-               cfg.H >= 2.0 * cfg.h && cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE && kv2_foldable();
+               cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE && kv2_foldable();
     }
     ForceParams<T> force_params(int src, int a, int out, double dt) const {
         ForceParams<T> P{};
@@ -497,11 +497,8 @@ struct Engine final : EngineBase {
     // tiles per block of the one-wave-per-tile launches (3-D fp32 compiled-in model; $SPHMI_TPB = 1, 2 or 4 overrides).  Measured at
     // 1.06 M particles (kernel ms per launch): 1 → 0.5601, 2 → 0.5591, 4 → 0.5558; it is what lets ONE tile segment per XCD
     // (the L2-friendly schedule) run as fast as sixteen: 0.5562 against 0.5585 / 0.5558
-#ifndef SPHMI_TPB_F64
-#define SPHMI_TPB_F64 0            // 1: fp64 handles launch their one-wave tiles four per block too.  Off: 32 KB of queues per block leave the
-                                   // units five blocks where registers allow four waves per SIMD anyway, and a block lives as long as its slowest
-                                   // tile — 470 k particles 921 → 895 µs per step, 1.06 M 1917 → 1906 (tools/bench_f64.py, both with SPHMI_PIPE_F64 = 0)
-#endif
+    // (fp64 handles launch their one-wave tiles one per block: 32 KB of queues per four-tile block would leave the units five blocks where
+    // registers allow four waves per SIMD anyway, and a block lives as long as its slowest tile — 470 k particles 921 → 895 µs per step, round 3)
     int tpb = 4;
     int tpb2 = 1;                      // two-wave tiles in pairs (workgroups of four waves); $SPHMI_TPB2=0 switches it off
     template <int PASS, int MODEL, int TPB> void launch_force_tpb(const ForceParams<T>& P, int list) {
@@ -510,7 +507,7 @@ struct Engine final : EngineBase {
         HC(hipGetLastError());
     }
     template <int PASS, int MODEL, int WPT> void launch_force_wpt(const ForceParams<T>& P, int list) {
-        if constexpr (WPT == 1 && MODEL == kModelDefault && (sizeof(T) == 4 || SPHMI_TPB_F64 != 0)) {
+        if constexpr (WPT == 1 && MODEL >= 0 && sizeof(T) == 4) {
             if (D == 3 && tpb == 4) { launch_force_tpb<PASS, MODEL, 4>(P, list); return; }
             if (D == 3 && tpb == 2) { launch_force_tpb<PASS, MODEL, 2>(P, list); return; }
         }
@@ -572,7 +569,10 @@ struct Engine final : EngineBase {
     }
     // list: 0 = interior tiles (all tiles when the handle has no slab), 1 = slab-edge tiles
     template <int PASS> void launch_force(const ForceParams<T>& P, int list = 0) {
-        if (compiled_in_model()) launch_force_model<PASS, kModelDefault>(P, list);
+        if (compiled_in_model()) {
+            if (cfg.H >= 2.0 * cfg.h) launch_force_model<PASS, kModelDefault>(P, list);
+            else launch_force_model<PASS, kModelDefaultCut>(P, list);
+        }
         else      launch_force_model<PASS, kModelGeneric>(P, list);
     }
 

@@ -82,6 +82,9 @@ enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 enum { kViscZero = 0, kViscArtificial = 1, kViscLaminar = 2, kViscLaminarSPS = 3 };
 enum { kDdtNone = 0, kDdtZeroGravityLinear = 1, kDdtLinear = 2, kDdtComplex = 3 };
 constexpr int kModelDefault = kViscArtificial | (kDdtLinear << 4), kModelGeneric = -1;
+// bit 8 of a compiled-in model tag: the kernel is cut off BEFORE it vanishes (H = k·h with k < 2 — example/DucklingMDBC.jl: 1.5), so the
+// r² ≤ H² test of src/SPHCellList.jl:275 is applied per pair.  Round 4: DucklingMDBC ran the run-time variant for this flag alone.
+constexpr int kModelCutBit = 256, kModelDefaultCut = kModelDefault | kModelCutBit;
 
 // Device-side step control (Engine::advance): everything the while loop of src/SPHCellList.jl:742-802 decides per
 // step lives here, so the host can queue several steps without a round trip and look at the flags afterwards.
@@ -535,7 +538,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         // H = k·h with k < 2 (example/DucklingMDBC.jl: 1.5, MovingSquare2d.jl: √2) cuts the kernel off before it
         // vanishes: there the cut of :275 has to be applied for real (run-time variant of the kernel only)
-        if (MODEL < 0 && P.exact_cut) fac = (r2 <= P.H2) ? fac : T(0);
+        if ((MODEL < 0 && P.exact_cut) || (MODEL >= 0 && (MODEL & kModelCutBit) != 0)) fac = (r2 <= P.H2) ? fac : T(0);
         const T dvx = q1.x - n1.x, dvy = q1.y - n1.y, dvz = (D == 3) ? q1.z - n1.z : T(0);
         const T vdx = (D == 3) ? dvx * dx + dvy * dy + dvz * dz : dvx * dx + dvy * dy;          // vᵢⱼ·xᵢⱼ
         const T inv_rho_b = fast_rcp(rho_b);

@@ -725,13 +725,18 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
     if (M.list) { have = wid < M.n_list; i = have ? M.list[wid] : 0; }
     else { have = wid < M.N; i = have ? wid : 0; if (have && M.ghost[i].w == T(0)) have = false; }
     if (M.ctl_in != nullptr) {
-        // (a wave without a ghost node has nothing to decide for — except the one that stores the decisions)
-        if (!have && !(blockIdx.x == 0 && threadIdx.x < 64)) return;
-        StepCtrl c = *M.ctl_in;
-        const unsigned long long r0 = M.red_in[0], r1 = M.red_in[1], r2 = M.red_in[2], r3 = M.red_in[3];
-        (void)step_control_decide<T>(r0, r1, r2, r3, c, M.ctl_h, M.ctl_c0, M.ctl_CFL);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *M.ctl_out = c;
-        if (!c.active) return;
+        // the decisions of the step, taken by the first wave of every block for its four (round 3: by every wave for itself — ≈100 fp64
+        // instructions per ghost node, which is why handles above 32 768 particles kept the one-thread launch); block 0 stores them
+        __shared__ int s_active;
+        if (threadIdx.x < 64) {
+            StepCtrl c = *M.ctl_in;
+            const unsigned long long r0 = M.red_in[0], r1 = M.red_in[1], r2 = M.red_in[2], r3 = M.red_in[3];
+            (void)step_control_decide<T>(r0, r1, r2, r3, c, M.ctl_h, M.ctl_c0, M.ctl_CFL);
+            if (blockIdx.x == 0 && threadIdx.x == 0) *M.ctl_out = c;
+            if (threadIdx.x == 0) s_active = c.active;
+        }
+        __syncthreads();
+        if (!s_active) return;
     } else if (M.ctrl && !M.ctrl->active) return;
     if (!have) return;
     const auto gq = M.ghost[i];
