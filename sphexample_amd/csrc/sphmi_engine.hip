@@ -884,6 +884,8 @@ struct Engine final : EngineBase {
 
     // take_control: the kernel takes the decisions of the step itself (MdbcParams::ctl_in): reads control block `cpar` and slot set
     // `rpar`, writes block cpar ^ 1; its flag goes to the set the coming corrector fills.  The caller flips both indices afterwards.
+    static constexpr int kMdbcGroupFrom = 4096;
+    const int mdbc_group_env = getenv("SPHMI_MDBC_GROUP") ? atoi(getenv("SPHMI_MDBC_GROUP")) : -1;
     bool mdbc_list_ready() {
         if (cfg.mdbc != SPHMI_MDBC_SIMPLE || dd_slab || mdbc_n_list <= 0) return false;
         if (!mdbc_list_d) HC(hipMalloc(&mdbc_list_d, (size_t)mdbc_n_list * 4));
@@ -905,9 +907,18 @@ struct Engine final : EngineBase {
         M.gfac = cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h);
         const bool listed = mdbc_list_valid && !dd_slab;
         if (listed) { M.list = mdbc_list_d; M.n_list = mdbc_n_list; }
-        dim3 g(((listed ? mdbc_n_list : N) + 3) / 4), b(256);       // one wave per ghost node (per particle without the list), four per block
-        if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
-        else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
+        // sixteen lanes per node from kMdbcGroupFrom nodes on (enough waves to fill the chip four nodes at a time; below, the launch is
+        // latency-bound and the shorter wave of the one-node kernel wins); SPHMI_MDBC_GROUP=0 / 1 forces either
+        const bool grouped = listed && (mdbc_group_env >= 0 ? mdbc_group_env != 0 : mdbc_n_list >= kMdbcGroupFrom);
+        if (grouped) {
+            dim3 g((mdbc_n_list + 15) / 16), b(256);
+            if (D == 3) hipLaunchKernelGGL((k_mdbc_group<T, 3>), g, b, 0, stream, M);
+            else        hipLaunchKernelGGL((k_mdbc_group<T, 2>), g, b, 0, stream, M);
+        } else {
+            dim3 g(((listed ? mdbc_n_list : N) + 3) / 4), b(256);       // one wave per ghost node (per particle without the list), four per block
+            if (D == 3) hipLaunchKernelGGL((k_mdbc<T, 3>), g, b, 0, stream, M);
+            else        hipLaunchKernelGGL((k_mdbc<T, 2>), g, b, 0, stream, M);
+        }
         HC(hipGetLastError());
         end_phase(ev);
     }

@@ -692,6 +692,150 @@ template <class T> __device__ __forceinline__ T det3(T a00, T a01, T a02, T a10,
     return a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
 }
 
+// One parked record against ghost node g: the exact test of src/SPHCellList.jl:336 and the moments of :337-359 (fp64 in both builds)
+template <class T, int D>
+__device__ __forceinline__ void mdbc_moments(const MdbcParams<T>& M, const double (&g)[3], const typename Vec4<T>::type n0,
+                                             double (&b)[D + 1], double (&A)[D + 1][D + 1]) {
+    constexpr int P = D + 1;
+    using R = double;
+    const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
+    const R r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
+    if (!(r2 <= M.H2)) return;                                       // the exact test (src/SPHCellList.jl:336)
+    // |xᵢⱼ| from the fp32 reciprocal square root + two Newton steps in fp64 (≈2⁻²⁴ → 2⁻⁴⁸ → below an ulp; the library's
+    // correctly rounded sqrt is ≈25 instructions of a kernel that is bound by their number)
+    R rr;
+    {
+        R y = (R)__builtin_amdgcn_rsqf((float)r2);
+        y = y * (R(1.5) - R(0.5) * r2 * y * y);
+        y = y * (R(1.5) - R(0.5) * r2 * y * y);
+        rr = r2 > R(1e-30) ? r2 * y : sqrt(r2);                     // (the float conversion underflows below 1e-38)
+    }
+    R q = rr * M.h_inv;
+    q = q > R(2) ? R(2) : q;
+    const R tq = q - R(2);
+    R Wij, fac;
+    if (M.kernel == 1) {                                         // CubicSpline, src/SPHKernels.jl:89-106
+        Wij = q <= R(1) ? M.alphaD * (R(1) - R(1.5) * q * q + R(0.75) * q * q * q) : M.alphaD * R(0.25) * (-(tq * tq * tq));
+        const R dWdq = q <= R(1) ? M.alphaD * (R(-3) * q + R(2.25) * q * q) : M.alphaD * R(-0.75) * (tq * tq);
+        fac = dWdq * M.h_inv / (rr + M.eta2);
+    } else {
+        const R t1 = R(1) - q * R(0.5);
+        const R t2 = t1 * t1;
+        Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));          // src/SPHKernels.jl:75-78
+        fac = M.gfac * (tq * tq * tq);                           // αD·5/(8h²)·(q − 2)³, :85-86
+    }
+    const R Vj = M.m0 * fast_rcp((R)n0.w);
+    R fc[P];
+    fc[0] = Vj * Wij;
+    b[0] += M.m0 * Wij;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const R gw = fac * xij[d];
+        fc[d + 1] = Vj * gw;
+        b[d + 1] += M.m0 * gw;
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        A[r][0] += fc[r];
+#pragma unroll
+        for (int k = 0; k < D; ++k) A[r][k + 1] += (-xij[k]) * fc[r];
+    }
+}
+
+// ApplyMDBCCorrection (src/SPHCellList.jl:598-622) for particle i from the summed moments: one lane
+template <class T, int D>
+__device__ __forceinline__ void mdbc_apply(const MdbcParams<T>& M, const int i, const double (&g)[3], double (&b)[D + 1], double (&A)[D + 1][D + 1]) {
+    constexpr int P = D + 1;
+    using R = double;
+    R det;
+    if constexpr (P == 3) {
+        det = det3<R>(A[0][0], A[0][1], A[0][2], A[1][0], A[1][1], A[1][2], A[2][0], A[2][1], A[2][2]);
+    } else {
+        det = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            R m[3][3];
+            int cc = 0;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                if (c2 == c) continue;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) m[r - 1][cc] = A[r][c2];
+                cc++;
+            }
+            const R d3 = det3<R>(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
+            det += ((c & 1) ? R(-1) : R(1)) * A[0][c] * d3;
+        }
+    }
+    auto me = M.pk0[i];
+    R newrho = fabs((R)me.w);
+    bool write = false;
+    if (fabs(det) >= R(1e-3)) {
+        // Gaussian elimination with partial pivoting on [A | b] (same order as the oracle)
+        R Mx[P][P + 1], ipiv[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+#pragma unroll
+            for (int c = 0; c < P; ++c) Mx[r][c] = A[r][c];
+            Mx[r][P] = b[r];
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            int p = k;
+            R best = fabs(Mx[k][k]);
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) if (fabs(Mx[r][k]) > best) { best = fabs(Mx[r][k]); p = r; }
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) {
+                if (r == p) {
+#pragma unroll
+                    for (int c = 0; c <= P; ++c) { R t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
+                }
+            }
+            // (one reciprocal per pivot instead of a division per row — ten IEEE divisions of ≈15 instructions each on the one lane
+            // the wave waits for; 1/pivot to 2⁻⁵², the system is solved to its conditioning either way)
+            ipiv[k] = fast_rcp(Mx[k][k]);
+#pragma unroll
+            for (int r = k + 1; r < P; ++r) {
+                const R f = Mx[r][k] * ipiv[k];
+#pragma unroll
+                for (int c = k; c <= P; ++c) Mx[r][c] -= f * Mx[k][c];
+            }
+        }
+        R s[P];
+#pragma unroll
+        for (int r = P - 1; r >= 0; --r) {
+            R acc = Mx[r][P];
+#pragma unroll
+            for (int c = r + 1; c < P; ++c) acc -= Mx[r][c] * s[c];
+            s[r] = acc * ipiv[r];
+        }
+        const R xi[3] = {(R)me.x, (R)me.y, (R)me.z};
+        R v1 = s[0];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v1 += s[d + 1] * (xi[d] - g[d]);
+        newrho = (v1 != v1) ? (R)M.rho0 : v1;
+        write = true;
+    } else if (A[0][0] > R(0)) {
+        const R v = b[0] / A[0][0];
+        newrho = (v != v) ? (R)M.rho0 : v;
+        write = true;
+    }
+    if (write) {
+        // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive.  A ghost copy far out in a wide halo
+        // sums over a truncated neighbourhood: whatever that gives is never read, must not flip the flag and is
+        // no error (the owner of the particle judges the real value)
+        if (!(newrho > R(0))) {
+            if (M.type[i] & kGhostMask) return;
+            atomicOr(&M.red[3], 1ull);
+        }
+        const T hi = (T)newrho;
+        me.w = me.w > T(0) ? hi : -hi;
+        M.pk0[i] = me;
+        if (sizeof(T) == 4 && M.comp) M.comp[i].w = (T)(newrho - (R)hi);
+    }
+}
+
 // All arithmetic of the moment matrix and its solve is fp64 in BOTH builds: the (D+1)×(D+1) systems of thin
 // boundary layers are ill-conditioned, and fp32 accumulation flipped the |det| ≥ 1e-3 branch for a handful
 // of particles of example/Dambreak2dMDBC.jl (density off by 3e-3); the kernel is a negligible part of a step.
@@ -785,7 +929,7 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
         for (int c = 0; c < P; ++c) A[r][c] = 0; }
     V4* const stash = reinterpret_cast<V4*>(s_lds[wv]);
     const T H2t = sizeof(T) == 4 ? (T)(M.H2 * (1.0 + 1e-5)) : (T)M.H2;       // fp32: a superset of what the fp64 test accepts
-    int job0 = 0;
+    int job0 = 0, parked = 0;
     do {
         // phase 1: U chunk loads in flight, test, park — until the rows are through or the stash could not take another group
         int npend = 0;
@@ -811,55 +955,17 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
         }
         // phase 2 on the parked records
         const int n = npend;
+        parked += n;
         wave_sync();
         for (int k0 = 0; k0 < n; k0 += 64) {
             if (k0 + lane >= n) continue;
             const V4 n0 = stash[k0 + lane];
-            const R xij[3] = {g[0] - (R)n0.x, g[1] - (R)n0.y, D == 3 ? g[2] - (R)n0.z : R(0)};
-            const R r2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
-            if (!(r2 <= M.H2)) continue;                                     // the exact test (src/SPHCellList.jl:336)
-            // |xᵢⱼ| from the fp32 reciprocal square root + two Newton steps in fp64 (≈2⁻²⁴ → 2⁻⁴⁸ → below an ulp; the library's
-            // correctly rounded sqrt is ≈25 instructions of a kernel that is bound by their number)
-            R rr;
-            {
-                R y = (R)__builtin_amdgcn_rsqf((float)r2);
-                y = y * (R(1.5) - R(0.5) * r2 * y * y);
-                y = y * (R(1.5) - R(0.5) * r2 * y * y);
-                rr = r2 > R(1e-30) ? r2 * y : sqrt(r2);                     // (the float conversion underflows below 1e-38)
-            }
-            R q = rr * M.h_inv;
-            q = q > R(2) ? R(2) : q;
-            const R tq = q - R(2);
-            R Wij, fac;
-            if (M.kernel == 1) {                                         // CubicSpline, src/SPHKernels.jl:89-106
-                Wij = q <= R(1) ? M.alphaD * (R(1) - R(1.5) * q * q + R(0.75) * q * q * q) : M.alphaD * R(0.25) * (-(tq * tq * tq));
-                const R dWdq = q <= R(1) ? M.alphaD * (R(-3) * q + R(2.25) * q * q) : M.alphaD * R(-0.75) * (tq * tq);
-                fac = dWdq * M.h_inv / (rr + M.eta2);
-            } else {
-                const R t1 = R(1) - q * R(0.5);
-                const R t2 = t1 * t1;
-                Wij = M.alphaD * (t2 * t2) * (R(2) * q + R(1));          // src/SPHKernels.jl:75-78
-                fac = M.gfac * (tq * tq * tq);                           // αD·5/(8h²)·(q − 2)³, :85-86
-            }
-            const R Vj = M.m0 * fast_rcp((R)n0.w);
-            R fc[P];
-            fc[0] = Vj * Wij;
-            b[0] += M.m0 * Wij;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const R gw = fac * xij[d];
-                fc[d + 1] = Vj * gw;
-                b[d + 1] += M.m0 * gw;
-            }
-#pragma unroll
-            for (int r = 0; r < P; ++r) {
-                A[r][0] += fc[r];
-#pragma unroll
-                for (int k = 0; k < D; ++k) A[r][k + 1] += (-xij[k]) * fc[r];
-            }
+            mdbc_moments<T, D>(M, g, n0, b, A);
         }
         wave_sync();
     } while (job0 < njobs);
+    // no Fluid record near the node (a dry wall: a third of DucklingMDBC's nodes): all moments are zero, the particle stays as it is (:618-621)
+    if (parked == 0) return;
     // the 64 partial sums of every moment, added in a fixed order: upper half onto lower half, then lane v adds row v
     {
         double (*red)[33] = reinterpret_cast<double (*)[33]>(s_lds[wv]);
@@ -891,94 +997,166 @@ __global__ void __launch_bounds__(256) k_mdbc(const MdbcParams<T> M) {
             for (int c = 0; c < P; ++c) A[r][c] = red[P + r * P + c][32];
         }
     }
-    // ApplyMDBCCorrection, src/SPHCellList.jl:598-622
-    R det;
-    if constexpr (P == 3) {
-        det = det3<R>(A[0][0], A[0][1], A[0][2], A[1][0], A[1][1], A[1][2], A[2][0], A[2][1], A[2][2]);
-    } else {
-        det = 0;
+    mdbc_apply<T, D>(M, i, g, b, A);
+}
+
+template <int CTRL> __device__ __forceinline__ double dpp_f64(const double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// the sum over the 16 lanes of a DPP row, in every lane of the row, bit-identical in all of them (each step adds the same two
+// values in both lanes of a pair): lane ^ 1, lane ^ 2, then the mirror images inside 8 and inside 16 lanes
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_f64<0xB1>(x);        // quad_perm [1, 0, 3, 2]
+    x += dpp_f64<0x4E>(x);        // quad_perm [2, 3, 0, 1]
+    x += dpp_f64<0x141>(x);       // row_half_mirror
+    x += dpp_f64<0x140>(x);       // row_mirror
+    return x;
+}
+
+// SIXTEEN LANES per ghost node, four nodes per wave — the launch for handles with thousands of nodes and sparse neighbourhoods
+// (DucklingMDBC: 226 candidate records and 9 accepted ones per node, a third of the nodes next to no Fluid at all).  With one
+// wave per node the candidate rows of such a case fill 25 of the 64 lanes of a chunk, and the per-wave fixed costs — the row
+// look-ups, the reduction of the (D+1)² + (D+1) moments, the solve on one lane — are paid 21 408 times.  Here they are paid once per
+// four nodes: a node's rows go through in chunks of 16, the records that pass are parked per group, every lane of a group takes one
+// parked record per round, the 16 partial sums of a moment are added inside the DPP row, and lane 0 of each group solves.  Same
+// arithmetic per record as k_mdbc (mdbc_moments / mdbc_apply); only the order of the sums differs.  Needs the node list.
+// Registers: 128 (four waves per SIMD; the 20 fp64 sums of a 3-D node are 40 of them).  Builds held to 96 / 80 registers spill 136 / 216
+// bytes and run DucklingMDBC's launch in 32 / 66 µs against 27 (184 registers, two waves per SIMD: 29).
+template <class T, int D>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_mdbc_group(const MdbcParams<T> M) {
+    constexpr int P = D + 1;
+    constexpr int G = 16, NG = 4;
+    constexpr int NROW = D == 3 ? 9 : 3;
+    constexpr int U = sizeof(T) == 4 ? 4 : 2;
+    constexpr int kStashG = G * U + (sizeof(T) == 4 ? 32 : 16);      // records a group can park (24 KB per block either way)
+    using R = double;
+    using V4 = typename Vec4<T>::type;
+    __shared__ __attribute__((aligned(16))) V4 s_stash[4][NG][kStashG];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int slot = wid * NG + grp;
+    const bool have = slot < M.n_list;
+    int i = have ? M.list[slot] : 0;
+    if (M.ctl_in != nullptr) {
+        __shared__ int s_active;
+        if (threadIdx.x < 64) {
+            StepCtrl c = *M.ctl_in;
+            const unsigned long long r0 = M.red_in[0], r1 = M.red_in[1], r2 = M.red_in[2], r3 = M.red_in[3];
+            (void)step_control_decide<T>(r0, r1, r2, r3, c, M.ctl_h, M.ctl_c0, M.ctl_CFL);
+            if (blockIdx.x == 0 && threadIdx.x == 0) *M.ctl_out = c;
+            if (threadIdx.x == 0) s_active = c.active;
+        }
+        __syncthreads();
+        if (!s_active) return;
+    } else if (M.ctrl && !M.ctrl->active) return;
+    if (__builtin_amdgcn_ballot_w64(have) == 0) return;
+    const auto gq = M.ghost[i];
+    const T gT[3] = {gq.x, gq.y, gq.z};
+    int gc[3];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            R m[3][3];
-            int cc = 0;
-#pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) {
-                if (c2 == c) continue;
-#pragma unroll
-                for (int r = 1; r < 4; ++r) m[r - 1][cc] = A[r][c2];
-                cc++;
-            }
-            const R d3 = det3<R>(m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2], m[2][0], m[2][1], m[2][2]);
-            det += ((c & 1) ? R(-1) : R(1)) * A[0][c] * d3;
+    for (int d = 0; d < 3; ++d) gc[d] = d < D ? map_floor<T>(gT[d], M.H_inv) - M.g.gmin[d] + 1 : 0;
+    int rs = 0, rc = 0;
+    if (have && sub < NROW) {
+        const int sy = sub % 3, sz = sub / 3;
+        const int cy = gc[1] + sy - 1, cz = D == 3 ? gc[2] + sz - 1 : 0;
+        int x0 = gc[0] - 1, x1 = gc[0] + 1;
+        if (x0 < 0) x0 = 0;
+        if (x1 > M.g.np[0] - 1) x1 = M.g.np[0] - 1;
+        if (cy >= 0 && cy < M.g.np[1] && cz >= 0 && cz < M.g.np[2] && x0 <= x1) {
+            const int row = M.g.np[0] * (cy + M.g.np[1] * cz);
+            rs = M.cstart[row + x0];
+            rc = M.cstart[row + x1 + 1] - rs;
         }
     }
-    auto me = M.pk0[i];
-    R newrho = fabs((R)me.w);
-    bool write = false;
-    if (fabs(det) >= R(1e-3)) {
-        // Gaussian elimination with partial pivoting on [A | b] (same order as the oracle)
-        R Mx[P][P + 1], ipiv[P];
+    // the chunks ("jobs") of a node's rows, numbered through per group; lane `sub` of a group describes job jbase + sub of its node
+    const int jrow = (rc + G - 1) / G;
+    int jincl = jrow;
 #pragma unroll
-        for (int r = 0; r < P; ++r) {
+    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(jincl, o, G); if (sub >= o) jincl += u; }
+    const int njobs = __shfl(jincl, NROW - 1, G);
+    const int jexcl = jincl - jrow;
+    int job_first = 0, job_left = 0;
+    auto describe_jobs = [&](const int jbase) __attribute__((always_inline)) {
+        const int jb = jbase + sub;
+        job_first = 0; job_left = 0;
 #pragma unroll
-            for (int c = 0; c < P; ++c) Mx[r][c] = A[r][c];
-            Mx[r][P] = b[r];
+        for (int r = 0; r < NROW; ++r) {
+            const int e = __shfl(jexcl, r, G), st = __shfl(rs, r, G), cn = __shfl(rc, r, G);
+            const int o = (jb - e) * G;
+            if (jb >= e && o < cn) { job_first = st + o; job_left = cn - o; }
         }
+    };
+    R b[P], A[P][P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            int p = k;
-            R best = fabs(Mx[k][k]);
+    for (int r = 0; r < P; ++r) { b[r] = 0;
 #pragma unroll
-            for (int r = k + 1; r < P; ++r) if (fabs(Mx[r][k]) > best) { best = fabs(Mx[r][k]); p = r; }
+        for (int c = 0; c < P; ++c) A[r][c] = 0; }
+    V4* const stash = s_stash[wv][grp];
+    const T H2t = sizeof(T) == 4 ? (T)(M.H2 * (1.0 + 1e-5)) : (T)M.H2;
+    const unsigned below = (1u << sub) - 1u;
+    int job0 = 0, parked = 0;
+    int npend = 0;
+    do {
+        while (__builtin_amdgcn_ballot_w64(job0 < njobs) != 0 && __builtin_amdgcn_ballot_w64(npend > kStashG - G * U) == 0) {
+            if ((job0 & (G - 1)) == 0) describe_jobs(job0);
+            V4 v[U];
+            bool ok[U];
 #pragma unroll
-            for (int r = k + 1; r < P; ++r) {
-                if (r == p) {
-#pragma unroll
-                    for (int c = 0; c <= P; ++c) { R t = Mx[k][c]; Mx[k][c] = Mx[r][c]; Mx[r][c] = t; }
-                }
+            for (int u = 0; u < U; ++u) {
+                const int jl = (job0 & (G - 1)) + u;
+                const int first = __shfl(job_first, jl, G), left = __shfl(job_left, jl, G);
+                ok[u] = sub < left;
+                v[u] = M.pk0[ok[u] ? first + sub : 0];
             }
-            // (one reciprocal per pivot instead of a division per row — ten IEEE divisions of ≈15 instructions each on the one lane
-            // the wave waits for; 1/pivot to 2⁻⁵², the system is solved to its conditioning either way)
-            ipiv[k] = fast_rcp(Mx[k][k]);
 #pragma unroll
-            for (int r = k + 1; r < P; ++r) {
-                const R f = Mx[r][k] * ipiv[k];
-#pragma unroll
-                for (int c = k; c <= P; ++c) Mx[r][c] -= f * Mx[k][c];
+            for (int u = 0; u < U; ++u) {
+                const T dx = gT[0] - v[u].x, dy = gT[1] - v[u].y, dz = D == 3 ? gT[2] - v[u].z : T(0);
+                const bool pass = ok[u] && v[u].w > T(0) && (dx * dx + dy * dy + dz * dz) <= H2t;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+                const unsigned w = lane < 32 ? (unsigned)bal : (unsigned)(bal >> 32);
+                const unsigned gb = (w >> (lane & 16)) & 0xFFFFu;                 // the 16 verdicts of my group
+                if (pass) stash[npend + __builtin_popcount(gb & below)] = v[u];
+                npend += __builtin_popcount(gb);
+            }
+            job0 += U;
+        }
+        // phase 2 for the groups whose stash is full, for all of them once every row is through: which lane takes which record of a
+        // node — the order of its sums — then depends on that node's own rows only, not on the three nodes it shares the wave with
+        // (the list is appended by atomics: its order differs from run to run)
+        const bool last = __builtin_amdgcn_ballot_w64(job0 < njobs) == 0;
+        const int n = (last || npend > kStashG - G * U) ? npend : 0;
+        parked |= npend;
+        wave_sync();
+        for (int k0 = 0; __builtin_amdgcn_ballot_w64(k0 < n) != 0; k0 += G) {
+            if (k0 + sub < n) {
+                const V4 n0 = stash[k0 + sub];
+                const R g[3] = {(R)gT[0], (R)gT[1], (R)gT[2]};
+                mdbc_moments<T, D>(M, g, n0, b, A);
             }
         }
-        R s[P];
+        if (n != 0) npend = 0;
+        wave_sync();
+        if (last) break;
+    } while (true);
+    if (__builtin_amdgcn_ballot_w64(parked != 0) == 0) return;          // four dry nodes
 #pragma unroll
-        for (int r = P - 1; r >= 0; --r) {
-            R acc = Mx[r][P];
+    for (int r = 0; r < P; ++r) {
+        b[r] = row16_sum(b[r]);
 #pragma unroll
-            for (int c = r + 1; c < P; ++c) acc -= Mx[r][c] * s[c];
-            s[r] = acc * ipiv[r];
-        }
-        const R xi[3] = {(R)me.x, (R)me.y, (R)me.z};
-        R v1 = s[0];
-#pragma unroll
-        for (int d = 0; d < D; ++d) v1 += s[d + 1] * (xi[d] - g[d]);
-        newrho = (v1 != v1) ? (R)M.rho0 : v1;
-        write = true;
-    } else if (A[0][0] > R(0)) {
-        const R v = b[0] / A[0][0];
-        newrho = (v != v) ? (R)M.rho0 : v;
-        write = true;
+        for (int c = 0; c < P; ++c) A[r][c] = row16_sum(A[r][c]);
     }
-    if (write) {
-        // the sign of ρ carries the MotionLimiter flag, so ρ must stay positive.  A ghost copy far out in a wide halo
-        // sums over a truncated neighbourhood: whatever that gives is never read, must not flip the flag and is
-        // no error (the owner of the particle judges the real value)
-        if (!(newrho > R(0))) {
-            if (M.type[i] & kGhostMask) return;
-            atomicOr(&M.red[3], 1ull);
-        }
-        const T hi = (T)newrho;
-        me.w = me.w > T(0) ? hi : -hi;
-        M.pk0[i] = me;
-        if (sizeof(T) == 4 && M.comp) M.comp[i].w = (T)(newrho - (R)hi);
-    }
+    // (slot and node index are worked out again from the lane number the hardware counts, behind an asm — a value the compiler cannot merge with the
+    // ones above and therefore does not keep, or spill, through the loops: the kernel has not one register to spare)
+    int lane_now;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
+    const int slot_now = wid * NG + (lane_now >> 4);
+    if ((lane_now & 15) != 0 || slot_now >= M.n_list || parked == 0) return;
+    i = M.list[slot_now];
+    const R g[3] = {(R)gT[0], (R)gT[1], (R)gT[2]};
+    mdbc_apply<T, D>(M, i, g, b, A);
 }
 
 // Output side: the SimParticles fields in the HOST's layout and float type, packed on the device

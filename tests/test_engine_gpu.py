@@ -351,6 +351,36 @@ def test_mdbc_examples(case, steps, request):
     assert relmax(e["Position"], o["Position"]) < 1e-9
 
 
+@pytest.mark.parametrize("case,steps", [("dam_break_2d_mdbc", 150), ("duckling", 40)])
+@pytest.mark.parametrize("fb", [8, 4])
+def test_mdbc_sixteen_lanes_per_node(case, steps, fb, request, monkeypatch):
+    """k_mdbc_group (sixteen lanes per ghost node, four nodes per wave: the launch of handles with ≥ 4 096 nodes — DucklingMDBC) against
+    the oracle like the one-node-per-wave kernel (src/SPHCellList.jl:219-266,319-365,598-622).  A node's sums must not depend on the
+    nodes it shares a wave with — the node list is appended by atomics, its order differs from run to run: two runs, same bits.  The 2-D
+    case is forced onto the kernel and runs through rebuilds on the device and on the host."""
+    from sphexample_amd.engine import make_engine
+    p, s = request.getfixturevalue(case)
+    q = perturbed(p, seed=11, vel_scale=0.05)
+    monkeypatch.setenv("SPHMI_MDBC_GROUP", "1")
+    out = []
+    for _ in range(2):
+        eng = make_engine(q, s, device_float_bytes=fb)
+        eng.advance(1e9, max_steps=steps // 2)
+        pr = eng.advance(1e9, max_steps=steps - steps // 2)           # (a second call: its opening rebuild refills the list)
+        out.append((pr, by_id(eng.download())))
+    (p1, e1), (p0, e0) = out
+    assert p1.n_rebuilds == p0.n_rebuilds and p1.total_time == p0.total_time
+    for k in ("Density", "Position", "Velocity"):
+        assert np.array_equal(e1[k], e0[k]), k
+    if fb == 8:
+        from oracle.oracle import make_oracle
+        orc = make_oracle(q, s)
+        orc.advance(1e9, max_steps=steps // 2); po = orc.advance(1e9, max_steps=steps - steps // 2)
+        o = by_id(orc.download())
+        assert p1.n_rebuilds == po.n_rebuilds and p1.total_time == pytest.approx(po.total_time, rel=1e-10)
+        assert relmax(e1["Density"], o["Density"]) < 1e-9 and relmax(e1["Position"], o["Position"]) < 1e-9
+
+
 @pytest.mark.parametrize("visc,ddt", [("Laminar", "LinearDensityDiffusion"), ("LaminarSPS", "LinearDensityDiffusion"),
                                       ("ArtificialViscosity", "ZeroGravityLinearDensityDiffusion"),
                                       ("ArtificialViscosity", "ComplexDensityDiffusion"),

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect SQ / TA / TCP / TCC counter passes for the neighbour kernel (each pass its own run; no tracing options — gpurun refuses
 # --pmc together with trace domains).  The library measured is $SPHMI_LIB (default: the in-tree build).
-# usage: tools/pmc_passes.sh <outdir under gpurun_out/> [bench args]     (PMC_CMD='python … ' replaces the bench command)
+# usage: tools/pmc_passes.sh <outdir under gpurun_out/> [bench args]     (PMC_CMD='python … ' replaces the bench command, PMC_FILTER the
+# kernel name the SQ / TA passes are summarised for, PMC_MAX=n stops after the first n passes)
 set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +14,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
+  [ $i -gt ${PMC_MAX:-99} ] && break
   timeout 300 rocprofv3 --pmc $line -d $R/gpurun_out/$out/p$i -o p -- ${PMC_CMD:-python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --precondition-ms 0 "$@"} > $R/gpurun_out/$out/p$i.log 2>&1
   db=$(find $R/gpurun_out/$out/p$i -name '*.db' | head -1)
   echo "### pass $i: $line"
