@@ -405,12 +405,15 @@ struct Engine final : EngineBase {
     // ---- timing helpers ---------------------------------------------------------------------
     // An event pair costs several µs of stream bubbles (27 µs per step on the 7 k-particle 2-D case whose
     // passes last 20 µs; 28 µs = 2 % per step at 1 M particles), so the phases are timed on one step in
-    // kEvSample and the sample is weighted accordingly; rebuilds are always timed.
+    // ev_period and the sample is weighted accordingly; rebuilds are always timed.  The period follows the step: a timed step carries
+    // ≈30 µs of bubbles (a ≈10 µs gap before and after every timed launch, profiles/r04_raw/window_curve.txt) — one in 8 is 0.4 % of a
+    // 0.97 ms step but was 13 % of the 28 µs steps of the reference's 2-D examples: one in 32 below 400 µs per step, one in 64 below 100.
     static constexpr int kEvSample = 8;
+    int ev_period = kEvSample;
     Ev begin_phase(int phase) {
         Ev e{};
         e.phase = phase; e.bstep = batch_step;
-        e.weight = (phase == PH_REBUILD || phase == PH_REBUILD_DEVICE || iteration < ev_always_until) ? 1 : ((iteration % kEvSample) == 0 ? kEvSample : 0);
+        e.weight = (phase == PH_REBUILD || phase == PH_REBUILD_DEVICE || iteration < ev_always_until) ? 1 : ((iteration % ev_period) == 0 ? ev_period : 0);
         if (e.weight == 0) return e;
         if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; e.bstep = batch_step; }
         else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
@@ -436,6 +439,10 @@ struct Engine final : EngineBase {
             ev_pool.push_back(e);
         }
         ev_pending.clear();
+        if (force_launches > 0) {
+            const double step_us = 2.0 * force_ms * 1e3 / (double)force_launches;
+            ev_period = step_us >= 400.0 ? kEvSample : (step_us >= 100.0 ? 4 * kEvSample : 8 * kEvSample);
+        }
     }
 
     static double decode(unsigned long long bits) {
