@@ -416,7 +416,11 @@ struct Engine final : EngineBase {
         e.weight = (phase == PH_REBUILD || phase == PH_REBUILD_DEVICE || iteration < ev_always_until) ? 1 : ((iteration % ev_period) == 0 ? ev_period : 0);
         if (e.weight == 0) return e;
         if (!ev_pool.empty()) { const int w = e.weight; e = ev_pool.back(); ev_pool.pop_back(); e.phase = phase; e.weight = w; e.bstep = batch_step; }
-        else { HC(hipEventCreate(&e.a)); HC(hipEventCreate(&e.b)); }
+        else {
+            // timing only: no system-scope fence when the event completes (the default writes back and invalidates the caches — a ≈10 µs
+            // gap after every timed launch, and a cold L2 for the launch behind it); the values are read after a stream synchronisation
+            HC(hipEventCreateWithFlags(&e.a, hipEventDisableSystemFence)); HC(hipEventCreateWithFlags(&e.b, hipEventDisableSystemFence));
+        }
         HC(hipEventRecord(e.a, stream));
         return e;
     }
