@@ -303,6 +303,7 @@ struct Engine final : EngineBase {
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) force_wpt = v; }
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
+        xcd_trace = getenv("SPHMI_XCD_TRACE") != nullptr;          // one line per sampled launch on stderr: finishing time of each XCD ÷ mean, shares
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
         if (const char* w = getenv("SPHMI_RESCHED")) resched = atoi(w);
         if (const char* w = getenv("SPHMI_TPB2")) tpb2 = atoi(w);
@@ -620,6 +621,13 @@ struct Engine final : EngineBase {
         const unsigned long long t0 = xcd_clock_h[8];
         double Tx[8], mean = 0; bool ok = t0 != ~0ull;
         for (int x = 0; x < 8 && ok; ++x) { ok = xcd_clock_h[x] > t0; Tx[x] = ok ? (double)(xcd_clock_h[x] - t0) : 0.0; mean += Tx[x] / 8; }
+        if (ok && xcd_trace) {
+            fprintf(stderr, "[sphmi xcd] it %lld tiles %d  T/mean:", (long long)iteration, list_tiles[0]);
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f", Tx[x] / mean);
+            fprintf(stderr, "  shares:");
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.4f", xcd_w[x]);
+            fprintf(stderr, "  mean %.1f us\n", mean * 0.01);
+        }
         if (ok && xcd_feedback) {
             double sum = 0;
             for (int x = 0; x < 8; ++x) { xcd_w[x] *= std::sqrt(mean / Tx[x]); xcd_w[x] = std::min(0.15, std::max(0.10, xcd_w[x])); sum += xcd_w[x]; }
@@ -629,6 +637,7 @@ struct Engine final : EngineBase {
             if (work_valid && resched && !dd_slab) resched0_pending = true;
         }
     }
+    bool xcd_trace = false;
     bool work_valid = false;           // tile_work_d holds the measured work of the tiles in their PRESENT order
 
     // ---- UpdateNeighbors! -------------------------------------------------------------------
