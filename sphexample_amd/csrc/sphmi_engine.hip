@@ -272,6 +272,14 @@ struct Engine final : EngineBase {
         return ntile < tiny ? 8 : (ntile < small ? 4 : (ntile < medium ? 2 : 1));
     }
     int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
+    // Split mode of the eight-wave kernels (ForceParams::split): pays when a tile has enough pairs to share out, costs one workgroup
+    // barrier and a walk over the tile's masks.  Decided ONCE per upload, at the first host-side rebuild, from the candidates a target
+    // sees — 3^D cells × particles per occupied cell: 115 on the 2-D dam break and StillWedge layouts, 510 on Dambreak3d Dp0.02, 35 on
+    // Dambreak2dMDBC (whose script pairs dx = 0.01 with the Dp0.02 layout: four particles per cell) — sticky, so that the summation
+    // order of a handle does not depend on when a count reaches the host.  $SPHMI_SPLIT = 0 / 1 forces it.
+    static constexpr int kSplitFromCandidates = 64;
+    int split_mode = -1;
+    const int split_env = getenv("SPHMI_SPLIT") ? atoi(getenv("SPHMI_SPLIT")) : -1;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -475,6 +483,7 @@ struct Engine final : EngineBase {
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_cur(); P.stats = red_d + 8; P.ctrl = nullptr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
+        P.split = split_env >= 0 ? (split_env != 0) : (split_mode > 0);
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
         P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
@@ -773,6 +782,11 @@ struct Engine final : EngineBase {
                 if (l < nlist) for (int x = 0; x < 8; ++x) { part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]); list_tiles[l] += part_h[16 * l + 8 + x]; }
             }
             part_seen = part_max[0];
+        }
+        if (split_mode < 0) {
+            // (misc_h[0] = occupied cells, copied above and synchronised with the run table)
+            const int64_t cells = std::max<int64_t>(misc_h[0], 1);
+            split_mode = (int64_t)N * (D == 3 ? 27 : 9) >= (int64_t)kSplitFromCandidates * cells ? 1 : 0;
         }
         have_grid = true;
         n_rebuilds += 1;
@@ -1178,7 +1192,7 @@ struct Engine final : EngineBase {
                            (T)cfg.h, (T)cfg.eta2, red_d);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream));
-        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0; split_mode = -1;
     }
 
     // ---- the bench lattice generated on the device (no host arrays, no upload) ---------------------
@@ -1236,7 +1250,7 @@ struct Engine final : EngineBase {
             HC(hipStreamSynchronize(stream));
         } catch (...) { release(); throw; }
         release();
-        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0; split_mode = -1;
     }
 
     template <class H> static void unpack3(const std::vector<V4>& s, H* out, int N, int D) {

@@ -52,17 +52,6 @@ template <class V> struct Half {
 };
 
 constexpr int kWave = 64;
-// Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles (DESIGN.md §4.4)
-// and the loop counters of the kernel agree: with 8 entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the
-// pair-loop iterations (the bound set by the lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.
-// LDS pays for the depth — 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32):
-// 8 → 1.013e9 / –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
-// 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
-// The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
-// Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues.
-template <class T, int WPT = 1> constexpr int queue_entries() { return WPT >= 8 ? 6 : (sizeof(T) == 8 ? 16 : 12); }
-constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
-
 // Build switches that remain.  Everything else that rounds 2 and 3 measured and left off (role bits in the queue entries, half
 // prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the f16 distance matrix, the predictor's masks handed to the
 // corrector, the sign bits on the matrix pipe) lives as patches under profiles/ (r03_raw/mask_mfma_experiment.patch,
@@ -76,6 +65,21 @@ constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE −
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
                                 // neither / adjacent lanes sharing a gathered record
 #endif
+
+// Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles (DESIGN.md §4.4)
+// and the loop counters of the kernel agree: with 8 entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the
+// pair-loop iterations (the bound set by the lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.
+// LDS pays for the depth — 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32):
+// 8 → 1.013e9 / –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
+// 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
+// The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
+// Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues — eight, because
+// in split mode (ForceParams::split) a wave queues its share of EVERY chunk of the tile and drains in bursts like the large kernels.
+// (not the fp64 kernel of the run-time models: its three sets of partial sums take 43 KB, and two workgroups per compute unit — handles of
+// 256 to 400 tiles — matter more than the split)
+template <class T, int WPT, int MODEL> constexpr bool split_capable() { return WPT >= 8 && SPHMI_LDS_STAGE == 0 && !(sizeof(T) == 8 && MODEL < 0); }
+template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() { return WPT >= 8 ? (split_capable<T, WPT, MODEL>() ? 8 : 6) : (sizeof(T) == 8 ? 16 : 12); }
+constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 // model tags (values of include/sphmi.h)
@@ -212,6 +216,8 @@ struct ForceParams {
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
     double hyd_a, hyd_b; // ComplexDensityDiffusion: ρᴴ(z) = ρ₀·(⁷√(1 + hyd_a·z) − 1), hyd_a = ρ₀·g/Cb, hyd_b = ρ₀
+    int split;           // tiles of eight waves: 1 = every wave takes a share of EVERY chunk's accepted pairs (k_neighbor_force, "split mode"), 0 = a
+                         // wave keeps the pairs of the chunks it scanned.  Chosen by the engine once per upload (Engine::split_mode).
 };
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +396,7 @@ k_neighbor_force(const ForceParams<T> P) {
     const bool shift = MODEL >= 0 ? false : (P.shift != 0 && PASS == PASS_CORRECTOR);
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
-    constexpr int QCAP = queue_entries<T, WPT>();         // per-lane queue of non-empty accept masks
+    constexpr int QCAP = queue_entries<T, WPT, MODEL>();         // per-lane queue of non-empty accept masks
     static_assert(QCAP >= 4 && kQueueSlack >= 1 && kQueueSlack <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[SPHMI_LDS_STAGE ? 1 : WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
@@ -688,7 +694,8 @@ k_neighbor_force(const ForceParams<T> P) {
     // to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration.  The loop tests are
     // computed once per iteration, at its END (a hand-rotated do … while: written top-tested the compiler copied six accumulators
     // per iteration).
-    auto run_pairs_plain = [&](const int keep, const bool drain) __attribute__((always_inline)) {
+    auto run_pairs_plain = [&](const int keep, const bool drain, auto two_tag) __attribute__((always_inline)) {
+        constexpr bool kTwo = decltype(two_tag)::value;
         unsigned qf = qn != 0 ? 1u : 0u;
         bool more = qn != 0, have = cm != 0;
         if (__builtin_amdgcn_ballot_w64(drain ? (more | have) : (qn > keep)) != 0) do {
@@ -703,7 +710,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #ifdef SPHMI_STATS
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(m != 0));
 #endif
-            if constexpr (kTwoPairs) {
+            if constexpr (kTwo) {
                 // TWO neighbours per iteration, their four gathers in flight together; the pairs are still accumulated one after
                 // the other, in mask order, so the sums are those of the one-pair loop bit for bit.
                 const unsigned m1 = m & (m - 1);
@@ -823,7 +830,13 @@ k_neighbor_force(const ForceParams<T> P) {
     auto run_pairs = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         if constexpr (kPipe2) run_pairs_piped2(keep, drain);
         else if constexpr (kPipe) run_pairs_piped(keep, drain);
-        else run_pairs_plain(keep, drain);
+        else run_pairs_plain(keep, drain, std::bool_constant<kTwoPairs>());
+    };
+    // split mode (below): a wave's queue entries hold one or two bits — ONE pair per iteration (a second slot would run for the few
+    // lanes that have one and be waited for by all: Dambreak3d Dp0.02 in fp64 88 against 79 µs per step)
+    [[maybe_unused]] auto run_pairs_split = [&](const int keep, const bool drain) __attribute__((always_inline)) {
+        if constexpr (sizeof(T) == 4 && MODEL >= 0) run_pairs_piped(keep, drain);
+        else run_pairs_plain(keep, drain, std::false_type());
     };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
@@ -886,6 +899,73 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
     }
+    auto push_entry = [&](const unsigned bits, const int c0) {
+        if (bits != 0) {
+            *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
+        }
+    };
+    // Split mode (tiles of eight waves, ForceParams::split).  A target's neighbours sit in the two or three chunks that cover its own
+    // cells, so dealing whole chunks to the waves leaves most lanes of every wave idle and one or two waves of the tile with all the
+    // work of a lane (Dambreak3d Dp0.02: waves of interior tiles ran 50-58 two-pair iterations against a mean of 19).
+    // Here the waves still scan the tile's chunks in turn, but the accept masks go to a table in LDS, and after one workgroup barrier
+    // EVERY wave takes a share of every chunk: four consecutive bits of each 32-candidate half, rotated by the chunk index — an
+    // eighth of every lane's pairs, give or take the statistics.  Costs one barrier and a walk over the table; pays when a tile has
+    // enough pairs (the engine decides by particles per cell).
+    constexpr bool kSplitCapable = split_capable<T, WPT, MODEL>();
+    constexpr int KC = kSplitCapable ? ((D == 3) ? 40 : 16) : 1;       // chunks per round of the table (a tile of spray has more: rounds)
+    __shared__ uint2 s_tab[KC * kWave];                                  // [chunk][lane]
+    bool split_done = false;
+    if constexpr (kSplitCapable) if (P.split) {
+        split_done = true;
+        // every wave enumerates the tile's chunks alike (the ranges are the tile's, the skip test is the same ballot in every wave):
+        // chunk ci is scanned by wave ci % WPT
+        auto for_chunks = [&](auto&& fn) __attribute__((always_inline)) -> int {
+            int ci = 0;
+#pragma unroll 1
+            for (int seg = 0; seg < NSEG; ++seg) {
+                const int2 rg = s_rng[(kShareRanges ? seg : 0) * kWave + lane];
+                const int lo_l = rg.x, hi_l = rg.y;
+                const int LO = rl_i(lo_l, 0), HI = rl_i(hi_l, last_lane);
+#pragma unroll 1
+                for (int cb = LO; cb < HI; cb += kWave) {
+                    if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;      // (as below: no lane's cells)
+                    fn(ci, cb, HI, lo_l, hi_l);
+                    ci += 1;
+                }
+            }
+            return ci;
+        };
+        int w0 = 0, total = 0;
+        do {
+            total = for_chunks([&](const int ci, const int cb, const int HI, const int lo_l, const int hi_l) __attribute__((always_inline)) {
+                if (ci < w0 || ci >= w0 + KC || (ci & (WPT - 1)) != wv) return;
+                const V4 cpk = chunk_packet(cb, HI);
+                unsigned long long m = scan_chunk(cb, HI, cpk);
+                const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);      // MY three cells of this row (quirk Q1)
+                const int w = b1 - b0;
+                const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
+                m = (w > 0) ? (m & rm) : 0ull;
+                s_tab[(ci - w0) * kWave + lane] = make_uint2((unsigned)m, (unsigned)(m >> 32));
+                work_ch += 1;
+#ifdef SPHMI_STATS
+                st_chunks += 1;
+#endif
+            });
+            __syncthreads();
+            for_chunks([&](const int ci, const int cb, const int, const int, const int) __attribute__((always_inline)) {
+                if (ci < w0 || ci >= w0 + KC) return;
+                const uint2 mm = s_tab[(ci - w0) * kWave + lane];
+                constexpr int kShare = 32 / WPT;
+                const unsigned pat = ((1u << kShare) - 1u) << (kShare * ((wv + ci) & (WPT - 1)));
+                if (__builtin_amdgcn_ballot_w64(qn > QCAP - 2) != 0) run_pairs_split(QCAP - 1 - kQueueSlack, false);
+                push_entry(mm.x & pat, cb); push_entry(mm.y & pat, cb + 32);
+            });
+            w0 += KC;
+            if (w0 < total) __syncthreads();                       // the table is filled again
+        } while (w0 < total);
+        run_pairs_split(0, true);
+    }
+    if (!split_done) {
 #pragma unroll 1
     for (int seg = 0; seg < NSEG; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
@@ -959,15 +1039,11 @@ k_neighbor_force(const ForceParams<T> P) {
                 continue;
             }
 #endif
-            auto push = [&](const unsigned bits, const int c0) {
-                if (bits != 0) {
-                    *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
-                }
-            };
-            push((unsigned)m, cb); push((unsigned)(m >> 32), cb + 32);
+            push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32);
         }
     }
-    run_pairs(0, true);
+        run_pairs(0, true);
+    }
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
 #if SPHMI_DIAG != 0

@@ -987,3 +987,47 @@ def test_a_particle_leaving_the_sticky_grid_sends_the_rebuild_to_the_host(dims, 
         o = orc.download()
         np.testing.assert_array_equal(d["ID"], o["ID"])
         assert relmax(d["Density"], o["Density"]) < 1e-9 and np.abs(d["Position"] - o["Position"]).max() < 1e-9 * np.abs(o["Position"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_split_mode_of_the_eight_wave_kernels(split, dam_break_3d_shipped, dam_break_2d_mdbc, monkeypatch):
+    """Tiles of eight waves (launches below 512 tiles) hand their accept masks round through a table in LDS and every wave takes a
+    share of every chunk when the engine expects enough pairs per tile (ForceParams::split, decided once per upload from the
+    particles per occupied cell).  Both modes are forced here — on a crowd whose rows hold more chunks than one round of the table
+    (2-D: 16, 3-D: 40), and over K steps of a layout the rule switches on (Dambreak3d Dp0.02) and of one it leaves off
+    (Dambreak2dMDBC: four particles per cell) — and have to track the fp64 oracle alike."""
+    from test_oracle import default_2d_setup
+    monkeypatch.setenv("SPHMI_SPLIT", split)
+    rng = np.random.default_rng(7)
+    s2 = default_2d_setup()
+    n = 2300                                                # 3 cells of one row: 36 chunks per row, 108 per tile
+    pos = np.stack([rng.uniform(0.0, 0.23, n), rng.uniform(0.041, 0.119, n)], axis=1)
+    p = particles_from_arrays(2, pos, np.full(n, 1000.0) + rng.uniform(0, 3, n), np.ones(n), np.ones(n), np.arange(1, n + 1))
+    p.Velocity[:] = rng.uniform(-1, 1, size=(n, 2))
+    for fb, tol in ((8, 1e-10), (4, 2e-4)):
+        eng, orc = engines(p, s2, fb)
+        d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+        ie, io = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
+        np.testing.assert_allclose(d1[ie], d2[io], rtol=0, atol=tol * np.abs(d2).max())
+        np.testing.assert_allclose(a1[ie], a2[io], rtol=0, atol=tol * np.abs(a2).max())
+    dp = 0.02
+    s3 = setup_dam_break_3d(dp)
+    n = 3000                                                # 3-D crowd: two cells of one row, 47 chunks per row
+    H = s3.SimKernel.H
+    pos = np.stack([rng.uniform(0.6 * H, 2.4 * H, n), rng.uniform(0.6 * H, 1.4 * H, n), rng.uniform(0.6 * H, 1.4 * H, n)], axis=1)
+    p = particles_from_arrays(3, pos, np.full(n, 1000.0) + rng.uniform(0, 3, n), np.ones(n), np.ones(n), np.arange(1, n + 1))
+    p.Velocity[:] = rng.uniform(-1, 1, size=(n, 3))
+    eng, orc = engines(p, s3, 8)
+    d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+    ie, io = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
+    np.testing.assert_allclose(d1[ie], d2[io], rtol=0, atol=1e-10 * np.abs(d2).max())
+    np.testing.assert_allclose(a1[ie], a2[io], rtol=0, atol=1e-10 * np.abs(a2).max())
+    for (p, s), steps in ((dam_break_3d_shipped, 12), (dam_break_2d_mdbc, 20)):
+        for fb, tol in ((8, 1e-9), (4, 1e-5)):
+            eng, orc = engines(p, s, fb)
+            pe, po = eng.advance(1e9, max_steps=steps), orc.advance(1e9, max_steps=steps)
+            assert (pe.iteration, pe.n_rebuilds) == (po.iteration, po.n_rebuilds)
+            e, o = by_id(eng.download()), by_id(orc.download())
+            assert relmax(e["Density"], o["Density"]) < tol
+            assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < tol
