@@ -58,7 +58,7 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 COUNTER_RECORD = "profiles/r04_counters.json"
 DP1 = 0.00425
-BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 1, 4>", "corrector": "k_neighbor_force<float, 3, 2, 33, 1, 4>"}
+BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 2, 2>", "corrector": "k_neighbor_force<float, 3, 2, 33, 2, 2>"}
 
 
 def loaded_kernel_identity():

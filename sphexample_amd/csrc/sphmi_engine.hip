@@ -265,7 +265,10 @@ struct Engine final : EngineBase {
     int kWptMedium = -1;               // $SPHMI_WPT2_BELOW: overrides `medium` for every kernel
     int waves_per_tile(int ntile, bool generic) const {
         if (force_wpt > 0) return force_wpt;
-        int tiny = 512, small = 1024, medium = 6000;
+        // fp32, round 4: two-wave tiles are HALF tiles (sphmi_kernels.h, kHalf: a wave serves 32 targets with two lanes each) and beat the
+        // one-wave kernels at every size measured — 6.3 k tiles 421 -> 380 us per step, 16.5 k (C3) 957 -> 914, 44 k 2553 -> 2507, 120 k
+        // 7117 -> 7080 — and the four-wave kernels from ~900 tiles on (819 tiles: 97 against 106 us; 993: 118 against 108)
+        int tiny = 512, small = 900, medium = INT32_MAX;
         if (sizeof(T) == 8) { tiny = 400; small = 400; medium = 2000; }
         (void)generic;
         if (kWptMedium >= 0) medium = kWptMedium;
@@ -534,6 +537,12 @@ struct Engine final : EngineBase {
         }
         if constexpr (WPT == 2) {
             // two tiles of two waves per workgroup: four waves = one per SIMD of the compute unit ($SPHMI_TPB2=0: one tile per block)
+            if (D == 3 && tpb2 == 4) {
+                dim3 g2(8 * ((part_max[list] + 3) / 4)), b2(kWave * 8);
+                hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, 2, 4>), g2, b2, 0, stream, P);
+                HC(hipGetLastError());
+                return;
+            }
             if (D == 3 && tpb2) {
                 dim3 g2(8 * ((part_max[list] + 1) / 2)), b2(kWave * 4);
                 hipLaunchKernelGGL((k_neighbor_force<T, 3, PASS, MODEL, 2, 2>), g2, b2, 0, stream, P);

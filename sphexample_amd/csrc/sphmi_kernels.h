@@ -61,6 +61,10 @@ constexpr int kWave = 64;
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
                                 // (build/variants/libsphmi_ldsstage.so: __graft_entry__.build(); parity: tests/test_lds_stage_variant_gpu.py)
 #endif
+#ifndef SPHMI_HALF_TILE
+#define SPHMI_HALF_TILE 1       // two-wave tiles: 1 = each wave serves 32 targets, two lanes per target (k_neighbor_force, kHalf); 0 = both waves serve
+                                // the tile's 64 targets and split its chunks (rounds 1-4) — A/B builds only
+#endif
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
                                 // neither / adjacent lanes sharing a gathered record
@@ -78,7 +82,11 @@ constexpr int kWave = 64;
 // (not the fp64 kernel of the run-time models: its three sets of partial sums take 43 KB, and two workgroups per compute unit — handles of
 // 256 to 400 tiles — matter more than the split)
 template <class T, int WPT, int MODEL> constexpr bool split_capable() { return WPT >= 8 && SPHMI_LDS_STAGE == 0 && !(sizeof(T) == 8 && MODEL < 0); }
-template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() { return WPT >= 8 ? (split_capable<T, WPT, MODEL>() ? 8 : 6) : (sizeof(T) == 8 ? 16 : 12); }
+// Half tiles (two waves per tile, fp32): ten entries — measured at 1.06 M / 323 k / 159 k / 90 k particles (µs per step): 8 → 922 / 312 / 187 /
+// 132, 10 → 914 / 316 / 192 / 133, 12 → 915 / 316 / 192 / 135, 14 → 951, 16 → 1020.
+template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
+    return WPT >= 8 ? (split_capable<T, WPT, MODEL>() ? 8 : 6) : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? 10 : 12));
+}
 constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
@@ -432,8 +440,16 @@ k_neighbor_force(const ForceParams<T> P) {
         if (r >= P.part[8 + x]) return;
         b = P.order[P.part[x] + r];
     }
-    const int t0 = b * kWave;
-    const int a = t0 + lane;
+    // kHalf (tiles of two waves): wave w serves targets 32w … 32w+31 of the tile, TWO LANES PER TARGET — lane l and lane l + 32 hold the
+    // same target and take the lower / upper 32 candidates of every chunk (what the matrix layout hands each lane half anyway: one
+    // target block per chunk instead of two, no exchange of mask halves), and add their sums once after the loop.  The two waves of a
+    // tile share nothing — no partial sums in LDS, no barrier — and a target's pairs are dealt half-chunk by half-chunk instead of chunk
+    // by chunk: 159 k particles ran 93.8 pair-loop iterations per wave for 67.6 pairs per lane (72 % of the lane slots; one wave per
+    // tile: 90 %).
+    constexpr bool kHalf = WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
+    const int hl = kHalf ? (lane >> 5) : 0;                 // which 32 candidates of a chunk this lane takes
+    const int t0 = kHalf ? b * kWave + 32 * wv : b * kWave;
+    const int a = kHalf ? t0 + (lane & 31) : t0 + lane;
     const bool valid = a < P.N;
     const int ac = valid ? a : P.N - 1;
     // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
@@ -475,7 +491,7 @@ k_neighbor_force(const ForceParams<T> P) {
 
     const int key_a = P.key[ac];
     const int cs_a = P.cstart[key_a], ce_a = P.cstart[key_a + 1];
-    const int last_lane = min(kWave - 1, P.N - 1 - t0);
+    const int last_lane = min(kHalf ? 31 : kWave - 1, P.N - 1 - t0);
 
     // Phase 1 works in tile-local coordinates (origin = the tile's first particle) and in the expanded
     // form  |c − t|² − H'² = |c|² − 2c·t + (|t|² − H'²)  with a slightly generous cut-off
@@ -848,9 +864,15 @@ k_neighbor_force(const ForceParams<T> P) {
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
     const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
     float B0[2], B1[2], B2[2], A2;
+    if constexpr (kHalf) {
+        // lanes l and l + 32 hold the same target: the operand layout without an exchange, one target block
+        B0[0] = hl ? m2y : m2x; B1[0] = hl ? 1.0f : m2z; B2[0] = hl ? 0.0f : -thr;
+        B0[1] = B1[1] = B2[1] = 0.0f;
+    } else {
     B0[0] = m2x; B0[1] = m2y; swap_halves(B0[0], B0[1]);       // [T]: {k0: −2tx | k1: −2ty}
     B1[0] = m2z; B1[1] = 1.0f; swap_halves(B1[0], B1[1]);      //      {k2: −2tz | k3: 1}
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
+    }
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
     auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
     auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
@@ -865,7 +887,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #pragma unroll
         for (int C = 1; C >= 0; --C) {
 #pragma unroll
-            for (int Tb = 0; Tb < 2; ++Tb) {
+            for (int Tb = 0; Tb < (kHalf ? 1 : 2); ++Tb) {
                 f32x16 d = {0};
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[C], B0[Tb], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[C], B1[Tb], d, 0, 0, 0);
@@ -876,6 +898,8 @@ k_neighbor_force(const ForceParams<T> P) {
                 __builtin_amdgcn_sched_barrier(0);      // one 32×32 block in flight: 16 accumulator registers
             }
         }
+        // (kHalf: W[0] IS this lane's share — its target against candidates cb + 32·hl … + 31)
+        if constexpr (kHalf) return (unsigned long long)W[0];
         swap_halves(W[0], W[1]);
         return ((unsigned long long)W[1] << 32) | W[0];
     };
@@ -980,15 +1004,15 @@ k_neighbor_force(const ForceParams<T> P) {
         const int LO = rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
         int first = 0;
-        if constexpr (WPT > 1) {
+        if constexpr (WPT > 1 && !kHalf) {
             // chunks dealt round-robin over ALL rows with four or more waves (counts differ by one at most); two-wave tiles keep
-            // the rotation by row
+            // the rotation by row (kHalf: a wave scans every chunk of ITS 32 targets)
             if constexpr (WPT >= 4) first = (wv - g0) & (WPT - 1);
             else first = (wv + WPT - seg % WPT) % WPT;
             g0 = (g0 + (HI > LO ? (HI - LO + kWave - 1) / kWave : 0)) & (WPT - 1);
         }
 #pragma unroll 1
-        for (int cb = LO + first * kWave; cb < HI; cb += kWave * WPT) {
+        for (int cb = LO + first * kWave; cb < HI; cb += kHalf ? kWave : kWave * WPT) {
             // A tile of a sparse region (spray, a thin sheet) spans many cells: the union range of a row is then
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
@@ -1001,10 +1025,19 @@ k_neighbor_force(const ForceParams<T> P) {
                 m = scan_chunk(cb, HI, cpk);
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
+                if constexpr (kHalf) {
+                    // (this lane's 32 candidates start at cb + 32·hl)
+                    const int cbh = cb + 32 * hl;
+                    const int b0 = max(lo_l - cbh, 0), b1 = min(hi_l - cbh, 32);
+                    const int w = b1 - b0;
+                    const unsigned rm = ((~0u) >> ((32 - w) & 31)) << (b0 & 31);
+                    m = (w > 0) ? (unsigned long long)((unsigned)m & rm) : 0ull;
+                } else {
                 const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);
                 const int w = b1 - b0;
                 const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
                 m = (w > 0) ? (m & rm) : 0ull;
+                }
             }
             work_ch += 1;
 #ifdef SPHMI_STATS
@@ -1039,20 +1072,36 @@ k_neighbor_force(const ForceParams<T> P) {
                 continue;
             }
 #endif
-            push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32);
+            if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
+            else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }
         }
     }
         run_pairs(0, true);
     }
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
+    if constexpr (kHalf) {
+        // the two lanes of a target add their sums (lower half + upper half, in that order on both): every lane then holds the totals
+        auto both = [](T v) -> T {
+            if constexpr (sizeof(T) == 4) { float p = v, q = v; swap_halves(p, q); return p + q; }
+            else {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                unsigned l0 = (unsigned)u, l1 = l0, h0 = (unsigned)(u >> 32), h1 = h0;
+                swap_halves(l0, l1); swap_halves(h0, h1);
+                return __longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)) + __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1));
+            }
+        };
+        ax = both(ax); ay = both(ay); az = both(az); drho = both(drho);
+        if (shift) { gcx = both(gcx); gcy = both(gcy); gcz = both(gcz); divr = both(divr); }
+        if (MODEL < 0 && P.kout) { kgx = both(kgx); kgy = both(kgy); kgz = both(kgz); kw = both(kw); }
+    }
 #if SPHMI_DIAG != 0
     { const T z = (T)P.exact_cut; drho *= z; ax *= z; ay *= z; az *= z; }      // (0 at run time for the compiled-in model: the state stays sane, the loop stays alive)
 #endif
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
     int tile_work = 9 * work_it + 16 * work_ch + 16;
-    if (P.xcd_clock && lane == 0 && wv == 0) {
+    if (P.xcd_clock && lane == 0 && (kHalf || wv == 0)) {
         // one launch per rebuild interval is sampled: when does each XCD run out of tiles?  The engine moves the XCDs'
         // shares of the estimated cost towards equal finishing times at the next rebuild.
         atomicMax(&P.xcd_clock[blockIdx.x & 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -1081,7 +1130,11 @@ k_neighbor_force(const ForceParams<T> P) {
         atomicAdd(&P.stats[3], st_emp); atomicAdd(&P.stats[4], st_chunks); atomicAdd(&P.stats[5], 1ull);
     }
 #endif
-    if constexpr (WPT > 1) {
+    if constexpr (kHalf) {
+        // (a sampled launch: the tile's work = its slower wave × 2; the table was zeroed in front of the launch)
+        tile_work *= WPT;
+        if (P.tile_work && lane == 0) atomicMax(&P.tile_work[b], tile_work);
+    } else if constexpr (WPT > 1) {
         // partial sums of waves 1 … WPT−1: { a, dρ/dt }, and for the run-time variant the shifting and kernel-output sums
         constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;
         __shared__ V4 s_part_all[TPB * kPartArrays * (WPT - 1) * kWave];
@@ -1112,16 +1165,17 @@ k_neighbor_force(const ForceParams<T> P) {
             if (MODEL < 0 && P.kout) { const V4 g = s_part[(2 * (WPT - 1) + k) * kWave + lane]; kgx += g.x; kgy += g.y; kgz += g.z; kw += g.w; }
         }
     }
-    if (P.tile_work && lane == 0) P.tile_work[b] = tile_work;
+    if (!kHalf && P.tile_work && lane == 0) P.tile_work[b] = tile_work;
     // ---- epilogue ---------------------------------------------------------------------------
     // (the pre-test reading of the reduction slots is issued first: it comes from beyond the XCD's L2 and is needed last)
 
+    const bool storer = owned && (!kHalf || hl == 0);      // (kHalf: both lanes of a target hold the results, the lower one stores)
     const uint8_t ty_a = ty_raw & 0x3F;
     const T gf = ty_a == 1 ? T(-1) : (ty_a == 3 ? T(1) : T(0));     // src/PreProcess.jl:78-87
     const T ml = fluid_a ? T(1) : T(0);
     if constexpr (PASS == PASS_FORCES_ONLY) {
         V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho;
-        if (owned) P.accbuf[a] = o;
+        if (storer) P.accbuf[a] = o;
     } else if constexpr (PASS == PASS_PREDICTOR) {
         // HalfTimeStep (src/SPHCellList.jl:624-638) + LimitDensityAtBoundary! (SimulationEquations.jl:36-42)
         if constexpr (D == 3) az += P.g * gf; else ay += P.g * gf;
@@ -1132,7 +1186,7 @@ k_neighbor_force(const ForceParams<T> P) {
         if (!fluid_a && rho_h < P.rho0) rho_h = P.rho0;
         o0.w = rho_h;
         o1.w = s_a;                         // ρⁿ·s travels with the half-step stream
-        if (owned) { P.out0[a] = o0; P.out1[a] = o1; }
+        if (storer) { P.out0[a] = o0; P.out1[a] = o1; }
     } else {
         // LimitDensityAtBoundary!(Density) → DensityEpsi! → FullTimeStep
         // (src/SPHCellList.jl:794-798, 640-652; src/SimulationEquations.jl:28-33)
@@ -1182,7 +1236,7 @@ k_neighbor_force(const ForceParams<T> P) {
         o0.w = fluid_a ? rho_new : -rho_new;
         o1.w = eos7<T>(rho_new, P.rho0, P.inv_rho0, P.Cbe);
         oa.x = ax; oa.y = ay; oa.z = az; oa.w = drho;
-        if (owned) {
+        if (storer) {
             if (MODEL < 0 && P.kout) { V4 ko; ko.x = kgx; ko.y = kgy; ko.z = kgz; ko.w = kw; P.kout[a] = ko; }
             P.out0[a] = o0; P.out1[a] = o1; P.accbuf[a] = oa;
             if (comp_on) P.comp[a] = lo4;

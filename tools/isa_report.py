@@ -10,7 +10,7 @@ import argparse, collections, json, os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["k_neighbor_force<float, 3, 1, 33, 1, 4>", "k_neighbor_force<float, 3, 2, 33, 1, 4>"]
+BENCH = ["k_neighbor_force<float, 3, 1, 33, 2, 2>", "k_neighbor_force<float, 3, 2, 33, 2, 2>"]
 
 
 def code_object(lib, workdir):

@@ -6,7 +6,7 @@
 """
 import json, os, re, sys
 N = 1057738
-BENCH = {"predictor": "k_neighbor_force<float, 3, 1, 33, 1, 4>", "corrector": "k_neighbor_force<float, 3, 2, 33, 1, 4>"}
+BENCH = {"predictor": "k_neighbor_force<float, 3, 1, 33, 2, 2>", "corrector": "k_neighbor_force<float, 3, 2, 33, 2, 2>"}
 if os.environ.get("PMC_KERNELS"):            # other kernels than the bench's: "predictor name|corrector name" ($PMC_FLOAT_BYTES = 8 for fp64 handles)
     BENCH = dict(zip(("predictor", "corrector"), os.environ["PMC_KERNELS"].split("|")))
 FB = int(os.environ.get("PMC_FLOAT_BYTES", "4"))
