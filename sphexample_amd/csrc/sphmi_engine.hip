@@ -268,8 +268,10 @@ struct Engine final : EngineBase {
         // fp32, round 4: two-wave tiles are HALF tiles (sphmi_kernels.h, kHalf: a wave serves 32 targets with two lanes each) and beat the
         // one-wave kernels at every size measured — 6.3 k tiles 421 -> 380 us per step, 16.5 k (C3) 957 -> 914, 44 k 2553 -> 2507, 120 k
         // 7117 -> 7080 — and the four-wave kernels from ~900 tiles on (819 tiles: 97 against 106 us; 993: 118 against 108)
+        // (fp64 likewise once the two lanes of a target took alternate groups of four candidates: 1.06 M particles 1924 -> 1877 us per step,
+        // 470 k 890 -> 868, 159 k 324 = 324; the one-wave kernels remain behind $SPHMI_WPT=1)
         int tiny = 512, small = 900, medium = INT32_MAX;
-        if (sizeof(T) == 8) { tiny = 400; small = 400; medium = 2000; }
+        if (sizeof(T) == 8) { tiny = 400; small = 400; }
         (void)generic;
         if (kWptMedium >= 0) medium = kWptMedium;
         return ntile < tiny ? 8 : (ntile < small ? 4 : (ntile < medium ? 2 : 1));

@@ -65,6 +65,9 @@ constexpr int kWave = 64;
 #define SPHMI_HALF_TILE 1       // two-wave tiles: 1 = each wave serves 32 targets, two lanes per target (k_neighbor_force, kHalf); 0 = both waves serve
                                 // the tile's 64 targets and split its chunks (rounds 1-4) — A/B builds only
 #endif
+#ifndef SPHMI_HALF_INTERLEAVE
+#define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0)
+#endif
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
                                 // neither / adjacent lanes sharing a gathered record
@@ -529,6 +532,15 @@ k_neighbor_force(const ForceParams<T> P) {
     // ---- pair physics for one accepted neighbour j ------------------------------------------
     T sum_c = 0, sum_d = 0;                             // Σ (1/ρ_b)·(∇W·vᵢⱼ) (continuity without ρₐm₀), Σ density diffusion
     constexpr int kRecShift = sizeof(T) == 4 ? 5 : 6;      // log2 of the record size
+    // bit p of a queue entry → the candidate's distance from the entry's base.  Half tiles with interleaved shares: the matrix layout
+    // hands lane half h the rows 8g + 4h + k (g = 0 … 7, k = 0 … 3) of a chunk loaded in natural order, so bit p = 4g + k is candidate
+    // 8g + k = p + (p & ~3) behind the base cb + 4h — the two lanes of a target take alternate groups of four candidates and their
+    // pair counts differ by a handful instead of by half a cell (one v_and + one v_add per pair)
+    constexpr bool kInterleave = WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 && SPHMI_HALF_INTERLEAVE != 0;
+    auto bit_offset = [](const unsigned m) -> unsigned {
+        const unsigned p = (unsigned)__builtin_ctz(m);
+        if constexpr (kInterleave) return p + (p & 0x1Cu); else return p;
+    };
     const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
     // `if_i` when the target plays "i", `if_j` otherwise
     auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T { return a_is_i ? if_i : if_j; };
@@ -733,8 +745,8 @@ k_neighbor_force(const ForceParams<T> P) {
                 cm = m1 & (m1 - 1);
                 if (m != 0) {
                     const bool two = m1 != 0;
-                    const unsigned jr0 = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
-                    const unsigned jr1 = two ? ((unsigned)__builtin_ctz(m1) << kRecShift) + cbase : jr0;
+                    const unsigned jr0 = (bit_offset(m) << kRecShift) + cbase;
+                    const unsigned jr1 = two ? (bit_offset(m1) << kRecShift) + cbase : jr0;
                     const V4 n0a = gather_packet(rs0, jr0, 0, T());
                     const V4 n1a = gather_packet(rs0, jr0, 1, T());
                     const V4 n0b = gather_packet(rs0, jr1, 0, T());
@@ -745,7 +757,7 @@ k_neighbor_force(const ForceParams<T> P) {
             } else {
                 cm = m & (m - 1);                                    // (0 stays 0)
                 if (m != 0) {
-                    const unsigned jr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;      // record size × the neighbour's index
+                    const unsigned jr = (bit_offset(m) << kRecShift) + cbase;      // record size × the neighbour's index
                     const V4 n0 = gather_packet(rs0, jr, 0, T());
                     const V4 n1 = gather_packet(rs0, jr, 1, T());
                     pair(jr, n0, n1, plays_i(jr));
@@ -800,7 +812,7 @@ k_neighbor_force(const ForceParams<T> P) {
             // (meaningless without pv.  __builtin_ctz(0) is a POISON value in clang — llvm.cttz with is_zero_poison — not immediate
             // undefined behaviour: it is harmless as long as nothing consumes it, and every use of pjr sits under `if (v)`.  An inline
             // `v_ffbl_b32`, defined for 0, pins the LDS wait in front of the arithmetic and measured −0.5 %.)
-            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
+            pjr = (bit_offset(m) << kRecShift) + cbase;
             // 3. the arithmetic
             if (v) pair(jr, n0, n1, plays_i(jr));
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
@@ -835,8 +847,8 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned m1 = m & (m - 1);
             cm = m1 & (m1 - 1);
             pv = m != 0; pv2 = m1 != 0;
-            pjr = ((unsigned)__builtin_ctz(m) << kRecShift) + cbase;
-            pjr2 = pv2 ? ((unsigned)__builtin_ctz(m1) << kRecShift) + cbase : pjr;
+            pjr = (bit_offset(m) << kRecShift) + cbase;
+            pjr2 = pv2 ? (bit_offset(m1) << kRecShift) + cbase : pjr;
             if (v0) {
                 pair(jr0, n0a, n1a, plays_i(jr0));
                 if (v1) pair(jr1, n0b, n1b, plays_i(jr1));
@@ -862,7 +874,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // column for 16 candidate rows per 32×32 block; their sign bits are shifted into a word with
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
-    const int bperm = (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+    const int bperm = kInterleave ? lane : (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
     float B0[2], B1[2], B2[2], A2;
     if constexpr (kHalf) {
         // lanes l and l + 32 hold the same target: the operand layout without an exchange, one target block
@@ -1025,7 +1037,16 @@ k_neighbor_force(const ForceParams<T> P) {
                 m = scan_chunk(cb, HI, cpk);
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
-                if constexpr (kHalf) {
+                if constexpr (kInterleave) {
+                    // this lane's candidates: cb + 4·hl + 8g + k; how many of them sit below a bound X (relative to cb + 4·hl):
+                    // 4·(X >> 3) + min(X & 7, 4), X clamped to 0 … 64 — the bits of MY cells are [below(lo), below(hi))
+                    auto below = [](int X) -> int { X = min(max(X, 0), 64); return 4 * (X >> 3) + min(X & 7, 4); };
+                    const int cbh = cb + 4 * hl;
+                    const int b0 = below(lo_l - cbh), b1 = below(hi_l - cbh);
+                    const int w = b1 - b0;
+                    const unsigned rm = ((~0u) >> ((32 - w) & 31)) << (b0 & 31);
+                    m = (w > 0) ? (unsigned long long)((unsigned)m & rm) : 0ull;
+                } else if constexpr (kHalf) {
                     // (this lane's 32 candidates start at cb + 32·hl)
                     const int cbh = cb + 32 * hl;
                     const int b0 = max(lo_l - cbh, 0), b1 = min(hi_l - cbh, 32);
@@ -1072,7 +1093,8 @@ k_neighbor_force(const ForceParams<T> P) {
                 continue;
             }
 #endif
-            if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
+            if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
+            else if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
             else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }
         }
     }
