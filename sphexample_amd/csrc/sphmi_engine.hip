@@ -271,8 +271,9 @@ struct Engine final : EngineBase {
         // (fp64 likewise once the two lanes of a target took alternate groups of four candidates: 1.06 M particles 1924 -> 1877 us per step,
         // 470 k 890 -> 868, 159 k 324 = 324; the one-wave kernels remain behind $SPHMI_WPT=1)
         int tiny = 512, small = 900, medium = INT32_MAX;
-        if (sizeof(T) == 8) { tiny = 400; small = 400; }
-        (void)generic;
+        // (… but not the fp64 kernels of the run-time models, 180 registers: above 2 000 tiles their one-wave kernels stay 3 … 14 % ahead —
+        // profiles/r04_variants_vs_round3.md)
+        if (sizeof(T) == 8) { tiny = 400; small = 400; if (generic) medium = 2000; }
         if (kWptMedium >= 0) medium = kWptMedium;
         return ntile < tiny ? 8 : (ntile < small ? 4 : (ntile < medium ? 2 : 1));
     }

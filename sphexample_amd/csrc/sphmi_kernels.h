@@ -1015,6 +1015,14 @@ k_neighbor_force(const ForceParams<T> P) {
         // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
         const int LO = rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
+        // kInterleave: this lane's candidates of the chunk at cb are cb + 4·hl + 8g + k (g = 0 … 7, k = 0 … 3); how many of them sit below a
+        // bound X relative to cb + 4·hl: below(X) = 4·(X >> 3) + min(X & 7, 4) (floor shift: exact for negative X too), and a chunk further on
+        // it is 32 less — so the range of MY cells' bits is worked out once per row and moved by 32 per chunk
+        [[maybe_unused]] int row_b0 = 0, row_b1 = 0;
+        if constexpr (kInterleave) {
+            auto below = [](const int X) -> int { return 4 * (X >> 3) + min(X & 7, 4); };
+            row_b0 = below(lo_l - LO - 4 * hl); row_b1 = below(hi_l - LO - 4 * hl);
+        }
         int first = 0;
         if constexpr (WPT > 1 && !kHalf) {
             // chunks dealt round-robin over ALL rows with four or more waves (counts differ by one at most); two-wave tiles keep
@@ -1038,11 +1046,9 @@ k_neighbor_force(const ForceParams<T> P) {
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
                 if constexpr (kInterleave) {
-                    // this lane's candidates: cb + 4·hl + 8g + k; how many of them sit below a bound X (relative to cb + 4·hl):
-                    // 4·(X >> 3) + min(X & 7, 4), X clamped to 0 … 64 — the bits of MY cells are [below(lo), below(hi))
-                    auto below = [](int X) -> int { X = min(max(X, 0), 64); return 4 * (X >> 3) + min(X & 7, 4); };
-                    const int cbh = cb + 4 * hl;
-                    const int b0 = below(lo_l - cbh), b1 = below(hi_l - cbh);
+                    // the bits of MY cells: [below(lo) − 32j, below(hi) − 32j) within 0 … 32 for the j-th chunk of the row (row_b0 / row_b1 above)
+                    const int t = (cb - LO) >> 1;
+                    const int b0 = min(max(row_b0 - t, 0), 32), b1 = min(max(row_b1 - t, 0), 32);
                     const int w = b1 - b0;
                     const unsigned rm = ((~0u) >> ((32 - w) & 31)) << (b0 & 31);
                     m = (w > 0) ? (unsigned long long)((unsigned)m & rm) : 0ull;
