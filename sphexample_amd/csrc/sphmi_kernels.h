@@ -88,6 +88,7 @@ template <class T, int WPT, int MODEL> constexpr bool split_capable() { return W
 // Half tiles (two waves per tile, fp32): ten entries — measured at 1.06 M / 323 k / 159 k / 90 k particles (µs per step): 8 → 922 / 312 / 187 /
 // 132, 10 → 914 / 316 / 192 / 133, 12 → 915 / 316 / 192 / 135, 14 → 951, 16 → 1020.
 template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
+    // (fp64 half tiles: 10 / 12 / 16 / 20 entries all within 0.5 % of each other at 1.06 M / 159 k / 70 k particles: sixteen stay)
     return WPT >= 8 ? (split_capable<T, WPT, MODEL>() ? 8 : 6) : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? 10 : 12));
 }
 constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
@@ -886,7 +887,13 @@ k_neighbor_force(const ForceParams<T> P) {
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     }
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
-    auto chunk_packet = [&](const int cb, const int HI) -> V4 { const int c = cb + bperm; return P.src0[c < HI ? c : cb]; };
+    // (half tiles: through the buffer descriptor of the gathers — one address instruction instead of a compare, a select and 64-bit
+    // pointer arithmetic; a lane beyond HI reads a record that phase 1 then discards (`cv`), one beyond the array reads zeros)
+    auto chunk_packet = [&](const int cb, const int HI) -> V4 {
+        const int c = cb + bperm;
+        if constexpr (kHalf) return gather_packet(rs0, (unsigned)c << kRecShift, 0, T());
+        else return P.src0[c < HI ? c : cb];
+    };
     auto scan_chunk = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
         const int c = cb + bperm;
         const bool cv = c < HI;
