@@ -1031,3 +1031,33 @@ def test_split_mode_of_the_eight_wave_kernels(split, dam_break_3d_shipped, dam_b
             e, o = by_id(eng.download()), by_id(orc.download())
             assert relmax(e["Density"], o["Density"]) < tol
             assert np.abs(e["Position"] - o["Position"]).max() / np.abs(o["Position"]).max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 97, 130, 1000])
+def test_half_tiles_on_ragged_sizes(n, monkeypatch):
+    """Two waves per tile = two HALF tiles of 32 targets with two lanes per target: forced here on particle counts whose
+    last tile leaves the second wave with no target, one target, or a partial set, in 2-D and 3-D, fp32 and fp64 — forces of one
+    evaluation and the state after three steps against the oracle."""
+    from test_oracle import default_2d_setup
+    monkeypatch.setenv("SPHMI_WPT", "2")
+    rng = np.random.default_rng(100 + n)
+    for dims, s in ((2, default_2d_setup()), (3, setup_dam_break_3d(0.02))):
+        H = s.SimKernel.H
+        side = max(1.0, (n / 12.0) ** (1.0 / dims))                      # ≈12 particles per cell
+        pos = rng.uniform(0.6 * H, (0.6 + side) * H, size=(n, dims))
+        ty = np.where(rng.random(n) < 0.8, 1, 2)
+        p = particles_from_arrays(dims, pos, np.full(n, 1000.0) + rng.uniform(0, 3, n), ty, ty, np.arange(1, n + 1))
+        p.Velocity[:] = rng.uniform(-0.1, 0.1, size=(n, dims))
+        for fb, tol in ((8, 1e-10), (4, 2e-4)):
+            eng, orc = engines(p, s, fb)
+            d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+            ie, io = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
+            np.testing.assert_allclose(d1[ie], d2[io], rtol=0, atol=tol * max(np.abs(d2).max(), 1e-300), err_msg=f"drho {dims}-D n={n} fb={fb}")
+            np.testing.assert_allclose(a1[ie], a2[io], rtol=0, atol=tol * max(np.abs(a2).max(), 1e-300), err_msg=f"acc {dims}-D n={n} fb={fb}")
+        eng, orc = engines(p, s, 8)
+        pe, po = eng.advance(1e9, max_steps=3), orc.advance(1e9, max_steps=3)
+        assert (pe.iteration, pe.n_rebuilds) == (po.iteration, po.n_rebuilds)
+        e, o = by_id(eng.download()), by_id(orc.download())
+        assert relmax(e["Density"], o["Density"]) < 1e-9
+        assert np.abs(e["Position"] - o["Position"]).max() <= 1e-10 * np.abs(o["Position"]).max()
