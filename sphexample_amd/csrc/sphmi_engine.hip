@@ -267,10 +267,11 @@ struct Engine final : EngineBase {
         if (force_wpt > 0) return force_wpt;
         // fp32, round 4: two-wave tiles are HALF tiles (sphmi_kernels.h, kHalf: a wave serves 32 targets with two lanes each) and beat the
         // one-wave kernels at every size measured — 6.3 k tiles 421 -> 380 us per step, 16.5 k (C3) 957 -> 914, 44 k 2553 -> 2507, 120 k
-        // 7117 -> 7080 — and the four-wave kernels from ~900 tiles on (819 tiles: 97 against 106 us; 993: 118 against 108)
+        // 7117 -> 7080 — and the four-wave kernels from somewhere between 819 and 993 tiles on (the dam-break lattice, 819 tiles: 97 against
+        // 106 us; 993: 118 against 108; DucklingMDBC, 857 tiles of a k = 1.5 kernel: 88 against 79 — the crossover sits at or below it)
         // (fp64 likewise once the two lanes of a target took alternate groups of four candidates: 1.06 M particles 1924 -> 1877 us per step,
         // 470 k 890 -> 868, 159 k 324 = 324; the one-wave kernels remain behind $SPHMI_WPT=1)
-        int tiny = 512, small = 900, medium = INT32_MAX;
+        int tiny = 512, small = 850, medium = INT32_MAX;
         // (… but not the fp64 kernels of the run-time models, 180 registers: above 2 000 tiles their one-wave kernels stay 3 … 14 % ahead —
         // profiles/r04_variants_vs_round3.md)
         if (sizeof(T) == 8) { tiny = 400; small = 400; if (generic) medium = 2000; }
