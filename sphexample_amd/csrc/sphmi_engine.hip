@@ -265,28 +265,20 @@ struct Engine final : EngineBase {
     int kWptMedium = -1;               // $SPHMI_WPT2_BELOW: overrides `medium` for every kernel
     int waves_per_tile(int ntile, bool generic) const {
         if (force_wpt > 0) return force_wpt;
-        // fp32, round 4: two-wave tiles are HALF tiles (sphmi_kernels.h, kHalf: a wave serves 32 targets with two lanes each) and beat the
-        // one-wave kernels at every size measured — 6.3 k tiles 421 -> 380 us per step, 16.5 k (C3) 957 -> 914, 44 k 2553 -> 2507, 120 k
-        // 7117 -> 7080 — and the four-wave kernels from somewhere between 819 and 993 tiles on (the dam-break lattice, 819 tiles: 97 against
-        // 106 us; 993: 118 against 108; DucklingMDBC, 857 tiles of a k = 1.5 kernel: 88 against 79 — the crossover sits at or below it)
-        // (fp64 likewise once the two lanes of a target took alternate groups of four candidates: 1.06 M particles 1924 -> 1877 us per step,
-        // 470 k 890 -> 868, 159 k 324 = 324; the one-wave kernels remain behind $SPHMI_WPT=1)
-        int tiny = 512, small = 850, medium = INT32_MAX;
-        // (… but not the fp64 kernels of the run-time models, 180 registers: above 2 000 tiles their one-wave kernels stay 3 … 14 % ahead —
-        // profiles/r04_variants_vs_round3.md)
-        if (sizeof(T) == 8) { tiny = 400; small = 400; if (generic) medium = 2000; }
+        // Round 4: every kernel of two, four or eight waves per tile serves HALF tiles (sphmi_kernels.h, kHalf: a wave serves 32 targets with two
+        // lanes each; with four / eight waves per tile the two / four waves of a half deal its chunks alternately).  Measured on the dam-break
+        // lattice (µs per step, `tools/time_sizes.py`; profiles/r04_raw/half_tile_thresholds.txt):
+        //   fp32  273 tiles: 8 → 46, 4 → 53;  381: 59 / 57;  489: 68 / 66;  2 482: 4 → 175, 2 → 180;  3 455: 226 / 224;  5 051: 325 / 299;
+        //         two waves against ONE (rounds 1-4) at 6.3 k / 16.5 k / 44 k / 120 k tiles: 380 / 895 / 2 444 / 6 950 against 421 / 957 / 2 553 / 7 117
+        //   fp64  273 tiles: 8 → 79, 4 → 71;  607: 4 → 107, 2 → 116;  881: 157 / 161;  1 098: 194 / 169;  16.5 k: 2 → 1 845, 1 → 1 924
+        // The fp64 kernels of the run-time models (180 registers) keep one wave per tile above 2 000 tiles (+3 … +14 % with two there).
+        int tiny = 330, small = 3000, medium = INT32_MAX;
+        // (fp64: DucklingMDBC, 857 tiles of a k = 1.5 kernel, runs 110 µs per step with two waves and 120 with four: the crossover sits below the lattice's)
+        if (sizeof(T) == 8) { tiny = 0; small = 800; if (generic) medium = 2000; }
         if (kWptMedium >= 0) medium = kWptMedium;
         return ntile < tiny ? 8 : (ntile < small ? 4 : (ntile < medium ? 2 : 1));
     }
     int classes_fine_below = 10000;    // $SPHMI_CLASSES_FINE_BELOW
-    // Split mode of the eight-wave kernels (ForceParams::split): pays when a tile has enough pairs to share out, costs one workgroup
-    // barrier and a walk over the tile's masks.  Decided ONCE per upload, at the first host-side rebuild, from the candidates a target
-    // sees — 3^D cells × particles per occupied cell: 115 on the 2-D dam break and StillWedge layouts, 510 on Dambreak3d Dp0.02, 35 on
-    // Dambreak2dMDBC (whose script pairs dx = 0.01 with the Dp0.02 layout: four particles per cell) — sticky, so that the summation
-    // order of a handle does not depend on when a count reaches the host.  $SPHMI_SPLIT = 0 / 1 forces it.
-    static constexpr int kSplitFromCandidates = 64;
-    int split_mode = -1;
-    const int split_env = getenv("SPHMI_SPLIT") ? atoi(getenv("SPHMI_SPLIT")) : -1;
     // domain decomposition: slab axis and the rank's cell-column range along it
     bool dd_slab = false; int dd_axis = 0; int64_t dd_col_lo = 0, dd_col_hi = 0; bool dd_has_lo = false, dd_has_hi = false;
     int64_t cell_cap = 0;
@@ -490,7 +482,6 @@ struct Engine final : EngineBase {
         P.key = key[cur]; P.cstart = cstart; P.type = type[cur];
         P.red = red_cur(); P.stats = red_d + 8; P.ctrl = nullptr;
         P.N = N; P.nxp = grid.np[0]; P.nxyp = grid.np[0] * grid.np[1];
-        P.split = split_env >= 0 ? (split_env != 0) : (split_mode > 0);
         P.dt = (T)dt; P.dt2 = (T)(dt * 0.5);
         P.H2 = (T)cfg.H2; P.h = (T)cfg.h; P.h_inv = (T)cfg.h_inv;
         P.Cgw = (T)(cfg.alphaD * 5.0 / (8.0 * cfg.h * cfg.h));
@@ -795,11 +786,6 @@ struct Engine final : EngineBase {
                 if (l < nlist) for (int x = 0; x < 8; ++x) { part_max[l] = std::max(part_max[l], part_h[16 * l + 8 + x]); list_tiles[l] += part_h[16 * l + 8 + x]; }
             }
             part_seen = part_max[0];
-        }
-        if (split_mode < 0) {
-            // (misc_h[0] = occupied cells, copied above and synchronised with the run table)
-            const int64_t cells = std::max<int64_t>(misc_h[0], 1);
-            split_mode = (int64_t)N * (D == 3 ? 27 : 9) >= (int64_t)kSplitFromCandidates * cells ? 1 : 0;
         }
         have_grid = true;
         n_rebuilds += 1;
@@ -1205,7 +1191,7 @@ struct Engine final : EngineBase {
                            (T)cfg.h, (T)cfg.eta2, red_d);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream));
-        uploaded = true; stepped = false; have_grid = false; index_counter = 0; split_mode = -1;
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
     }
 
     // ---- the bench lattice generated on the device (no host arrays, no upload) ---------------------
@@ -1263,7 +1249,7 @@ struct Engine final : EngineBase {
             HC(hipStreamSynchronize(stream));
         } catch (...) { release(); throw; }
         release();
-        uploaded = true; stepped = false; have_grid = false; index_counter = 0; split_mode = -1;
+        uploaded = true; stepped = false; have_grid = false; index_counter = 0;
     }
 
     template <class H> static void unpack3(const std::vector<V4>& s, H* out, int N, int D) {

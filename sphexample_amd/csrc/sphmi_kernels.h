@@ -65,6 +65,10 @@ constexpr int kWave = 64;
 #define SPHMI_HALF_TILE 1       // two-wave tiles: 1 = each wave serves 32 targets, two lanes per target (k_neighbor_force, kHalf); 0 = both waves serve
                                 // the tile's 64 targets and split its chunks (rounds 1-4) — A/B builds only
 #endif
+#ifndef SPHMI_HALF4
+#define SPHMI_HALF4 1           // four-wave tiles: 1 = two half tiles of two waves each (the waves of a half deal its chunks alternately), 0 = four waves
+                                // that serve the tile's 64 targets and split its chunks (rounds 2-4) — A/B builds only
+#endif
 #ifndef SPHMI_HALF_INTERLEAVE
 #define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0)
 #endif
@@ -80,16 +84,10 @@ constexpr int kWave = 64;
 // 8 → 1.013e9 / –, 10 (predictor) + 11 (corrector) → 1.050e9 / 1.074e9, 12 → 1.050–1.060e9 / 1.097e9, 13 → 1.052e9 / 1.089e9,
 // 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
 // The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
-// Eight waves per tile (the smallest cases) scan one or two chunks each: six entries hold everything a wave ever queues — eight, because
-// in split mode (ForceParams::split) a wave queues its share of EVERY chunk of the tile and drains in bursts like the large kernels.
-// (not the fp64 kernel of the run-time models: its three sets of partial sums take 43 KB, and two workgroups per compute unit — handles of
-// 256 to 400 tiles — matter more than the split)
-template <class T, int WPT, int MODEL> constexpr bool split_capable() { return WPT >= 8 && SPHMI_LDS_STAGE == 0 && !(sizeof(T) == 8 && MODEL < 0); }
-// Half tiles (two waves per tile, fp32): ten entries — measured at 1.06 M / 323 k / 159 k / 90 k particles (µs per step): 8 → 922 / 312 / 187 /
-// 132, 10 → 914 / 316 / 192 / 133, 12 → 915 / 316 / 192 / 135, 14 → 951, 16 → 1020.
+// Eight waves per tile (the smallest cases; four waves per half tile) scan every fourth chunk of their half: eight entries.
 template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
     // (fp64 half tiles: 10 / 12 / 16 / 20 entries all within 0.5 % of each other at 1.06 M / 159 k / 70 k particles: sixteen stay)
-    return WPT >= 8 ? (split_capable<T, WPT, MODEL>() ? 8 : 6) : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? 10 : 12));
+    return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? 10 : 12));
 }
 constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
 
@@ -228,8 +226,6 @@ struct ForceParams {
     T Klam;              // 4·m₀·ν₀ (Laminar)
     T sps_cs2, sps_blin; // (Cs·dx)², (2/3)·C_Blin·dx² (LaminarSPS)
     double hyd_a, hyd_b; // ComplexDensityDiffusion: ρᴴ(z) = ρ₀·(⁷√(1 + hyd_a·z) − 1), hyd_a = ρ₀·g/Cb, hyd_b = ρ₀
-    int split;           // tiles of eight waves: 1 = every wave takes a share of EVERY chunk's accepted pairs (k_neighbor_force, "split mode"), 0 = a
-                         // wave keeps the pairs of the chunks it scanned.  Chosen by the engine once per upload (Engine::split_mode).
 };
 
 // ------------------------------------------------------------------------------------------
@@ -450,9 +446,14 @@ k_neighbor_force(const ForceParams<T> P) {
     // tile share nothing — no partial sums in LDS, no barrier — and a target's pairs are dealt half-chunk by half-chunk instead of chunk
     // by chunk: 159 k particles ran 93.8 pair-loop iterations per wave for 67.6 pairs per lane (72 % of the lane slots; one wave per
     // tile: 90 %).
-    constexpr bool kHalf = WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
+    // Four-wave tiles (launches of 512 … 850 tiles) are two half tiles of TWO waves: the waves of a half deal its chunks alternately and the
+    // second hands its sums to the first through LDS — the lanes of a target still share every chunk they scan.
+    constexpr bool kHalf = (WPT == 2 || ((WPT == 4 || WPT == 8) && SPHMI_HALF4 != 0)) && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
+    constexpr int kPar = kHalf ? WPT / 2 : 1;               // waves per half tile
     const int hl = kHalf ? (lane >> 5) : 0;                 // which 32 candidates of a chunk this lane takes
-    const int t0 = kHalf ? b * kWave + 32 * wv : b * kWave;
+    const int half = kHalf ? (wv & 1) : 0;                  // which half of the tile this wave serves
+    [[maybe_unused]] const int par = kHalf ? (wv >> 1) : 0; // … and which of the half's waves it is
+    const int t0 = kHalf ? b * kWave + 32 * half : b * kWave;
     const int a = kHalf ? t0 + (lane & 31) : t0 + lane;
     const bool valid = a < P.N;
     const int ac = valid ? a : P.N - 1;
@@ -537,7 +538,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // hands lane half h the rows 8g + 4h + k (g = 0 … 7, k = 0 … 3) of a chunk loaded in natural order, so bit p = 4g + k is candidate
     // 8g + k = p + (p & ~3) behind the base cb + 4h — the two lanes of a target take alternate groups of four candidates and their
     // pair counts differ by a handful instead of by half a cell (one v_and + one v_add per pair)
-    constexpr bool kInterleave = WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 && SPHMI_HALF_INTERLEAVE != 0;
+    constexpr bool kInterleave = kHalf && SPHMI_HALF_INTERLEAVE != 0;
     auto bit_offset = [](const unsigned m) -> unsigned {
         const unsigned p = (unsigned)__builtin_ctz(m);
         if constexpr (kInterleave) return p + (p & 0x1Cu); else return p;
@@ -861,12 +862,6 @@ k_neighbor_force(const ForceParams<T> P) {
         else if constexpr (kPipe) run_pairs_piped(keep, drain);
         else run_pairs_plain(keep, drain, std::bool_constant<kTwoPairs>());
     };
-    // split mode (below): a wave's queue entries hold one or two bits — ONE pair per iteration (a second slot would run for the few
-    // lanes that have one and be waited for by all: Dambreak3d Dp0.02 in fp64 88 against 79 µs per step)
-    [[maybe_unused]] auto run_pairs_split = [&](const int keep, const bool drain) __attribute__((always_inline)) {
-        if constexpr (sizeof(T) == 4 && MODEL >= 0) run_pairs_piped(keep, drain);
-        else run_pairs_plain(keep, drain, std::false_type());
-    };
 
     // ---- phase 1: one 64-candidate chunk against the 64 targets of the tile → one 64-bit accept mask
     // per lane (= per target).  fp32: the 64×64 matrix |c−t|² − H'² comes from the matrix cores
@@ -929,7 +924,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // every row's range look-up one after the other (≈0.8 µs each; tools/trace_small.py).  The waves of the tile need the
     // same ranges: with four or more waves they fetch them TOGETHER — row s by wave s % WPT, all requests in flight at once —
     // and share them in LDS (two-wave tiles keep their own look-ups: sharing costs them 6 %).
-    constexpr bool kShareRanges = WPT >= 4;
+    constexpr bool kShareRanges = WPT >= 4 && !kHalf;
     __shared__ int2 s_rng[kShareRanges ? NSEG * kWave : 1];
     if constexpr (kShareRanges) {
 #pragma unroll
@@ -947,68 +942,6 @@ k_neighbor_force(const ForceParams<T> P) {
             *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
         }
     };
-    // Split mode (tiles of eight waves, ForceParams::split).  A target's neighbours sit in the two or three chunks that cover its own
-    // cells, so dealing whole chunks to the waves leaves most lanes of every wave idle and one or two waves of the tile with all the
-    // work of a lane (Dambreak3d Dp0.02: waves of interior tiles ran 50-58 two-pair iterations against a mean of 19).
-    // Here the waves still scan the tile's chunks in turn, but the accept masks go to a table in LDS, and after one workgroup barrier
-    // EVERY wave takes a share of every chunk: four consecutive bits of each 32-candidate half, rotated by the chunk index — an
-    // eighth of every lane's pairs, give or take the statistics.  Costs one barrier and a walk over the table; pays when a tile has
-    // enough pairs (the engine decides by particles per cell).
-    constexpr bool kSplitCapable = split_capable<T, WPT, MODEL>();
-    constexpr int KC = kSplitCapable ? ((D == 3) ? 40 : 16) : 1;       // chunks per round of the table (a tile of spray has more: rounds)
-    __shared__ uint2 s_tab[KC * kWave];                                  // [chunk][lane]
-    bool split_done = false;
-    if constexpr (kSplitCapable) if (P.split) {
-        split_done = true;
-        // every wave enumerates the tile's chunks alike (the ranges are the tile's, the skip test is the same ballot in every wave):
-        // chunk ci is scanned by wave ci % WPT
-        auto for_chunks = [&](auto&& fn) __attribute__((always_inline)) -> int {
-            int ci = 0;
-#pragma unroll 1
-            for (int seg = 0; seg < NSEG; ++seg) {
-                const int2 rg = s_rng[(kShareRanges ? seg : 0) * kWave + lane];
-                const int lo_l = rg.x, hi_l = rg.y;
-                const int LO = rl_i(lo_l, 0), HI = rl_i(hi_l, last_lane);
-#pragma unroll 1
-                for (int cb = LO; cb < HI; cb += kWave) {
-                    if (__builtin_amdgcn_ballot_w64((lo_l < cb + kWave) & (hi_l > cb)) == 0) continue;      // (as below: no lane's cells)
-                    fn(ci, cb, HI, lo_l, hi_l);
-                    ci += 1;
-                }
-            }
-            return ci;
-        };
-        int w0 = 0, total = 0;
-        do {
-            total = for_chunks([&](const int ci, const int cb, const int HI, const int lo_l, const int hi_l) __attribute__((always_inline)) {
-                if (ci < w0 || ci >= w0 + KC || (ci & (WPT - 1)) != wv) return;
-                const V4 cpk = chunk_packet(cb, HI);
-                unsigned long long m = scan_chunk(cb, HI, cpk);
-                const int b0 = max(lo_l - cb, 0), b1 = min(hi_l - cb, 64);      // MY three cells of this row (quirk Q1)
-                const int w = b1 - b0;
-                const unsigned long long rm = ((~0ull) >> ((64 - w) & 63)) << (b0 & 63);
-                m = (w > 0) ? (m & rm) : 0ull;
-                s_tab[(ci - w0) * kWave + lane] = make_uint2((unsigned)m, (unsigned)(m >> 32));
-                work_ch += 1;
-#ifdef SPHMI_STATS
-                st_chunks += 1;
-#endif
-            });
-            __syncthreads();
-            for_chunks([&](const int ci, const int cb, const int, const int, const int) __attribute__((always_inline)) {
-                if (ci < w0 || ci >= w0 + KC) return;
-                const uint2 mm = s_tab[(ci - w0) * kWave + lane];
-                constexpr int kShare = 32 / WPT;
-                const unsigned pat = ((1u << kShare) - 1u) << (kShare * ((wv + ci) & (WPT - 1)));
-                if (__builtin_amdgcn_ballot_w64(qn > QCAP - 2) != 0) run_pairs_split(QCAP - 1 - kQueueSlack, false);
-                push_entry(mm.x & pat, cb); push_entry(mm.y & pat, cb + 32);
-            });
-            w0 += KC;
-            if (w0 < total) __syncthreads();                       // the table is filled again
-        } while (w0 < total);
-        run_pairs_split(0, true);
-    }
-    if (!split_done) {
 #pragma unroll 1
     for (int seg = 0; seg < NSEG; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
@@ -1038,8 +971,9 @@ k_neighbor_force(const ForceParams<T> P) {
             else first = (wv + WPT - seg % WPT) % WPT;
             g0 = (g0 + (HI > LO ? (HI - LO + kWave - 1) / kWave : 0)) & (WPT - 1);
         }
+        if constexpr (kHalf && kPar > 1) first = (par + seg) & (kPar - 1);       // (the waves of a half take alternate chunks, rotated by row)
 #pragma unroll 1
-        for (int cb = LO + first * kWave; cb < HI; cb += kHalf ? kWave : kWave * WPT) {
+        for (int cb = LO + first * kWave; cb < HI; cb += kHalf ? kWave * kPar : kWave * WPT) {
             // A tile of a sparse region (spray, a thin sheet) spans many cells: the union range of a row is then
             // mostly candidates that belong to NO lane's three cells.  Skip those chunks (two straggler tiles of
             // this kind doubled the launch time of the developed dam break: 1.10 → 0.6x ms).
@@ -1111,8 +1045,7 @@ k_neighbor_force(const ForceParams<T> P) {
             else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }
         }
     }
-        run_pairs(0, true);
-    }
+    run_pairs(0, true);
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
     if constexpr (kHalf) {
@@ -1169,6 +1102,28 @@ k_neighbor_force(const ForceParams<T> P) {
         // (a sampled launch: the tile's work = its slower wave × 2; the table was zeroed in front of the launch)
         tile_work *= WPT;
         if (P.tile_work && lane == 0) atomicMax(&P.tile_work[b], tile_work);
+        if constexpr (kPar > 1) {
+            // two waves per half: the second hands its sums (already those of both lanes of a target) to the first; fixed order
+            constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;
+            constexpr int kSet = (kPar - 1) * 64;                  // entries of one array: [wave of the half − 1][half][target of the half]
+            __shared__ V4 s_hpart[kPartArrays * kSet];
+            const int slot = half * 32 + (lane & 31);
+            if (par > 0 && hl == 0) {
+                const int w = (par - 1) * 64 + slot;
+                V4 o; o.x = ax; o.y = ay; o.z = az; o.w = drho; s_hpart[w] = o;
+                if (shift) { V4 g; g.x = gcx; g.y = gcy; g.z = gcz; g.w = divr; s_hpart[kSet + w] = g; }
+                if (MODEL < 0 && P.kout) { V4 g; g.x = kgx; g.y = kgy; g.z = kgz; g.w = kw; s_hpart[2 * kSet + w] = g; }
+            }
+            __syncthreads();
+            if (par > 0) return;
+#pragma unroll
+            for (int k = 0; k < kPar - 1; ++k) {
+                const V4 o = s_hpart[k * 64 + slot];
+                ax += o.x; ay += o.y; az += o.z; drho += o.w;
+                if (shift) { const V4 g = s_hpart[kSet + k * 64 + slot]; gcx += g.x; gcy += g.y; gcz += g.z; divr += g.w; }
+                if (MODEL < 0 && P.kout) { const V4 g = s_hpart[2 * kSet + k * 64 + slot]; kgx += g.x; kgy += g.y; kgz += g.z; kw += g.w; }
+            }
+        }
     } else if constexpr (WPT > 1) {
         // partial sums of waves 1 … WPT−1: { a, dρ/dt }, and for the run-time variant the shifting and kernel-output sums
         constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;

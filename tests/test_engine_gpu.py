@@ -990,15 +990,14 @@ def test_a_particle_leaving_the_sticky_grid_sends_the_rebuild_to_the_host(dims, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_split_mode_of_the_eight_wave_kernels(split, dam_break_3d_shipped, dam_break_2d_mdbc, monkeypatch):
-    """Tiles of eight waves (launches below 512 tiles) hand their accept masks round through a table in LDS and every wave takes a
-    share of every chunk when the engine expects enough pairs per tile (ForceParams::split, decided once per upload from the
-    particles per occupied cell).  Both modes are forced here — on a crowd whose rows hold more chunks than one round of the table
-    (2-D: 16, 3-D: 40), and over K steps of a layout the rule switches on (Dambreak3d Dp0.02) and of one it leaves off
-    (Dambreak2dMDBC: four particles per cell) — and have to track the fp64 oracle alike."""
+@pytest.mark.parametrize("wpt", ["2", "4", "8"])
+def test_half_tiles_with_several_waves_per_half_on_crowds(wpt, dam_break_3d_shipped, dam_break_2d_mdbc, monkeypatch):
+    """Every kernel of two, four or eight waves per tile serves half tiles (32 targets, two lanes each); with four / eight
+    waves the two / four waves of a half deal its chunks alternately and hand their sums to the first through LDS.  Each is forced
+    here on crowds whose rows hold dozens of chunks (so that every wave of a half gets several, and the queues drain in bursts) and
+    over K steps of a dense and of a sparse layout (Dambreak3d Dp0.02; Dambreak2dMDBC, four particles per cell), against the oracle."""
     from test_oracle import default_2d_setup
-    monkeypatch.setenv("SPHMI_SPLIT", split)
+    monkeypatch.setenv("SPHMI_WPT", wpt)
     rng = np.random.default_rng(7)
     s2 = default_2d_setup()
     n = 2300                                                # 3 cells of one row: 36 chunks per row, 108 per tile
@@ -1034,13 +1033,14 @@ def test_split_mode_of_the_eight_wave_kernels(split, dam_break_3d_shipped, dam_b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wpt", ["2", "4", "8"])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 97, 130, 1000])
-def test_half_tiles_on_ragged_sizes(n, monkeypatch):
-    """Two waves per tile = two HALF tiles of 32 targets with two lanes per target: forced here on particle counts whose
-    last tile leaves the second wave with no target, one target, or a partial set, in 2-D and 3-D, fp32 and fp64 — forces of one
-    evaluation and the state after three steps against the oracle."""
+def test_half_tiles_on_ragged_sizes(n, wpt, monkeypatch):
+    """Half tiles of 32 targets with two lanes per target, one, two or four waves per half: forced here on particle counts
+    whose last tile leaves the waves of the second half with no target, one target, or a partial set, in 2-D and 3-D, fp32 and fp64 —
+    forces of one evaluation and the state after three steps against the oracle."""
     from test_oracle import default_2d_setup
-    monkeypatch.setenv("SPHMI_WPT", "2")
+    monkeypatch.setenv("SPHMI_WPT", wpt)
     rng = np.random.default_rng(100 + n)
     for dims, s in ((2, default_2d_setup()), (3, setup_dam_break_3d(0.02))):
         H = s.SimKernel.H
