@@ -717,6 +717,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // iteration (measured, µs per step one → two pairs: 2-D dam break 35.1 → 32.5, Dambreak3d Dp0.02 84.8 → 76.6, MovingSquare2d
     // 53.0 → 49.4; the 3-D run-time-model kernel at four waves per tile — DucklingMDBC — loses, 147.6 → 157.8: its corrector has
     // no registers left for a second neighbour)
+    // (re-measured with half tiles of two / four waves per half: one pair per iteration is 0 … 7 % slower from 108 to 2 482 tiles, fp64 most)
     constexpr bool kTwoPairs = WPT >= 8 || (WPT >= 4 && (MODEL >= 0 || D == 2));
     // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
     // cell (j < cs_a) or after it inside it (a < j < ce_a)
