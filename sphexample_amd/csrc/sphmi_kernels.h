@@ -10,8 +10,12 @@
 // reference (src/SPHCellList.jl:168-217, 268-317, 367-381, 624-652, 706-724;
 // src/SimulationEquations.jl:9-42; src/TimeStepping.jl:24-46) with ONE launch per pass.
 //
-// Mapping (one TILE = 64 consecutive sorted target particles = one workgroup of 1, 2 or 4 waves; which tile a
-// block takes comes from the tile schedule built with the cell list — sphmi_rebuild.h):
+// Mapping (one TILE = 64 consecutive sorted target particles; which tile a block takes comes from the tile schedule built with
+// the cell list — sphmi_rebuild.h).  The kernels of two, four and eight waves per tile — every default launch since the second half
+// of round 4 — serve a tile as two HALF TILES: a wave holds 32 targets with TWO LANES PER TARGET (lanes l and l + 32), which take
+// alternate groups of four candidates of every chunk the wave scans and add their sums after the loop; a half is worked off by one,
+// two or four waves that deal its chunks in turn (`kHalf`).  One wave per tile with one lane per target is the
+// organisation of rounds 1–4 ($SPHMI_WPT=1; the description below is written for it, the phases are the same):
 //   phase 1  "who is within H".  For each of the 3^(D-1) cell rows around the tile the three x-adjacent
 //            cells of every target are one contiguous particle range (x is the fastest sort axis); the
 //            union over the tile is scanned in 64-candidate chunks, one candidate per lane, loaded
