@@ -1,6 +1,7 @@
 #!/bin/bash
 # Every kernel instantiation of tools/bench_variants.py in this tree and in the previous round's (build/r3tree = `git archive <commit> | tar -x`,
-# library built in place, tools/bench_variants.py copied in), one gpurun call, then the table.   usage (gpurun): bash tools/variants_vs_previous.sh <prev tree> <out md>
+# library built in place, tools/bench_variants.py copied in), one gpurun call, then the table.
+# The next round's reference: mkdir -p build/r4tree && git archive <last commit of round 4> | tar -x -C build/r4tree && (cd build/r4tree && python -m sphexample_amd.build --force)   usage (gpurun): bash tools/variants_vs_previous.sh <prev tree> <out md>
 cd $GRAFT_REPO_ROOT
 prev=${1:-build/r3tree}; out=${2:-gpurun_out/variants_vs_previous.md}
 python tools/bench_variants.py 200 > gpurun_out/variants_head.txt 2>/dev/null
