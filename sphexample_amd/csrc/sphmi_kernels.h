@@ -906,6 +906,9 @@ k_neighbor_force(const ForceParams<T> P) {
         unsigned W[2] = {0u, 0u};
 #pragma unroll
         for (int C = 1; C >= 0; --C) {
+            // (interleaved half tiles: the last chunk of a row is half empty on average — when its candidates 32 … 63 do not exist their
+            // block is not computed; its sixteen bits of every lane stay zero)
+            if (kInterleave && C == 1 && HI - cb <= 32) continue;      // (C3: 890 -> 873 µs per step)
 #pragma unroll
             for (int Tb = 0; Tb < (kHalf ? 1 : 2); ++Tb) {
                 f32x16 d = {0};
