@@ -20,8 +20,8 @@
  *   - vector fields cross the boundary exactly as Julia lays out Vector{SVector{D,T}}:
  *     contiguous AoS, D components interleaved, N*D scalars.
  *   - host scalars are `host_float_bytes` wide (8 for every stock example), device arithmetic is
- *     `device_float_bytes` wide (4 = fp32 kernels, 8 = fp64 kernels); conversion happens in
- *     upload/download.
+ *     `device_float_bytes` wide (4 = fp32 kernels, 8 = fp64 kernels, 0 = the library chooses:
+ *     sphmi_auto_device_float_bytes); conversion happens in upload/download.
  *   - the library installs no signal handlers and never calls back into the host runtime.
  *   - one handle = one simulation; a handle must not be used from two threads at once.  A handle created with a
  *     device list (sphmi_config.n_devices > 1) spreads the simulation over the GPUs of the node — slabs of the domain,
@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SPHMI_ABI_VERSION 4
+#define SPHMI_ABI_VERSION 5
 #define SPHMI_MAX_DEVICES 16
 
 /* status codes */
@@ -73,7 +73,7 @@ typedef struct sphmi_config {
     int32_t abi_version;         /* = SPHMI_ABI_VERSION                                          */
     int32_t dims;                /* Dimensions: 2 or 3                                           */
     int32_t host_float_bytes;    /* FloatType of the host arrays: 4 or 8                         */
-    int32_t device_float_bytes;  /* arithmetic type of the kernels: 4 or 8                       */
+    int32_t device_float_bytes;  /* arithmetic type of the kernels: 4, 8, or 0 = chosen by the library (sphmi_auto_device_float_bytes) */
     int32_t kernel;              /* SPHMI_KERNEL_*                                               */
     int32_t viscosity;           /* SPHMI_VISC_*                                                 */
     int32_t density_diffusion;   /* SPHMI_DDT_*                                                  */
@@ -124,6 +124,16 @@ const char* sphmi_last_error(const sphmi_handle* h);
  * src/SPHCellList.jl:825,837,840-844 (support arrays, per-thread copies, ParticleRanges,
  * UniqueCells, CellDict, sort scratch). */
 int sphmi_create(const sphmi_config* cfg, sphmi_handle** out);
+
+/* The arithmetic `device_float_bytes = 0` resolves to for this configuration: 4 (fp32 kernels, double-float state) when every term of
+ * the path is continuous in the positions — the kernel support ends where the kernel and its gradient vanish (H >= 2h, the default
+ * k = 2 of src/SPHKernels.jl:57-60, so nothing jumps at the r^2 <= H^2 cut of src/SPHCellList.jl:275) and there is no mDBC; 8 (fp64
+ * kernels) when the kernel is cut off before it vanishes (k < 2: example/DucklingMDBC.jl, example/MovingSquare2d.jl) or mDBC is on
+ * (src/SPHCellList.jl:598-622: "no neighbour -> keep", the Shepard fallback and the |det A| >= 1e-3 switch are discontinuities) — there
+ * an fp32 trajectory takes the other branch a step early or late and leaves the reference's state by more than 1e-5 on single
+ * particles.  sphmi_device_float_bytes: what a handle runs. */
+int32_t sphmi_auto_device_float_bytes(const sphmi_config* cfg);
+int sphmi_device_float_bytes(const sphmi_handle* h, int32_t* device_float_bytes_out);
 int sphmi_destroy(sphmi_handle* h);
 
 /*

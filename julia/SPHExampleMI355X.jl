@@ -18,7 +18,10 @@
 # MotionLimiter and BoundaryBool are per-particle constants and follow the same gather, Cells are written in place
 # (a CartesianIndex{D} is D Int64s).  The gathers run while the copies are in flight.
 #
-# Environment: SPHMI_LIB (path of libsphmi.so), SPHMI_DEVICE_FLOAT_BYTES (4 = fp32 kernels, default; 8 = fp64),
+# Environment: SPHMI_LIB (path of libsphmi.so), SPHMI_DEVICE_FLOAT_BYTES (0, default = the library chooses — fp32 kernels when every
+# term of the path is continuous: the kernel vanishes at its cut-off, SimKernel.k >= 2, and BMode is NoMDBC (Dambreak3d.jl); fp64
+# kernels for DucklingMDBC.jl / MovingSquare2d.jl (k < 2) and every SimpleMDBC run (sphmi_auto_device_float_bytes, include/sphmi.h);
+# 4 = fp32; 8 = fp64),
 # SPHMI_DEVICES ("0" default; "0,1,2,3,4,5,6,7" = one slab per GPU, halos over RCCL — same calls, see sphmi.h).
 #
 # EXPERIMENTAL: the build image has no Julia, so this file has never been executed.  struct layout and ABI version
@@ -29,7 +32,7 @@ using SPHExample, StaticArrays, TimerOutputs
 import SPHExample.SPHCellList: SimulationLoop, next_output_time
 
 const LIB = get(ENV, "SPHMI_LIB", "libsphmi.so")
-const ABI_VERSION = Int32(4)
+const ABI_VERSION = Int32(5)
 
 struct SphmiConfig                       # struct sphmi_config, field for field (include/sphmi.h)
     struct_size::Int32; abi_version::Int32; dims::Int32; host_float_bytes::Int32; device_float_bytes::Int32
@@ -78,7 +81,7 @@ pin(h, a::Array) = isempty(a) || ccall((:sphmi_host_register, LIB), Cint, (Ptr{C
 function open_session(SimDensityDiffusion, SimViscosity, SimKernel, SimMetaData::SimulationMetaData{D,T,S,K,B,L}, SimConstants, P, MotionDefinition) where {D,T,S,K,B,L}
     devs = parse.(Int32, split(get(ENV, "SPHMI_DEVICES", "0"), ","))
     N = length(P)
-    cfg = SphmiConfig(sizeof(SphmiConfig), ABI_VERSION, D, sizeof(T), parse(Int32, get(ENV, "SPHMI_DEVICE_FLOAT_BYTES", "4")),
+    cfg = SphmiConfig(sizeof(SphmiConfig), ABI_VERSION, D, sizeof(T), parse(Int32, get(ENV, "SPHMI_DEVICE_FLOAT_BYTES", "0")),
                       SimKernel.kernel isa CubicSpline ? 1 : 0, tag(SimViscosity), tag(SimDensityDiffusion), B <: SimpleMDBC ? 1 : 0,
                       devs[1], S <: PlanarShifting ? 1 : 0, K <: StoreKernelOutput ? 1 : 0, N, 0,
                       SimConstants.ρ₀, SimConstants.dx, SimConstants.m₀, SimConstants.α, SimConstants.g, SimConstants.c₀,

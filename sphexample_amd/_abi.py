@@ -13,7 +13,7 @@ import numpy as np
 from .config import (NoMDBC, SimpleMDBC, SimulationConstants, SimulationMetaData, SPHDensityDiffusion,
                      SPHKernelInstance, SPHViscosity)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DEVICES = 16
 
 OK, ERR_ARGUMENT, ERR_DEVICE, ERR_NUMERIC, ERR_DOMAIN, ERR_STATE = range(6)
@@ -52,12 +52,13 @@ class SphmiError(RuntimeError):
 
 def make_config(n_particles: int, SimConstants: SimulationConstants, SimKernel: SPHKernelInstance,
                 SimMetaData: SimulationMetaData, SimViscosity: SPHViscosity,
-                SimDensityDiffusion: SPHDensityDiffusion, *, device_float_bytes: int = 4,
+                SimDensityDiffusion: SPHDensityDiffusion, *, device_float_bytes: int = 0,
                 host_float_bytes: int = 8, device: int = 0, max_cells: int = 0) -> SphmiConfig:
     """Flatten the reference's configuration objects into the C parameter block.
 
     Model tags the engine does not implement raise here, which is where the Julia shim falls back
-    to the stock CPU path."""
+    to the stock CPU path.  device_float_bytes: 4 / 8, or 0 = the library chooses
+    (`sphmi_auto_device_float_bytes`: fp32 kernels when H >= 2h without mDBC, fp64 when the kernel is cut off before it vanishes or mDBC is on)."""
     for tag, what in ((SimViscosity, "viscosity"), (SimDensityDiffusion, "density diffusion")):
         if getattr(tag, "abi_value", None) is None:
             raise NotImplementedError(f"{type(tag).__name__}: {what} model not implemented by the engine")

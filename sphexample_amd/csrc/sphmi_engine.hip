@@ -1658,9 +1658,9 @@ struct sphmi_handle { sphmi::EngineBase* e; };
 
 extern "C" {
 
-static_assert(SPHMI_ABI_VERSION == 4, "update the text of sphmi_backend_info");
+static_assert(SPHMI_ABI_VERSION == 5, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
-    return "sphmi abi 4 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
+    return "sphmi abi 5 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
            "counting-sort cell list, mDBC, moving bodies, shifting | multi-device handles: slabs over device copies / RCCL "
            "(RCCL transport not yet run with more than one rank) | no CPU fallback";
 }
@@ -1677,6 +1677,12 @@ static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, cons
     auto fail = [&](int st, const std::string& m) { g_create_error = m; return st; };
     if (!cfg || !out) return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: null argument");
     std::string why;
+    if (cfg->struct_size != (int32_t)sizeof(sphmi_config) || cfg->abi_version != SPHMI_ABI_VERSION)
+        return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: struct_size / abi_version mismatch");
+    // device_float_bytes = 0: the library chooses the arithmetic (sphmi_auto_device_float_bytes, include/sphmi.h)
+    sphmi_config resolved = *cfg;
+    if (resolved.device_float_bytes == 0) resolved.device_float_bytes = sphmi_auto_device_float_bytes(cfg);
+    cfg = &resolved;
     // slabs the particle set is spread over: sphmi_create_rank's world, or the device list of sphmi_create
     if (int st = check_config(cfg, rank >= 0 ? std::max(world, 1) : std::max(cfg->n_devices, 1), why)) return fail(st, why);
     try {
@@ -1700,6 +1706,27 @@ static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, cons
     catch (const std::exception& x) { return fail(SPHMI_ERR_DEVICE, x.what()); }
 }
 
+// The precision policy of `device_float_bytes = 0` (include/sphmi.h): fp32 kernels where every term of the path is CONTINUOUS in the
+// particle positions, fp64 kernels where the reference's algorithm has a discontinuity that fp32 state decides differently:
+//  * a kernel cut off BEFORE it vanishes (H = k·h, k < 2: example/DucklingMDBC.jl 1.5, example/MovingSquare2d.jl sqrt 2) — a pair at
+//    r ~ H switches a finite force on or off (src/SPHCellList.jl:275), lattices with spacing H/2 put thousands of pairs exactly on
+//    r = H, and fp32 handles leave the 1e-5 of the fp64 path within tens of steps.  With H >= 2h Wendland C2 and the cubic spline vanish
+//    with their gradients at the cut: a pair that fp32 rounding puts on the other side contributes (nearly) nothing either way;
+//  * mDBC (src/SPHCellList.jl:598-622): a ghost node keeps its density when it has no fluid neighbour, takes rho := b1/A11 — a 0/0 — when
+//    its only neighbour sits at r ~ H, and switches between the full solve and that fallback at |det A| = 1e-3; an fp32 trajectory
+//    (x off by 1e-7) crosses those lines a step early or late and freezes a different density into single boundary particles (1e-4
+//    relative on a handful of them in a streaming Dambreak2dMDBC; every fluid particle stays within 4e-6).
+// Measured on every stock example: BASELINE.md section 4, profiles/r05_fp32_examples_parity.md; tests/test_example_precision_gpu.py.
+int32_t sphmi_auto_device_float_bytes(const sphmi_config* cfg) {
+    if (!cfg) return 0;
+    const bool vanishes_at_cut = cfg->H >= 2.0 * cfg->h * (1.0 - 1e-12);
+    return (vanishes_at_cut && cfg->mdbc == SPHMI_MDBC_NONE) ? 4 : 8;
+}
+int sphmi_device_float_bytes(const sphmi_handle* h, int32_t* out) {
+    if (!h || !h->e || !out) return SPHMI_ERR_ARGUMENT;
+    *out = h->e->cfg.device_float_bytes;
+    return SPHMI_OK;
+}
 int sphmi_create(const sphmi_config* cfg, sphmi_handle** out) { return create_any(cfg, -1, 0, nullptr, out); }
 int sphmi_create_rank(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out) {
     if (rank < 0) { sphmi::g_create_error = "sphmi_create_rank: negative rank"; return SPHMI_ERR_ARGUMENT; }

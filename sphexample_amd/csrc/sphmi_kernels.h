@@ -432,18 +432,28 @@ k_neighbor_force(const ForceParams<T> P) {
     // Tile schedule (sphmi_rebuild.h): the dispatcher places block b on XCD b % 8; every XCD works through
     // one contiguous, cost-balanced run of tiles, expensive tiles first.  Measured on the 1 M-particle dam
     // break: equal-count contiguous runs 1.02 ms, 64-tile round-robin chunks 1.10 ms, identity 1.13 ms.
+    constexpr bool kHalf = (WPT == 2 || ((WPT == 4 || WPT == 8) && SPHMI_HALF4 != 0)) && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
+    constexpr int kPar = kHalf ? WPT / 2 : 1;               // waves per half tile
+    // waves of one workgroup may leave early for DIFFERENT reasons while others go on to a workgroup barrier (see below)
+    constexpr bool kMixedExit = (kHalf && kPar > 1) || (!kHalf && WPT > 1 && TPB > 1);
+    bool dead = false;
     int b;
     {
         const int x = blockIdx.x & 7, r = TPB == 1 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * TPB + tib;
-        // (Early returns and the workgroup barriers further down — TPB > 1 with WPT = 2, and kShareRanges: the waves of ONE tile
-        // return here, at the all-ghost test or on a cancelled step TOGETHER (the conditions are per tile or per launch), while the
-        // waves of the block's OTHER tile go on to `__syncthreads()`.  In the HIP model a barrier that not every thread of the block
-        // reaches is undefined; on gfx9 / CDNA `s_barrier` counts the waves of the workgroup that have not terminated — an ended wave
-        // is taken out of the barrier's count by the hardware ("s_endpgm" releases it) — and this kernel is built for gfx950 only.
-        // The tests force every WPT / TPB variant on layouts with partial last blocks and ghost-only tiles
-        // (test_every_waves_per_tile_variant_matches_the_oracle, tests/test_multi_gpu.py).)
-        if (r >= P.part[8 + x]) return;
-        b = P.order[P.part[x] + r];
+        // (Early exits and the workgroup barriers further down.  A cancelled step ends every wave of the launch; an exhausted XCD run or a
+        // tile of ghosts only ends the waves of ONE tile — or, with half tiles, of one HALF.  Where such waves share a workgroup with waves
+        // that go on to a `__syncthreads()` (`kMixedExit`: half tiles worked off by two or four waves, and the chunk-splitting builds with
+        // two tiles per block) they do not return: they are marked `dead`, scan no row, queue no pair, store nothing, and reach every
+        // barrier of the block like the others — a barrier that not every thread of the block reaches is undefined in the HIP model,
+        // whatever gfx9's `s_endpgm` does to the barrier count (rounds 2-4 relied on that).  Everywhere else the exit is uniform over
+        // the workgroup or the kernel has no barrier, and the waves simply return.
+        // test_every_waves_per_tile_variant_matches_the_oracle and tests/test_multi_gpu.py force every WPT / TPB variant on layouts
+        // with partial last blocks and ghost-only tiles.)
+        if (r >= P.part[8 + x]) {
+            if constexpr (TPB == 1 || !kMixedExit) return;      // (one tile per block: the whole workgroup leaves here)
+            dead = true;
+        }
+        b = dead ? 0 : P.order[P.part[x] + r];
     }
     // kHalf (tiles of two waves): wave w serves targets 32w … 32w+31 of the tile, TWO LANES PER TARGET — lane l and lane l + 32 hold the
     // same target and take the lower / upper 32 candidates of every chunk (what the matrix layout hands each lane half anyway: one
@@ -453,8 +463,6 @@ k_neighbor_force(const ForceParams<T> P) {
     // tile: 90 %).
     // Four-wave tiles (launches of 512 … 850 tiles) are two half tiles of TWO waves: the waves of a half deal its chunks alternately and the
     // second hands its sums to the first through LDS — the lanes of a target still share every chunk they scan.
-    constexpr bool kHalf = (WPT == 2 || ((WPT == 4 || WPT == 8) && SPHMI_HALF4 != 0)) && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
-    constexpr int kPar = kHalf ? WPT / 2 : 1;               // waves per half tile
     const int hl = kHalf ? (lane >> 5) : 0;                 // which 32 candidates of a chunk this lane takes
     const int half = kHalf ? (wv & 1) : 0;                  // which half of the tile this wave serves
     [[maybe_unused]] const int par = kHalf ? (wv >> 1) : 0; // … and which of the half's waves it is
@@ -465,9 +473,12 @@ k_neighbor_force(const ForceParams<T> P) {
     // ghost copies (type bits 0xC0: owned by a neighbour rank) take part as neighbours only: their own
     // state arrives by halo exchange, so they get no accept masks, and nothing is stored or reduced for them
     const uint8_t ty_raw = P.type[ac];
-    const bool owned = valid && !(ty_raw & 0xC0);
-    const unsigned long long owned_lanes = __builtin_amdgcn_ballot_w64(owned);
-    if (owned_lanes == 0) return;                                 // a tile of ghosts only
+    const bool owned = !dead && valid && !(ty_raw & 0xC0);
+    unsigned long long owned_lanes = __builtin_amdgcn_ballot_w64(owned);
+    if (owned_lanes == 0) {                                       // a tile (a half) of ghosts only
+        if constexpr (!kMixedExit) return;
+        dead = true; owned_lanes = 1;                             // (lane_o below: any lane — a dead wave computes nothing that is kept)
+    }
 
     // target data
     const V4 q0 = P.src0[ac];
@@ -951,8 +962,9 @@ k_neighbor_force(const ForceParams<T> P) {
             *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
         }
     };
+    const int nseg = dead ? 0 : NSEG;                   // (a dead wave scans nothing: empty queues, zero sums, no stores — it only keeps the barriers whole)
 #pragma unroll 1
-    for (int seg = 0; seg < NSEG; ++seg) {
+    for (int seg = 0; seg < nseg; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
         int lo_l, hi_l;
         if constexpr (kShareRanges) { const int2 rg = s_rng[seg * kWave + lane]; lo_l = rg.x; hi_l = rg.y; }
@@ -1110,7 +1122,7 @@ k_neighbor_force(const ForceParams<T> P) {
     if constexpr (kHalf) {
         // (a sampled launch: the tile's work = its slower wave × 2; the table was zeroed in front of the launch)
         tile_work *= WPT;
-        if (P.tile_work && lane == 0) atomicMax(&P.tile_work[b], tile_work);
+        if (P.tile_work && lane == 0 && !dead) atomicMax(&P.tile_work[b], tile_work);
         if constexpr (kPar > 1) {
             // two waves per half: the second hands its sums (already those of both lanes of a target) to the first; fixed order
             constexpr int kPartArrays = MODEL >= 0 ? 1 : 3;
@@ -1164,7 +1176,7 @@ k_neighbor_force(const ForceParams<T> P) {
             if (MODEL < 0 && P.kout) { const V4 g = s_part[(2 * (WPT - 1) + k) * kWave + lane]; kgx += g.x; kgy += g.y; kgz += g.z; kw += g.w; }
         }
     }
-    if (!kHalf && P.tile_work && lane == 0) P.tile_work[b] = tile_work;
+    if (!kHalf && P.tile_work && lane == 0 && !dead) P.tile_work[b] = tile_work;
     // ---- epilogue ---------------------------------------------------------------------------
     // (the pre-test reading of the reduction slots is issued first: it comes from beyond the XCD's L2 and is needed last)
 

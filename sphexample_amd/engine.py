@@ -84,6 +84,14 @@ class Engine(Backend):
         self._check(self._lib.sphmi_multi_info_get(self._h, C.byref(info)))
         return info
 
+    @property
+    def device_float_bytes(self) -> int:
+        """The arithmetic this handle runs (the resolution of `device_float_bytes = 0`)."""
+        n = C.c_int32()
+        self._lib.sphmi_device_float_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._check(self._lib.sphmi_device_float_bytes(self._h, C.byref(n)))
+        return n.value
+
     def owned_count(self) -> int:
         n = C.c_int64()
         self._lib.sphmi_owned_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -118,9 +126,12 @@ class Engine(Backend):
         return ms.value, n.value
 
 
-def make_engine(particles, setup, device_float_bytes: int = 4, device: int = 0, devices=None, slab_axis: int = None,
+def make_engine(particles, setup, device_float_bytes: int = 0, device: int = 0, devices=None, slab_axis: int = None,
                 cuts=None, rank: int = None, world: int = None, unique_id: bytes = None) -> Engine:
     """Engine for a SimParticles + CaseSetup pair, with the particles uploaded.
+    device_float_bytes: 4 (fp32 kernels), 8 (fp64 kernels) or 0 — the library's policy (`sphmi_auto_device_float_bytes`: fp32 where
+    the kernel vanishes at its cut-off, H >= 2h, and there is no mDBC; fp64 for k < 2 — DucklingMDBC, MovingSquare2d — and for
+    mDBC handles); `Engine.device_float_bytes` tells.
     devices=[0, 1, …]: one slab per listed GPU, all inside this handle (an ordinal may repeat: slabs sharing a GPU).
     rank= / world= / unique_id=: this process holds slab `rank` on GPU `device`; every process uploads the full set."""
     host_bytes = np.dtype(particles.FloatType).itemsize

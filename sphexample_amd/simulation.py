@@ -37,7 +37,7 @@ def RunSimulation(*, SimGeometry=None, SimMetaData: SimulationMetaData, SimConst
                   SimViscosity: SPHViscosity, SimDensityDiffusion: SPHDensityDiffusion,
                   ParticleNormalsPath: Optional[str] = None,
                   on_output: Optional[Callable[[SimulationMetaData, SimParticles], None]] = None,
-                  device_float_bytes: int = 4, device: int = 0, backend_factory=None,
+                  device_float_bytes: int = 0, device: int = 0, backend_factory=None,
                   async_output: bool = False) -> List[float]:
     """Same keyword signature as the reference (src/SPHCellList.jl:808-817); returns the list of
     time steps the reference collects in ``TimeSteps`` (:823,:884).  ``SimParticles`` is updated in

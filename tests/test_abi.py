@@ -126,3 +126,29 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not bad.search(text), f"{f} references the oracle"
+
+
+def test_precision_policy_of_the_stock_examples():
+    """`device_float_bytes = 0` (the default of make_engine and of the Julia shim): sphmi_auto_device_float_bytes chooses fp32 kernels where
+    every term of the path is continuous (the kernel vanishes at its cut-off, SimKernel.k >= 2, and no mDBC) and fp64 kernels where the
+    kernel is cut off earlier — example/DucklingMDBC.jl (k = 1.5), example/MovingSquare2d.jl (k = sqrt 2) — or mDBC is on; no device
+    needed.  What the choice rests on: tests/test_example_precision_gpu.py."""
+    import dataclasses
+    from sphexample_amd import cases
+    from sphexample_amd.config import NoMDBC
+    from sphexample_amd.engine import load_library
+    lib = load_library()
+    lib.sphmi_auto_device_float_bytes.argtypes = [C.POINTER(SphmiConfig)]
+    lib.sphmi_auto_device_float_bytes.restype = C.c_int32
+    cfg_of = lambda s: make_config(100, s.SimConstants, s.SimKernel, s.SimMetaData, s.SimViscosity, s.SimDensityDiffusion)  # noqa: E731
+    want = {"setup_dam_break_2d": 4, "setup_dam_break_2d_mdbc": 8, "setup_still_wedge_mdbc": 8, "setup_still_wedge_middle_square_mdbc": 8,
+            "setup_duckling_mdbc": 8, "setup_moving_square_2d": 8}
+    for name, fb in want.items():
+        cfg = cfg_of(getattr(cases, name)())
+        assert cfg.device_float_bytes == 0
+        assert lib.sphmi_auto_device_float_bytes(C.byref(cfg)) == fb, name
+    assert lib.sphmi_auto_device_float_bytes(C.byref(cfg_of(cases.setup_dam_break_3d(0.00425)))) == 4
+    # the two reasons, separately: StillWedge without mDBC is an fp32 case, DucklingMDBC without mDBC still is not (k = 1.5)
+    off = lambda s: dataclasses.replace(s, SimMetaData=dataclasses.replace(s.SimMetaData, BMode=NoMDBC))  # noqa: E731
+    assert lib.sphmi_auto_device_float_bytes(C.byref(cfg_of(off(cases.setup_still_wedge_mdbc())))) == 4
+    assert lib.sphmi_auto_device_float_bytes(C.byref(cfg_of(off(cases.setup_duckling_mdbc())))) == 8
