@@ -468,10 +468,13 @@ struct Engine final : EngineBase {
     // which multiplies by Kv2 per pair.  One predicate for the kernel choice and for inv_Kv2 (round-3 advice).
     T kv2() const { return (T)(2.0 * cfg.m0 * cfg.alpha * cfg.c0 * cfg.h); }
     bool kv2_foldable() const { const T k = kv2(); return std::isnormal(k) && std::isfinite(T(1) / k) && std::isnormal(T(1) / k); }
+    // … and evaluate Pressure! of a neighbour as ρ⁷·(Cb/γ/ρ₀⁷) − Cb/γ (fp32 kernels: ρ⁷ must stay finite up to 4ρ₀, the constant normal)
+    T cbe7() const { return (T)(((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0) / std::pow(cfg.rho0, 7.0)); }
+    bool eos_foldable() const { return sizeof(T) == 8 || (std::pow(4.0 * cfg.rho0, 7.0) < 1e37 && std::isnormal(cbe7())); }
     bool compiled_in_model() const {
         // the models of the stock examples; a kernel cut off before it vanishes (k < 2) takes the variant with the per-pair cut
         return cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR && cfg.shifting == SPHMI_SHIFT_NONE &&
-               cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE && kv2_foldable();
+               cfg.kernel == SPHMI_KERNEL_WENDLAND_C2 && cfg.kernel_output == SPHMI_KOUT_NONE && kv2_foldable() && eos_foldable();
     }
     ForceParams<T> force_params(int src, int a, int out, double dt) const {
         ForceParams<T> P{};
@@ -510,6 +513,7 @@ struct Engine final : EngineBase {
         P.rho0 = (T)cfg.rho0; P.inv_rho0 = (T)(1.0 / cfg.rho0);
         P.g = (T)cfg.g;
         P.Cbe = (T)((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0);
+        P.Cbe7 = eos_foldable() ? cbe7() : T(0);
         return P;
     }
 

@@ -74,7 +74,24 @@ constexpr int kWave = 64;
                                 // that serve the tile's 64 targets and split its chunks (rounds 2-4) — A/B builds only
 #endif
 #ifndef SPHMI_HALF_INTERLEAVE
-#define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0)
+#define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate SINGLE candidates (2: the chunk is loaded permuted inside its groups of eight,
+                                // bit p of an entry is candidate 2p behind the entry's base — no index arithmetic per pair, and the two lanes gather neighbouring
+                                // records), alternate groups of FOUR candidates (1: round 4), or the lower / upper 32 of a chunk (0) — 0 / 1: A/B builds only
+#endif
+#ifndef SPHMI_LOOP_UNROLL
+#define SPHMI_LOOP_UNROLL 2     // fp32 pair loop (one pair per iteration): iterations per loop test (1: rounds 1-4)
+#endif
+#ifndef SPHMI_FAST_PAIR
+#define SPHMI_FAST_PAIR 1       // fp32 kernels of the compiled-in models: pair_fast (one reciprocal per pair, transcendentals back to back, lane constants out of
+                                // the loop — round 5); 0 = pair_core for every kernel (rounds 1-4), A/B builds
+#endif
+#ifndef SPHMI_PACKED
+#define SPHMI_PACKED 0          // pair_fast with {dx, dy}, {dvx, dvy}, {r², v·x}, {ax, ay} and {Σ continuity, Σ diffusion} in v_pk_*_f32 on the register pairs
+                                // the b128 gathers deliver: measured SLOWER (−1.3 %), kept as an A/B build
+#endif
+#ifndef SPHMI_ALIGN_LO
+#define SPHMI_ALIGN_LO 0        // half tiles with groups of four: the chunks of a row start at a multiple of four records, so that the four candidates a lane
+                                // takes in turn are ONE 128-byte line (four 32-byte records) instead of parts of two lines it shares with its partner lane
 #endif
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
@@ -226,6 +243,7 @@ struct ForceParams {
     T dt, dt2;
     T H2, h, h_inv, Cgw, m0, Kddt, linfac, eta2, Kv2, rho0, inv_rho0, g, Cbe;
     T nhinv_half, Cfac, big;   // −1/(2h);  −8·Cgw: ∇W factor = Cfac·u³ with u = clamp(1 − q/2);  2⁴⁰ (step01)
+    T Cbe7;                    // Cb/γ ÷ ρ₀⁷: Pressure! of a neighbour's ρ⁺ as ρ⁷·Cbe7 − Cb/γ (packed pair loop of the corrector; the host routes handles whose ρ₀⁷ leaves fp32 to the run-time variant)
     T inv_Kv2;                 // 1 / Kv2 (the compiled-in model accumulates in units of Kv2; handles whose Kv2 is not a normal number run the run-time variant)
     T alphaD, tens_eps, inv_Wdx;   // CubicSpline: αD, CubicSpline.eps, 1 / W(q := dx) (src/SPHKernels.jl:114-126)
     T Klam;              // 4·m₀·ν₀ (Laminar)
@@ -245,6 +263,17 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return y;
 }
 __device__ __forceinline__ float  fast_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
+// The two transcendentals of the fp32 pair (round 5), issued BACK TO BACK and followed by a scalar instruction: on gfx950 a transcendental among
+// double-rate instructions (v_mul / v_add / v_fma: 2.6 cycles per wave64 instruction and SIMD) costs ≈12 cycles where it stands alone and 8.5 behind
+// another one (tools/ubench/issue_patterns.hip, loop_replay.hip); the s_nop is also the wait state a VALU instruction needs before it reads a
+// transcendental's result (the compiler cannot see into an asm).
+__device__ __forceinline__ void sqrt_and_rcp(const float a, const float b, float& sqrt_a, float& rcp_b) {
+#if defined(SPHMI_TRANS_SPLIT)
+    asm("v_sqrt_f32 %0, %2\n\ts_nop 0\n\tv_rcp_f32 %1, %3\n\ts_nop 0" : "=&v"(sqrt_a), "=v"(rcp_b) : "v"(a), "v"(b));
+#else
+    asm("v_sqrt_f32 %0, %2\n\tv_rcp_f32 %1, %3\n\ts_nop 0" : "=&v"(sqrt_a), "=v"(rcp_b) : "v"(a), "v"(b));
+#endif
+}
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }   // (v_rsq_f64 + Newton: no faster)
 
 __device__ __forceinline__ float  absT(float x)  { return __builtin_fabsf(x); }
@@ -274,6 +303,10 @@ __device__ __forceinline__ float fma1_clamp01(float a, float b) {
     // transcendental needs one wait state on gfx950 — the compiler pads its own instructions but cannot see into an asm
     float r; asm("s_nop 0\n\tv_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "s"(b)); return r;
 }
+// (the same when `a` comes out of sqrt_and_rcp, whose trailing s_nop already is the wait state)
+__device__ __forceinline__ float fma1_clamp01_ready(float a, float b) {
+    float r; asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "s"(b)); return r;
+}
 __device__ __forceinline__ double fma1_clamp01(double a, double b) {
     const double t = __builtin_fma(a, b, 1.0);
     return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
@@ -283,6 +316,26 @@ __device__ __forceinline__ float step01(float s, float big) {
     float r; asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(s), "s"(big)); return r;
 }
 __device__ __forceinline__ double step01(double s, double) { return s > 0.0 ? 1.0 : 0.0; }
+
+// Packed fp32 (v_pk_*_f32: two lanes of a 64-bit register pair per instruction, at the price of ONE v_fma_f32 — tools/ubench/valu_rates2.hip).
+// Inline asm: the compiler's own packing (SLP, DAG combines) pairs values that sit in different register pairs and pays for it in v_mov /
+// v_pk_mov shuffles (-fno-slp-vectorize); here only operands that ARE adjacent — the {x, y} / {vx, vy} halves of a gathered b128, or
+// the results of two scalar instructions written side by side — are packed.  None of these reads the result of a transcendental (that
+// needs a wait state the compiler cannot see into an asm for).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+// { a.x·b.x + c.x, a.x·b.y + c.y }: the LOW half of `a` multiplies both halves of `b` (op_sel_hi: no broadcast copy)
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
 
 // 16-/32-byte packet gathers through buffer loads: 32-bit offsets, one address instruction per gather
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -554,10 +607,17 @@ k_neighbor_force(const ForceParams<T> P) {
     // hands lane half h the rows 8g + 4h + k (g = 0 … 7, k = 0 … 3) of a chunk loaded in natural order, so bit p = 4g + k is candidate
     // 8g + k = p + (p & ~3) behind the base cb + 4h — the two lanes of a target take alternate groups of four candidates and their
     // pair counts differ by a handful instead of by half a cell (one v_and + one v_add per pair)
+    // (round 5, kSingles: the chunk is loaded PERMUTED inside its groups of eight — the lane that feeds matrix row 8g + 4h + k loads candidate
+    // 8g + 2k + h — so bit p = 4g + k of lane half h is candidate 2p + h: the two lanes of a target take alternate single candidates, the
+    // record offset of a pair is ONE shift-add on the bit number, and the two lanes gather neighbouring 32-byte records at the same time)
     constexpr bool kInterleave = kHalf && SPHMI_HALF_INTERLEAVE != 0;
-    auto bit_offset = [](const unsigned m) -> unsigned {
+    constexpr bool kSingles = kInterleave && SPHMI_HALF_INTERLEAVE == 2;
+    // record offset of the candidate at the lowest set bit of m, for an entry whose bit 0 sits at record offset `base`
+    auto rec_of = [](const unsigned m, const unsigned base) -> unsigned {
         const unsigned p = (unsigned)__builtin_ctz(m);
-        if constexpr (kInterleave) return p + (p & 0x1Cu); else return p;
+        if constexpr (kSingles) return (p << (kRecShift + 1)) + base;
+        else if constexpr (kInterleave) return ((p + (p & 0x1Cu)) << kRecShift) + base;
+        else return (p << kRecShift) + base;
     };
     const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
     // `if_i` when the target plays "i", `if_j` otherwise
@@ -694,8 +754,91 @@ k_neighbor_force(const ForceParams<T> P) {
             divr += (fluid_a && s_b > T(0)) ? dv : T(0);
         }
     };
+    // ---- the same pair for the fp32 kernels of the compiled-in models (ArtificialViscosity + LinearDensityDiffusion, kFoldKv2): round 5.
+    // Same terms as pair_core; what differs is how they are evaluated:
+    //  * ONE reciprocal per pair: inv = 1/(ρ_b·(r²+η²)(ρ̄ₐ+ρ̄_b)) [corrector: ·ρⁿ_b as well]; 1/ρ_b, 1/((r²+η²)ρ̄) [and 1/ρⁿ_b] are inv times the
+    //    other factors — two (three) transcendentals become multiplies, and the remaining two are issued back to back (sqrt_and_rcp);
+    //  * the density-diffusion sum runs without its lane constant Kd_a (applied once after the loop);
+    //  * Pressure! of a neighbour's ρ⁺ (corrector) as ρ⁷·(Cb/γ/ρ₀⁷) − Cb/γ: no scaling multiply;
+    //  * SPHMI_PACKED (off): {dx, dy}, {dvx, dvy}, {r², v·x}, {ax, ay}, {Σ continuity, Σ diffusion} in v_pk_*_f32 — measured slower: on gfx950
+    //    v_fma_f32 runs at the double rate like v_mul / v_add, a packed instruction at the full rate, so two FMAs cost what one packed FMA costs, and a
+    //    packed instruction among double-rate ones slows its neighbours (tools/ubench/pk_rates.hip).
+    constexpr bool kFast = kFoldKv2 && MODEL >= 0 && ((MODEL >> 4) & 15) == kDdtLinear && SPHMI_FAST_PAIR != 0;
+    constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5;      // (the diagnostic builds that keep the arithmetic)
+    constexpr bool kPacked = kFast && SPHMI_PACKED != 0;
+    [[maybe_unused]] f32x2 p_txy, p_tvxy, p_axy = {0.0f, 0.0f}, p_scd = {0.0f, 0.0f};
+    if constexpr (kPacked) { p_txy = f32x2{(float)xa, (float)ya}; p_tvxy = f32x2{(float)q1.x, (float)q1.y}; }
+    [[maybe_unused]] auto pair_fast = [&](const V4& n0, const V4& n1, const bool a_is_i) {
+        if constexpr (kFast) {
+            float dx, dy, dz = 0.0f, r2, vdx;
+            [[maybe_unused]] f32x2 dxy;
+            if constexpr (kPacked) {
+                dxy = pk_sub(p_txy, f32x2{n0.x, n0.y});                                 // { dx, dy }
+                const f32x2 dvxy = pk_sub(p_tvxy, f32x2{n1.x, n1.y});                   // { dvx, dvy }
+                const f32x2 sq = pk_mul(dxy, dxy), ab = pk_mul(dxy, dvxy);              // { dx², dy² }, { dx·dvx, dy·dvy }
+                dx = dxy.x; dy = dxy.y;
+                if constexpr (D == 3) {
+                    const f32x2 dzz = {za - n0.z, q1.z - n1.z};                         // { dz, dvz }: two scalar subtracts written side by side
+                    float s2x = sq.x + sq.y, s2y = ab.x + ab.y;
+                    asm("" : "+v"(s2x), "+v"(s2y));     // (keeps the two adds scalar: combined into one v_pk_add_f32 they cost three v_mov to line the operands up)
+                    const f32x2 rv = pk_fma_lo(dzz, dzz, f32x2{s2x, s2y});              // { dz·dz + …, dz·dvz + … } = { r², vᵢⱼ·xᵢⱼ }
+                    dz = dzz.x; r2 = rv.x; vdx = rv.y;
+                } else { r2 = sq.x + sq.y; vdx = ab.x + ab.y; }
+            } else {
+                dx = xa - n0.x; dy = ya - n0.y;
+                const float dvx = q1.x - n1.x, dvy = q1.y - n1.y;
+                if constexpr (D == 3) {
+                    dz = za - n0.z;
+                    const float dvz = q1.z - n1.z;
+                    r2 = dx * dx + dy * dy + dz * dz; vdx = dvx * dx + dvy * dy + dvz * dz;
+                } else { r2 = dx * dx + dy * dy; vdx = dvx * dx + dvy * dy; }
+            }
+            float rho_b, rhon_b, s_b;
+            if constexpr (PASS == PASS_CORRECTOR) { rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w; }
+            else { rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; }
+            const float rs = rhon_a + rhon_b;
+            const float prod = (r2 + P.eta2) * rs;
+            float r, inv, inv_rho_b, inv_rhon_b, inv_r2e_rs;
+            if constexpr (PASS == PASS_CORRECTOR) {
+                const float qq = rho_b * rhon_b;
+                sqrt_and_rcp(r2, qq * prod, r, inv);
+                const float pq = inv * prod;
+                inv_rho_b = pq * rhon_b; inv_rhon_b = pq * rho_b; inv_r2e_rs = inv * qq;
+            } else {
+                sqrt_and_rcp(r2, rho_b * prod, r, inv);
+                inv_rho_b = inv * prod; inv_rhon_b = inv_rho_b; inv_r2e_rs = inv * rho_b;
+            }
+            const float u = fma1_clamp01_ready(r, P.nhinv_half);
+            float fac = (u * u) * u;
+            if constexpr ((MODEL & kModelCutBit) != 0) fac = (r2 <= P.H2) ? fac : 0.0f;
+            const float inv_r2e = inv_r2e_rs * rs;
+            const float cairb = c_a * inv_rho_b;
+            // density diffusion, src/SPHDensityDiffusionModels.jl:100-136 with the orientation rule Q4 (Kd_a after the loop)
+            const float drn = (rhon_b - rhon_a) - P.linfac * (D == 3 ? dz : dy);
+            const float inv_sel = a_is_i ? inv_rhon_b : inv_rhon_a;
+            const float Dv = inv_sel * (drn * (fac * (r2 * inv_r2e)));
+            const float on = step01(s_b, P.big);
+            if constexpr (kPacked) p_scd = pk_fma(f32x2{cairb, on}, f32x2{fac * vdx, Dv}, p_scd);    // (the continuity sum in units of c_a: no transcendental's result read by the asm)
+            else { sum_c += inv_rho_b * (fac * vdx); sum_d += Dv * on; }
+            // pressure (src/SPHCellList.jl:301-303) + ArtificialViscosity (src/SPHViscosityModels.jl:56-74)
+            float Psum;
+            if constexpr (PASS == PASS_CORRECTOR) {
+                const float x2 = rho_b * rho_b, x3 = x2 * rho_b, x6 = x3 * x3, x7 = x6 * rho_b;
+                Psum = x7 * P.Cbe7 + PaC;
+            } else Psum = P_a + n1.w;
+            const float vneg = min_raw(vdx, 0.0f);
+            float coef = Psum * cairb + vneg * inv_r2e_rs;
+            coef *= fac;
+            if constexpr (kPacked) {
+                f32x2 c2; c2.x = coef;                       // (the high half is never read — op_sel_hi — and stays undefined: no copy)
+                p_axy = pk_fma_lo(c2, dxy, p_axy);
+            } else { ax += coef * dx; ay += coef * dy; }
+            if constexpr (D == 3) az += coef * dz;
+        }
+    };
     // 2-D handles keep z = vz = 0: the z terms are dropped at compile time
     auto pair = [&](const unsigned jr, const V4& n0, const V4& n1, const bool a_is_i) {
+        if constexpr (kFast && kFastDiag) { pair_fast(n0, n1, a_is_i); return; }
 #if SPHMI_DIAG == 1 || SPHMI_DIAG == 4
         // DIAGNOSTIC BUILD (wrong results): the gathers without the arithmetic — the floor set by the gather path
         sum_c += n0.x + n1.x;
@@ -736,7 +879,9 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr bool kTwoPairs = WPT >= 8 || (WPT >= 4 && (MODEL >= 0 || D == 2));
     // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
     // cell (j < cs_a) or after it inside it (a < j < ce_a)
-    auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr > a_r) & (jr < ce_ar))); };
+    // (the range a < j < ce_a as ONE unsigned compare of j − (a + 1) against ce_a − (a + 1): a subtract and two compares instead of three compares)
+    const unsigned a_r1 = a_r + (1u << kRecShift), w_ai = ce_ar - a_r1;
+    auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr - a_r1) < w_ai)); };
     // "current mask used up AND something queued" is ONE unsigned compare, cm < qf with qf = min(qn, 1): the 0 / 1 flag is kept up
     // to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration.  The loop tests are
     // computed once per iteration, at its END (a hand-rotated do … while: written top-tested the compiler copied six accumulators
@@ -764,8 +909,8 @@ k_neighbor_force(const ForceParams<T> P) {
                 cm = m1 & (m1 - 1);
                 if (m != 0) {
                     const bool two = m1 != 0;
-                    const unsigned jr0 = (bit_offset(m) << kRecShift) + cbase;
-                    const unsigned jr1 = two ? (bit_offset(m1) << kRecShift) + cbase : jr0;
+                    const unsigned jr0 = rec_of(m, cbase);
+                    const unsigned jr1 = two ? rec_of(m1, cbase) : jr0;
                     const V4 n0a = gather_packet(rs0, jr0, 0, T());
                     const V4 n1a = gather_packet(rs0, jr0, 1, T());
                     const V4 n0b = gather_packet(rs0, jr1, 0, T());
@@ -776,7 +921,7 @@ k_neighbor_force(const ForceParams<T> P) {
             } else {
                 cm = m & (m - 1);                                    // (0 stays 0)
                 if (m != 0) {
-                    const unsigned jr = (bit_offset(m) << kRecShift) + cbase;      // record size × the neighbour's index
+                    const unsigned jr = rec_of(m, cbase);      // record size × the neighbour's index
                     const V4 n0 = gather_packet(rs0, jr, 0, T());
                     const V4 n1 = gather_packet(rs0, jr, 1, T());
                     pair(jr, n0, n1, plays_i(jr));
@@ -796,9 +941,11 @@ k_neighbor_force(const ForceParams<T> P) {
     constexpr bool kPipe = (sizeof(T) == 4 || WPT == 2) && !kTwoPairs && SPHMI_LDS_STAGE == 0;
     [[maybe_unused]] bool pv = false;
     [[maybe_unused]] unsigned pjr = 0;
+    // (round 5: the loop test — a compare, a ballot and a branch — once per TWO iterations, SPHMI_LOOP_UNROLL: a burst may run one iteration longer than it
+    // had to, which only moves a pair from the next burst into this one; the copy that rotated `cm` goes with it)
     auto run_pairs_piped = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         unsigned qf = qn != 0 ? 1u : 0u;
-        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
+        auto iteration = [&]() __attribute__((always_inline)) {
             work_it += 1;
 #ifdef SPHMI_STATS
             st_it += 1; st_lane += __builtin_popcountll(__builtin_amdgcn_ballot_w64(pv));
@@ -823,7 +970,8 @@ k_neighbor_force(const ForceParams<T> P) {
             if (cm < qf) {
                 const uint2 ne = *reinterpret_cast<const uint2*>(s_qb + raddr);
                 m = ne.x; raddr = q_next(raddr); qn -= 1;
-                qf = min((unsigned)qn, 1u);
+                if constexpr (sizeof(T) == 4) asm("v_min_u32 %0, %1, 1" : "=v"(qf) : "v"(qn));      // (one instruction; the compiler makes a compare + select of min(qn, 1))
+                else qf = min((unsigned)qn, 1u);
                 cbase = ne.y;
             }
             cm = m & (m - 1);
@@ -831,9 +979,13 @@ k_neighbor_force(const ForceParams<T> P) {
             // (meaningless without pv.  __builtin_ctz(0) is a POISON value in clang — llvm.cttz with is_zero_poison — not immediate
             // undefined behaviour: it is harmless as long as nothing consumes it, and every use of pjr sits under `if (v)`.  An inline
             // `v_ffbl_b32`, defined for 0, pins the LDS wait in front of the arithmetic and measured −0.5 %.)
-            pjr = (bit_offset(m) << kRecShift) + cbase;
+            pjr = rec_of(m, cbase);
             // 3. the arithmetic
             if (v) pair(jr, n0, n1, plays_i(jr));
+        };
+        if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
+            iteration();
+            if constexpr (SPHMI_LOOP_UNROLL == 2 && sizeof(T) == 4) iteration();
         } while (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0);
     };
     // the two-pair loop with the addresses of the NEXT one or two neighbours worked out while the four gathers fly (compiled-in
@@ -866,8 +1018,8 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned m1 = m & (m - 1);
             cm = m1 & (m1 - 1);
             pv = m != 0; pv2 = m1 != 0;
-            pjr = (bit_offset(m) << kRecShift) + cbase;
-            pjr2 = pv2 ? (bit_offset(m1) << kRecShift) + cbase : pjr;
+            pjr = rec_of(m, cbase);
+            pjr2 = pv2 ? rec_of(m1, cbase) : pjr;
             if (v0) {
                 pair(jr0, n0a, n1a, plays_i(jr0));
                 if (v1) pair(jr1, n0b, n1b, plays_i(jr1));
@@ -887,7 +1039,8 @@ k_neighbor_force(const ForceParams<T> P) {
     // column for 16 candidate rows per 32×32 block; their sign bits are shifted into a word with
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
-    const int bperm = kInterleave ? lane : (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+    const int bperm = kSingles ? ((lane & ~7) | ((lane & 3) << 1) | ((lane >> 2) & 1))
+                    : kInterleave ? lane : (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
     float B0[2], B1[2], B2[2], A2;
     if constexpr (kHalf) {
         // lanes l and l + 32 hold the same target: the operand layout without an exchange, one target block
@@ -974,13 +1127,17 @@ k_neighbor_force(const ForceParams<T> P) {
             hi_l = valid ? P.cstart[key_a + off + 2] : 0;
         }
         // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
-        const int LO = rl_i(lo_l, 0);
+        const int LO = (SPHMI_ALIGN_LO != 0 && kInterleave) ? (rl_i(lo_l, 0) & ~(SPHMI_ALIGN_LO * 4 - 1)) : rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
         // kInterleave: this lane's candidates of the chunk at cb are cb + 4·hl + 8g + k (g = 0 … 7, k = 0 … 3); how many of them sit below a
         // bound X relative to cb + 4·hl: below(X) = 4·(X >> 3) + min(X & 7, 4) (floor shift: exact for negative X too), and a chunk further on
         // it is 32 less — so the range of MY cells' bits is worked out once per row and moved by 32 per chunk
         [[maybe_unused]] int row_b0 = 0, row_b1 = 0;
-        if constexpr (kInterleave) {
+        if constexpr (kSingles) {
+            // (this lane's candidates are cb + hl + 2p: below(X) = ceil(X / 2), floor shift: exact for negative X too)
+            auto below = [](const int X) -> int { return (X + 1) >> 1; };
+            row_b0 = below(lo_l - LO - hl); row_b1 = below(hi_l - LO - hl);
+        } else if constexpr (kInterleave) {
             auto below = [](const int X) -> int { return 4 * (X >> 3) + min(X & 7, 4); };
             row_b0 = below(lo_l - LO - 4 * hl); row_b1 = below(hi_l - LO - 4 * hl);
         }
@@ -1061,12 +1218,15 @@ k_neighbor_force(const ForceParams<T> P) {
                 continue;
             }
 #endif
-            if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
+            if constexpr (kSingles) push_entry((unsigned)m, cb + hl);
+            else if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
             else if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
             else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }
         }
     }
     run_pairs(0, true);
+    if constexpr (kPacked && kFastDiag) { ax = p_axy.x; ay = p_axy.y; sum_c = p_scd.x / c_a; sum_d = p_scd.y; }
+    if constexpr (kFast && kFastDiag) sum_d *= Kd_a;
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
     if constexpr (kHalf) {
