@@ -56,7 +56,7 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 # 157.3 TFLOP/s fp32 vector peak when every instruction is an FMA; MI355X_MICROARCH.md).  The SQ "busy" counter charges a
 # quad-cycle per instruction instead (measured issue cost of most of this kernel's instructions: tools/ubench/valu_rates2.hip).
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
-COUNTER_RECORD = "profiles/r04_counters.json"
+COUNTER_RECORD = "profiles/r05_counters.json"
 DP1 = 0.00425
 BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 2, 2>", "corrector": "k_neighbor_force<float, 3, 2, 33, 2, 2>"}
 
@@ -299,6 +299,7 @@ def main():
     args = ap.parse_args()
 
     launch = os.environ.get("SPHMI_BENCH_LAUNCH", "")
+    spawn_failure = None
     if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # Started like the N = 1 line (`python bench.py --gpus N …`): the ranks are started here; a launcher that cannot be
         # started (or ranks that fail) leaves the one-process handle over the N GPUs — a line comes out either way.
@@ -310,6 +311,7 @@ def main():
         args.single_process = True
         launch = (f"one process, one multi-device handle: bench.py was started without a launcher, its self-spawned "
                   f"torch.distributed.run ranks failed (exit code {rc})")
+        spawn_failure = rc
     import torch
     rank = int(os.environ.get("RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,7 +453,10 @@ def main():
         achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic, valu, refused = counters_for(identity, n_local, kern_ms)
         out = {
-            "metric": "particle-updates/sec (3D dam-break)", "value": value, "unit": "particle-updates/s",
+            "metric": "particle-updates/sec (3D dam-break)", "value": value,
+            # the same W + K window on a handle that starts on an idle device (no pre-conditioning) — next to `value`, so that nobody reads one without the other
+            "value_cold": cold["value"] if cold else (value if not pre_steps else None),
+            "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -474,7 +479,9 @@ def main():
                          "kernel": "k_neighbor_force", "avg_launch_ms": kern_ms,
                          # two launches per step (predictor, corrector); the average is taken over HIP-event pairs on every 8th
                          # step (an event pair costs a stream bubble), each weighted 8: `launch_time_samples` is that weighted count
-                         "launches": 2 * args.steps, "launch_time_samples": kern_launches,
+                         # `launches_expected`: predictor + corrector of every step of the window (edge-list launches of slab handles and steps the
+                         # device-side control cancelled are not counted); `launch_time_samples`: the weighted count avg_launch_ms was averaged over
+                         "launches_expected": 2 * args.steps, "launch_time_samples": kern_launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "valu": valu, "kernel_identity": identity},
             "value_excl_rebuild": n_total * args.steps / max(elapsed - rebuild_s, 1e-9),
             "rebuild_ms_in_window": rebuild_s * 1e3,
@@ -482,10 +489,9 @@ def main():
         if refused:
             out["roofline"]["counters_refused"] = refused
         if cold:
-            out["value_cold"] = cold["value"]
             out["cold_window"] = cold
-        elif not pre_steps:
-            out["value_cold"] = value
+        if spawn_failure is not None:
+            out["fallback_from_failed_ranks_exit_code"] = spawn_failure        # (the line below was measured by ONE process: its ranks could not be started)
         if plain and not args.no_extras and not args.dp:
             for name, fn in (("fp64", lambda: extra_fp64(device, args.warmup, args.steps)),
                              ("developed_window", lambda: extra_developed(device)), ("parity", lambda: extra_parity(device))):

@@ -278,6 +278,10 @@ int sphmi_force_kernel_stats(sphmi_handle* h, int reset, double* avg_ms_out, int
  * this is how the rank-mode driver runs — and is tested — with more ranks than GPUs.  Every wait has a deadline
  * (SPHMI_SHM_TIMEOUT seconds, default 120). */
 int sphmi_rccl_unique_id(void* id_out /* 128 bytes */);
+/* Binds RCCL in this process (dlopen + every symbol the slab driver calls) WITHOUT asking it for an id: ncclGetUniqueId starts a
+ * bootstrap root — a listening socket and a thread — per call, so only the rank that hands the id out should call it; the other ranks
+ * check with this that their process could join.  SPHMI_ERR_DEVICE + sphmi_last_error(NULL) when RCCL is out of reach. */
+int sphmi_rccl_probe(void);
 int sphmi_create_rank(const sphmi_config* cfg, int32_t rank, int32_t world, const void* unique_id, sphmi_handle** out);
 int sphmi_owned_count(sphmi_handle* h, int64_t* n_out);   /* particles sphmi_download returns (any handle)        */
 typedef struct sphmi_multi_info {

@@ -1747,6 +1747,12 @@ int sphmi_rccl_unique_id(void* id_out) {
     } catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
     catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_DEVICE; }
 }
+int sphmi_rccl_probe(void) {
+    using namespace sphmi;
+    try { (void)Rccl::get(); return SPHMI_OK; }      // dlopen + every symbol the slab driver calls; no bootstrap root, no thread, no socket
+    catch (const EngineError& x) { g_create_error = x.what(); return x.status; }
+    catch (const std::exception& x) { g_create_error = x.what(); return SPHMI_ERR_DEVICE; }
+}
 int sphmi_shm_selftest(const void* unique_id, int32_t rank, int32_t world, int64_t n_bytes) {
     using namespace sphmi;
     if (!unique_id || world < 1 || rank < 0 || rank >= world || n_bytes < 0) return SPHMI_ERR_ARGUMENT;

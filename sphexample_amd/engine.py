@@ -64,6 +64,14 @@ def rccl_unique_id() -> bytes:
     return buf.raw
 
 
+def rccl_probe() -> None:
+    """RCCL binds in this process (no id is made: `ncclGetUniqueId` starts a bootstrap root — a socket and a thread — per call)."""
+    lib = load_library()
+    rc = lib.sphmi_rccl_probe()
+    if rc != OK:
+        raise SphmiError(rc, (lib.sphmi_last_error(None) or b"").decode())
+
+
 class Engine(Backend):
     """One simulation behind the C ABI (`include/sphmi.h`): on one GPU, on the GPUs of `cfg.devices` (slabs of the
     domain, all driven by this process), or — `rank=` — one slab of a run whose other slabs live in other processes."""
@@ -178,4 +186,4 @@ def make_generated_dam_break_engine(dp: float, setup, device_float_bytes: int = 
     return e
 
 
-__all__ = ["Engine", "make_engine", "make_generated_dam_break_engine", "dam_break_3d_count", "load_library", "backend_info", "rccl_unique_id", "SphmiError", "SphmiMultiInfo"]
+__all__ = ["Engine", "make_engine", "make_generated_dam_break_engine", "dam_break_3d_count", "load_library", "backend_info", "rccl_unique_id", "rccl_probe", "SphmiError", "SphmiMultiInfo"]

@@ -98,25 +98,33 @@ class Rendezvous:
                 self._dist.destroy_process_group()
 
 
-def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSPORT", preflight=None, timeout: float = None):
+def library_check(shm: bool) -> None:
+    """The default local check of create_rank_engine: libsphmi.so loads (and is built first when stale), RCCL binds."""
+    from .engine import load_library, rccl_probe
+    load_library()
+    if not shm:
+        rccl_probe()                                  # dlopen + symbols only — no ncclGetUniqueId: that starts a bootstrap root per call
+
+
+def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSPORT", preflight=None, timeout: float = None,
+                       local_check=library_check, make_id=None):
     """One slab engine per rank with the id handed round, COLLECTIVELY: every rank learns whether all ranks succeeded.
     `make(unique_id)` builds this rank's engine (sphexample_amd.engine.make_engine(..., rank=, world=, unique_id=)).
-    Returns (engine | None, list of the ranks' error texts).  The id is RCCL's (sphmi_rccl_unique_id on rank 0) unless the
-    shared-memory transport is selected in the environment, where any 128 random bytes do.
+    Returns (engine | None, list of the ranks' error texts).  The id is RCCL's (sphmi_rccl_unique_id, asked for ONCE, on rank 0)
+    unless the shared-memory transport is selected in the environment, where any 128 random bytes do; `make_id` overrides both
+    (a caller with its own engine factory).
 
     Two phases (round-3 advice: a rank that failed BEFORE ncclCommInitRank left its peers waiting inside it for ever):
-      1. local — everything that can fail without a peer: the library loads, RCCL binds (every rank asks for an id of its own
-         and throws it away), `preflight()` of the caller (device present, memory for the slab …).  All ranks agree on the
-         outcome (all_ok) BEFORE anyone enters the communicator set-up.
+      1. local — everything that can fail without a peer: `local_check(shm)` (default: the library loads, RCCL binds — without
+         making an id; None: nothing, for callers whose `make` does not go through libsphmi) and `preflight()` of the caller
+         (device present, memory for the slab …).  All ranks agree on the outcome (all_ok) BEFORE anyone enters the communicator set-up.
       2. collective — `make(uid)`.  A communicator set-up that cannot reach a peer does not fail, it waits: `timeout` seconds
          (or $SPHMI_SETUP_TIMEOUT) arm a watchdog that ends the process with a message and exit code 3."""
-    from .engine import load_library, rccl_unique_id
     shm = os.environ.get(transport_env) == "shm"
     err = ""
     try:
-        load_library()
-        if not shm:
-            rccl_unique_id()                          # binds librccl in this process: a missing symbol shows here, on every rank
+        if local_check is not None:
+            local_check(shm)
         if preflight is not None:
             preflight()
     except Exception as exc:                          # noqa: BLE001
@@ -127,7 +135,13 @@ def create_rank_engine(rdv: Rendezvous, make, transport_env: str = "SPHMI_TRANSP
     uid = None
     if rdv.rank == 0:
         try:
-            uid = os.urandom(128) if shm else rccl_unique_id()
+            if make_id is not None:
+                uid = make_id()
+            elif shm:
+                uid = os.urandom(128)
+            else:
+                from .engine import rccl_unique_id
+                uid = rccl_unique_id()
         except Exception as exc:                      # noqa: BLE001 — every rank must learn it, not hang
             err = f"rank 0: sphmi_rccl_unique_id: {exc}"
     uid = rdv.broadcast_bytes(uid, src=0)

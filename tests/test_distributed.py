@@ -193,17 +193,27 @@ def _rendezvous_worker(rank, world, port, out_dir):
         if rank == world - 1:
             raise RuntimeError("no device for this rank")
         made.append(Fake()); return made[-1]
-    eng, errs = create_rank_engine(rdv, make)
+    # (Fake engines: the default local check — libsphmi.so loads, RCCL binds — is not theirs; a caller with its own factory switches it off)
+    eng, errs = create_rank_engine(rdv, make, local_check=None)
     ok &= eng is None and errs == [f"rank {world - 1}: no device for this rank"] and all(f.closed for f in made)
-    eng, errs = create_rank_engine(rdv, lambda uid: Fake())
+    eng, errs = create_rank_engine(rdv, lambda uid: Fake(), local_check=None)
     ok &= isinstance(eng, Fake) and errs == []
+    # a caller's own id: asked for ONCE, on rank 0 (ncclGetUniqueId starts a bootstrap root per call)
+    ids = []
+    eng, errs = create_rank_engine(rdv, lambda uid: Fake(), local_check=None, make_id=lambda: ids.append(1) or b"\x05" * 128)
+    ok &= isinstance(eng, Fake) and len(ids) == (1 if rank == 0 else 0)
+    # the default local check is injectable and its failure is a LOCAL failure
+    def broken(shm):
+        raise RuntimeError("libsphmi.so is missing")
+    eng, errs = create_rank_engine(rdv, lambda uid: Fake(), local_check=broken if rank == 1 else None)
+    ok &= eng is None and errs == ["rank 1 (local set-up): libsphmi.so is missing"]
     # a rank that fails in its LOCAL phase (no device, no memory, library missing) is learnt by every rank BEFORE anyone enters the
     # collective set-up: make() — where a real rank would sit in ncclCommInitRank waiting for the missing peer — is never called
     entered = []
     def preflight():
         if rank == 0:
             raise RuntimeError("no memory for this slab")
-    eng, errs = create_rank_engine(rdv, lambda uid: entered.append(1) or Fake(), preflight=preflight)
+    eng, errs = create_rank_engine(rdv, lambda uid: entered.append(1) or Fake(), preflight=preflight, local_check=None)
     ok &= eng is None and errs == ["rank 0 (local set-up): no memory for this slab"] and not entered
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("1" if ok else "0")
     rdv.close()
