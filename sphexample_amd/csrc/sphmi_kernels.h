@@ -78,6 +78,10 @@ constexpr int kWave = 64;
                                 // bit p of an entry is candidate 2p behind the entry's base — no index arithmetic per pair, and the two lanes gather neighbouring
                                 // records), alternate groups of FOUR candidates (1: round 4), or the lower / upper 32 of a chunk (0) — 0 / 1: A/B builds only
 #endif
+#ifndef SPHMI_SMALL_TRIMS
+#define SPHMI_SMALL_TRIMS 1     // launches of four and eight waves per tile (a few hundred waves, 10 µs): the epilogue's loads requested at the wave's start, no
+                                // pre-test in front of the reduction atomics (round 5); 0: A/B builds
+#endif
 #ifndef SPHMI_LOOP_UNROLL
 #define SPHMI_LOOP_UNROLL 2     // fp32 pair loop (one pair per iteration): iterations per loop test (1: rounds 1-4)
 #endif
@@ -386,13 +390,18 @@ template <class T> __device__ __forceinline__ T wave_max(T v) {
 }
 // max-reduction of non-negative values through their bit patterns (monotone for v ≥ 0; NaN sorts last).
 // Almost every wave is below the running maximum already: test before paying for the atomic.
-__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, float v) {
+// (`pretest` = false, round 5: the launches of EIGHT waves per tile — below 330 tiles, a few hundred waves — send the atomic at once (with four waves per tile, 500-850 tiles, the atomics of 3 000 waves on three counters cost MovingSquare2d 9 % and DucklingMDBC 15 %): the pre-test is a
+// device-scope load, ≈1 µs beyond the XCD's L2, that every wave WAITS for at the end of its life, and a launch of 108 tiles has nothing to
+// save on 650 atomics; tools/trace_small.py: the corrector's epilogue 3.2 → … µs on the 2-D dam break)
+__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, float v, bool pretest = true) {
     unsigned int* q = reinterpret_cast<unsigned int*>(p);
     const unsigned int b = __float_as_uint(v);
+    if (!pretest) { if (b != 0u) atomicMax(q, b); return; }
     if (b > __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q, b);
 }
-__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v) {
+__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v, bool pretest = true) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    if (!pretest) { if (b != 0ull) atomicMax(p, b); return; }
     if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
 }
 
@@ -548,6 +557,16 @@ k_neighbor_force(const ForceParams<T> P) {
         rhon_a = rho_a;
         s_a = q0.w;
         P_a = q1.w;                                     // Pressure! ran before mDBC (quirk Q3)
+    }
+    // (round 5, launches of four and eight waves per tile: the corrector's epilogue reads state A and the low words of this lane's particle — requested
+    // HERE, a whole pass ahead of their use, instead of as one more exposed round trip at the end of a wave whose life is 10 µs; twelve
+    // registers that those kernels have to spare, the large launches do not)
+    constexpr bool kEarlyEpilogueLoads = PASS == PASS_CORRECTOR && WPT >= 4 && SPHMI_SMALL_TRIMS != 0;
+    [[maybe_unused]] V4 pre_s0, pre_s1, pre_lo;
+    if constexpr (kEarlyEpilogueLoads) {
+        pre_s0 = P.a0[ac]; pre_s1 = P.a1[ac];
+        pre_lo.x = pre_lo.y = pre_lo.z = pre_lo.w = T(0);
+        if (sizeof(T) == 4 && P.comp != nullptr) pre_lo = P.comp[ac];
     }
     const bool fluid_a = s_a > T(0);
     const T inv_rho_a = fast_rcp(rho_a);
@@ -1361,13 +1380,13 @@ k_neighbor_force(const ForceParams<T> P) {
     } else {
         // LimitDensityAtBoundary!(Density) → DensityEpsi! → FullTimeStep
         // (src/SPHCellList.jl:794-798, 640-652; src/SimulationEquations.jl:28-33)
-        const V4 s0 = P.a0[ac];
-        const V4 s1 = P.a1[ac];
+        V4 s0, s1;
+        if constexpr (kEarlyEpilogueLoads) { s0 = pre_s0; s1 = pre_s1; } else { s0 = P.a0[ac]; s1 = P.a1[ac]; }
         // fp32 handles integrate ρ and x as double-floats (ForceParams::comp): state = what the record holds + the low word
         constexpr bool kComp = sizeof(T) == 4;
         const bool comp_on = kComp && P.comp != nullptr;
         V4 lo4; lo4.x = lo4.y = lo4.z = lo4.w = T(0);
-        if (comp_on) lo4 = P.comp[ac];
+        if constexpr (kEarlyEpilogueLoads) lo4 = pre_lo; else if (comp_on) lo4 = P.comp[ac];
         const T epsi = -(drho / rho_a) * step_dt;
         T rho_new;
         [[maybe_unused]] double rho_new_d = 0.0;
@@ -1426,7 +1445,7 @@ k_neighbor_force(const ForceParams<T> P) {
         // every lane holds the three maxima: lanes 0, 1, 2 serve one slot each — ONE pre-test load and ONE atomic instruction
         // per wave instead of three dependent round trips to the coherence point (a device-scope load is served beyond the
         // XCD's L2; the epilogue of a lone wave: 5.3 → 4.1 µs, tools/trace_small.py)
-        if (lane < 3) atomic_max_bits(&P.red[lane], lane == 0 ? disp2 : (lane == 1 ? vis : a2));
+        if (lane < 3) atomic_max_bits(&P.red[lane], lane == 0 ? disp2 : (lane == 1 ? vis : a2), /*pretest=*/WPT < 8 || SPHMI_SMALL_TRIMS == 0);
     }
 #if defined(SPHMI_STATS) || defined(SPHMI_TRACE)
     if (lane == 0 && wv == 0 && P.trace) {
