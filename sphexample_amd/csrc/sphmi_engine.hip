@@ -1720,7 +1720,7 @@ static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, cons
 //    its only neighbour sits at r ~ H, and switches between the full solve and that fallback at |det A| = 1e-3; an fp32 trajectory
 //    (x off by 1e-7) crosses those lines a step early or late and freezes a different density into single boundary particles (1e-4
 //    relative on a handful of them in a streaming Dambreak2dMDBC; every fluid particle stays within 4e-6).
-// Measured on every stock example: BASELINE.md section 4, profiles/r05_fp32_examples_parity.md; tests/test_example_precision_gpu.py.
+// Measured on every stock example: BASELINE.md section 7, profiles/r05_fp32_examples_parity.md; tests/test_example_precision_gpu.py.
 int32_t sphmi_auto_device_float_bytes(const sphmi_config* cfg) {
     if (!cfg) return 0;
     const bool vanishes_at_cut = cfg->H >= 2.0 * cfg->h * (1.0 - 1e-12);
