@@ -561,7 +561,9 @@ k_neighbor_force(const ForceParams<T> P) {
     // (round 5, launches of four and eight waves per tile: the corrector's epilogue reads state A and the low words of this lane's particle — requested
     // HERE, a whole pass ahead of their use, instead of as one more exposed round trip at the end of a wave whose life is 10 µs; twelve
     // registers that those kernels have to spare, the large launches do not)
-    constexpr bool kEarlyEpilogueLoads = PASS == PASS_CORRECTOR && WPT >= 4 && SPHMI_SMALL_TRIMS != 0;
+    // (compiled-in models only: the run-time-model corrector of eight waves per tile sits at 127 registers, and twelve more cost it its second workgroup per
+    // compute unit — +5 … +14 % per step on the 17 k-particle Laminar / SPS / shifting handles, caught by tools/variants_vs_previous.sh)
+    constexpr bool kEarlyEpilogueLoads = PASS == PASS_CORRECTOR && WPT >= 4 && MODEL >= 0 && SPHMI_SMALL_TRIMS != 0;
     [[maybe_unused]] V4 pre_s0, pre_s1, pre_lo;
     if constexpr (kEarlyEpilogueLoads) {
         pre_s0 = P.a0[ac]; pre_s1 = P.a1[ac];
@@ -638,7 +640,8 @@ k_neighbor_force(const ForceParams<T> P) {
         else if constexpr (kInterleave) return ((p + (p & 0x1Cu)) << kRecShift) + base;
         else return (p << kRecShift) + base;
     };
-    const unsigned cs_ar = (unsigned)cs_a << kRecShift, ce_ar = (unsigned)ce_a << kRecShift, a_r = (unsigned)a << kRecShift;
+    // (record offsets of the target's cell [cs_ar, ce_ar) and of the record BEHIND the target, a_r1: what the orientation rule and the kernel output compare with)
+    const unsigned cs_ar = (unsigned)cs_a << kRecShift, a_r1 = ((unsigned)a + 1u) << kRecShift, w_ai = ((unsigned)ce_a << kRecShift) - a_r1;
     // `if_i` when the target plays "i", `if_j` otherwise
     auto pick_i = [&](const T if_i, const T if_j, const bool a_is_i) -> T { return a_is_i ? if_i : if_j; };
     auto pair_core = [&](const unsigned jr, const T dx, const T dy, const T dz, const T n0w, const V4& n1, const bool a_is_i) {
@@ -761,7 +764,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         if (MODEL < 0 && P.kout && PASS == PASS_CORRECTOR) {
             // KernelOutput!, src/SPHCellList.jl:106-116
-            const bool in = (r2 <= P.H2) && (jr != a_r);           // the pair loop never meets i == j
+            const bool in = (r2 <= P.H2) && (jr + (1u << kRecShift) != a_r1);           // the pair loop never meets i == j
             kw += in ? Wq : T(0);
             kgx += fac * dx; kgy += fac * dy; kgz += fac * dz;
         }
@@ -899,7 +902,6 @@ k_neighbor_force(const ForceParams<T> P) {
     // orientation of the density-diffusion term: the target plays "i" iff j sorts before its
     // cell (j < cs_a) or after it inside it (a < j < ce_a)
     // (the range a < j < ce_a as ONE unsigned compare of j − (a + 1) against ce_a − (a + 1): a subtract and two compares instead of three compares)
-    const unsigned a_r1 = a_r + (1u << kRecShift), w_ai = ce_ar - a_r1;
     auto plays_i = [&](const unsigned jr) { return (bool)((jr < cs_ar) | ((jr - a_r1) < w_ai)); };
     // "current mask used up AND something queued" is ONE unsigned compare, cm < qf with qf = min(qn, 1): the 0 / 1 flag is kept up
     // to date where qn changes (a refill, the end of a chunk's pushes) instead of two compares per iteration.  The loop tests are

@@ -4,7 +4,11 @@
 # The next round's reference: mkdir -p build/r4tree && git archive <last commit of round 4> | tar -x -C build/r4tree && (cd build/r4tree && python -m sphexample_amd.build --force)   usage (gpurun): bash tools/variants_vs_previous.sh <prev tree> <out md>
 cd $GRAFT_REPO_ROOT
 prev=${1:-build/r3tree}; out=${2:-gpurun_out/variants_vs_previous.md}
+# (round 5: the first instantiations of the FIRST process ran on a device that had just left its idle state — +8 … +14 % on the 17 k-particle
+# run-time-model kernels of "this tree", which a targeted A/B, tools/variant_probe.py, did not reproduce: both trees now start behind a warm-up)
+python tools/variant_probe.py 0.0085 default 4 3000 > /dev/null 2>&1
 python tools/bench_variants.py 200 > gpurun_out/variants_head.txt 2>/dev/null
+python tools/variant_probe.py 0.0085 default 4 3000 > /dev/null 2>&1
 (cd $prev && python tools/bench_variants.py 200 > $GRAFT_REPO_ROOT/gpurun_out/variants_prev.txt 2>/dev/null)
 python - "$out" <<'P'
 import math, re, sys
