@@ -278,7 +278,25 @@ __device__ __forceinline__ void sqrt_and_rcp(const float a, const float b, float
     asm("v_sqrt_f32 %0, %2\n\tv_rcp_f32 %1, %3\n\ts_nop 0" : "=&v"(sqrt_a), "=v"(rcp_b) : "v"(a), "v"(b));
 #endif
 }
-__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }   // (v_rsq_f64 + Newton: no faster)
+#ifndef SPHMI_F64_TRIMS
+#define SPHMI_F64_TRIMS 1       // fp64 pair loop (round 5): square root without the compiler's range scaling, the clamp of u as an output modifier, the neighbour's
+                                // EOS with a multiply for its division — 0: rounds 1-4, A/B builds
+#endif
+__device__ __forceinline__ double fast_sqrt(double x) {
+#if SPHMI_F64_TRIMS
+    // sqrt of an r² of the pair loop (0 for the self pair, else 1e-8 … 1e-2 of a length² in metres: no subnormals, no infinities) — the compiler's sqrt() is
+    // v_rsq_f64 + the same two refinements INSIDE a range scaling of two v_ldexp_f64, a v_cmp_class and four selects (17 instructions; this: 9).
+    const double xs = x > 1e-300 ? x : 1e-300;
+    const double y = __builtin_amdgcn_rsq(xs);
+    double g = xs * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, xs);
+    return __builtin_fma(d, h, g);
+#else
+    return sqrt(x);
+#endif
+}
 
 __device__ __forceinline__ float  absT(float x)  { return __builtin_fabsf(x); }
 __device__ __forceinline__ double absT(double x) { return __builtin_fabs(x); }
@@ -312,8 +330,12 @@ __device__ __forceinline__ float fma1_clamp01_ready(float a, float b) {
     float r; asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "s"(b)); return r;
 }
 __device__ __forceinline__ double fma1_clamp01(double a, double b) {
+#if SPHMI_F64_TRIMS
+    double r; asm("v_fma_f64 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(a), "v"(b)); return r;      // (two compares and three selects as ONE output modifier)
+#else
     const double t = __builtin_fma(a, b, 1.0);
     return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+#endif
 }
 // 1 for a positive (Fluid) signed density, 0 for a negative one — the MotionLimiter of the neighbour as a factor
 __device__ __forceinline__ float step01(float s, float big) {
@@ -712,7 +734,12 @@ k_neighbor_force(const ForceParams<T> P) {
         if constexpr (PASS == PASS_CORRECTOR) {
             // EquationOfStateGamma7 (src/SimulationEquations.jl:9-11) of the neighbour's ρ⁺, folded into the sum
             T rr;
-            if constexpr (sizeof(T) == 8) rr = rho_b / P.rho0; else rr = rho_b * P.inv_rho0;
+            // (fp64: ρ/ρ₀ as in src/SimulationEquations.jl:10 costs an IEEE division — a dozen instructions — per PAIR.  Division by a CONSTANT: the
+            // quotient through the reciprocal, corrected with the exact residual — two FMAs, and the correctly rounded ρ/ρ₀ again but for rare double
+            // roundings; a bare multiply is off by an ulp often enough to move MovingSquare2d's r = H ties, 4.6e-13 → 3e-8 against the oracle after 100 steps)
+            if constexpr (sizeof(T) == 8 && SPHMI_F64_TRIMS == 0) rr = rho_b / P.rho0;
+            else if constexpr (sizeof(T) == 8) { const T q0 = rho_b * P.inv_rho0; rr = __builtin_fma(__builtin_fma(-q0, P.rho0, rho_b), P.inv_rho0, q0); }
+            else rr = rho_b * P.inv_rho0;
             const T rr2 = rr * rr, rr4 = rr2 * rr2, rr7 = (rr4 * rr2) * rr;
             Psum = P.Cbe * rr7 + PaC;
             P_b = Psum - P_a;
