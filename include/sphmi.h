@@ -288,7 +288,7 @@ typedef struct sphmi_multi_info {
     int32_t world, n_local;        /* slabs in total / held by this handle                                         */
     int32_t axis, halo_width;      /* slab axis (0 = x …); ghost-layer width in cell columns (1; 2 + off with mDBC) */
     int32_t transport;             /* 0 = stream-ordered device copies, 1 = RCCL, 2 = host shared memory (below)    */
-    int32_t reserved;
+    int32_t reserved;              /* how the four per-step maxima travel: 0 = the transport's collective (ncclAllReduce), 1 = device mailboxes ($SPHMI_EXCHANGE=mailbox) */
     int64_t n_recuts;              /* rebuilds at which the cuts moved (load balance by work)                        */
     int64_t cuts[SPHMI_MAX_DEVICES];    /* cuts[r-1] = first cell column of slab r                                  */
     int64_t n_live[SPHMI_MAX_DEVICES];  /* particles incl. ghost copies currently held per local slab               */

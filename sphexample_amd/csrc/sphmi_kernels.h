@@ -141,7 +141,7 @@ struct StepCtrl {
     int need_rebuild;          // Δx ≥ h: the host rebuilds the cell list, clears the flag and re-queues the step
     int resume;                // the step after a rebuild re-uses the Δt already computed
     int stop;                  // TotalTime > t_target or max_steps reached
-    int error;                 // 1: non-positive / NaN Δt, 2: non-positive density, 3: a particle left the cell grid of a device-side rebuild
+    int error;                 // 1: non-positive / NaN Δt, 2: non-positive density, 3: a particle left the cell grid of a device-side rebuild, 4: a peer slab never posted (mailbox exchange)
     int pre_rebuilt;           // the rebuild this control is about to ask for has been served already: every SimulationLoop call opens
                                // with one (Δx re-armed to 1 + h, src/SPHCellList.jl:739,758-762), so the host runs it BEFORE queueing the
                                // first step instead of queueing a one-step batch for the control to cancel (≈60 µs per call)

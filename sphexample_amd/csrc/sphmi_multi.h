@@ -115,6 +115,65 @@ __global__ void k_dd_merge_control(unsigned long long* M, RedPtrs Tp, unsigned l
     consumed = __shfl(consumed, 0, 64);
     if (i < 4) { M[i] = consumed ? 0ull : v; zero_set[i] = 0ull; }
 }
+// The same WITHOUT a collective (round 5, $SPHMI_EXCHANGE=mailbox): every slab owns a MAILBOX in its device memory — [2 parities][16 senders][8 words]:
+// { sequence number, four maxima } — that its peers can address (peer access between the devices of one process, hipIpc between processes).  The control
+// launch of a step first POSTS this slab's four maxima into every slab's box (lane q serves slab q: four relaxed stores, a release fence, the sequence
+// number — all at system scope), then lane q WAITS for slab q's post of this step in its OWN box and the wave takes the maximum: one launch, a handful of
+// stores over xGMI and one load round trip on the critical path corrector → control → predictor, where ncclAllReduce of 32 bytes pays a collective's
+// latency.  Two parities: a peer cannot post step n + 2 before this slab has read step n (it needs this slab's post of step n + 1 first).  The same four
+// words travel and the reduction is an integer maximum, so the result is the allreduce's bit for bit.  A peer that never posts is an error after
+// `timeout` ticks of the 100-MHz clock (StepCtrl::error = 4), not a hang.
+struct MboxArgs {
+    unsigned long long* dst[16];   // every slab's box as THIS device addresses it (null: no such slab)
+    const unsigned long long* own; // this slab's box
+    const unsigned long long* mine;// the four slots the last corrector of this slab filled
+    int world, me, parity;
+    unsigned long long seq, timeout;
+};
+constexpr int kMboxWords = 2 * 16 * 8;
+template <class T>
+__global__ void k_dd_mbox_merge_control(unsigned long long* M, MboxArgs A, unsigned long long* zero_set, StepCtrl* cp, double h, double c0, double CFL) {
+    const int i = threadIdx.x;
+    const size_t slot = ((size_t)A.parity * 16) * 8;
+    if (i < A.world && A.dst[i] != nullptr) {
+        unsigned long long* b = A.dst[i] + slot + (size_t)A.me * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(b + 1 + k, A.mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(b, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+    int late = 0;
+    if (i < A.world) {
+        const unsigned long long* b = A.own + slot + (size_t)i * 8;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != A.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((unsigned long long)__builtin_amdgcn_s_memrealtime() - t0 > A.timeout) { late = 1; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __hip_atomic_load(b + 1 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)v[k], o, 64), hi = __shfl_xor((unsigned)(v[k] >> 32), o, 64);
+            const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+            v[k] = u > v[k] ? u : v[k];
+        }
+    late = __builtin_amdgcn_ballot_w64(late != 0) != 0;
+    if (i == 0) {
+        unsigned long long r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const unsigned long long m = M[k]; r[k] = m > v[k] ? m : v[k]; }
+        StepCtrl c = *cp;
+        bool consumed = false;
+        if (late) { c.error = 4; c.active = 0; }
+        else consumed = step_control_decide<T>(r[0], r[1], r[2], r[3], c, h, c0, CFL);
+        *cp = c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { M[k] = consumed ? 0ull : r[k]; zero_set[k] = 0ull; }
+    }
+}
 // both halo lists of a side in one launch: [0, nl) → buf_l, [nl, nl + nr) → buf_r
 template <class T>
 __global__ void __launch_bounds__(256) k_halo_pack2(Half<const typename Vec4<T>::type> pk0, Half<const typename Vec4<T>::type> pk1,
@@ -494,6 +553,9 @@ struct MultiEngine final : EngineBase {
         // The travelling slots are the slab engine's own two sets of reduction slots (Engine::red_d, alternating by step parity: the
         // corrector of step n fills one, the control of step n+1 reads it — after the allreduce in place — and zeroes the other).
         unsigned long long *M = nullptr, *stage = nullptr;   // M: merged maxima not yet consumed by a step, stage: peers' slots (other devices)
+        unsigned long long* box = nullptr;                   // $SPHMI_EXCHANGE=mailbox: this slab's mailbox, and every slab's as this device addresses it
+        unsigned long long* box_of[16] = {};
+        void* box_ipc[16] = {};                              // … those opened from another process's handle (closed with the engine)
         DevBuf cx, flag, pos, idx[4], rec_s[2], rec_r[2], cost;
         int* mm_d = nullptr; int* mm_h = nullptr;
         int64_t* cnt_h = nullptr;
@@ -520,6 +582,7 @@ struct MultiEngine final : EngineBase {
     int64_t n_total = 0;
     double dx_rate = 0.0;
     int parity = 0;
+    bool mbox_on = false; unsigned long long mbox_seq = 0, mbox_timeout = 0;
     static constexpr int kBatch = 16;
     std::vector<int> dev_of;           // device of every global rank (one-process mode)
 
@@ -615,6 +678,71 @@ struct MultiEngine final : EngineBase {
             HC(hipMemset(r.M, 0, 4 * 8));
             HC(hipMalloc(&r.mm_d, 2 * 4)); HC(hipHostMalloc(&r.mm_h, 2 * 4)); HC(hipHostMalloc(&r.cnt_h, 8 * 8));
         }
+        if (const char* x = getenv("SPHMI_EXCHANGE")) {
+            if (!strcmp(x, "mailbox")) setup_mailboxes();
+            else if (strcmp(x, "allreduce") != 0) throw EngineError(SPHMI_ERR_ARGUMENT, "SPHMI_EXCHANGE must be allreduce (default) or mailbox");
+        }
+    }
+    // $SPHMI_EXCHANGE=mailbox (k_dd_mbox_merge_control): the per-step maxima through mailboxes in device memory instead of ncclAllReduce / the host
+    // round trip of the shared-memory transport.  The slabs of ONE process that talk through device pointers anyway (the local transport) have no use for it.
+    void setup_mailboxes() {
+        if (world < 2 || (!use_rccl && !shm)) return;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            HC(hipMalloc(&r.box, kMboxWords * 8));
+            HC(hipMemset(r.box, 0, kMboxWords * 8));
+            HC(hipDeviceSynchronize());
+        }
+        if (rank_mode) {
+            // one process per slab: the boxes of the peers through hipIpc — the 64-byte handles summed into one table (everybody adds zeros but its own row)
+            Rank& r = R[0];
+            HC(hipSetDevice(r.device));
+            static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t: 64 bytes per row");
+            std::vector<long long> tab((size_t)world * 8, 0);
+            hipIpcMemHandle_t mine_h;
+            HC(hipIpcGetMemHandle(&mine_h, r.box));
+            memcpy(&tab[(size_t)r.rank * 8], &mine_h, 64);
+            if (shm) {
+                // (a sum of int64 words: every row but one is zero, so nothing carries)
+                shm->allreduce((int64_t*)tab.data(), tab.size(), ShmWorld::SUM);
+            } else {
+                void* d = nullptr;
+                HC(hipMalloc(&d, tab.size() * 8));
+                try {
+                    HostBounce hb;
+                    hb.h2d(d, tab.data(), tab.size() * 8, nullptr);
+                    NCX("ncclAllReduce (handing the mailbox handles round)", r.rank, -1, r.comm_red, Rccl::get().AllReduce(d, d, tab.size() * 8, ncclUint8, ncclSum, r.comm_red, nullptr));
+                    HC(hipStreamSynchronize(nullptr));
+                    hb.d2h(tab.data(), d, tab.size() * 8, nullptr);
+                } catch (...) { (void)hipFree(d); throw; }
+                (void)hipFree(d);
+            }
+            for (int q = 0; q < world; ++q) {
+                if (q == r.rank) { r.box_of[q] = r.box; continue; }
+                hipIpcMemHandle_t hq; memcpy(&hq, &tab[(size_t)q * 8], 64);
+                void* pq = nullptr;
+                if (hipIpcOpenMemHandle(&pq, hq, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !pq) {
+                    (void)hipGetLastError();
+                    throw EngineError(SPHMI_ERR_DEVICE, "SPHMI_EXCHANGE=mailbox: hipIpcOpenMemHandle failed for the mailbox of slab " + std::to_string(q));
+                }
+                r.box_ipc[q] = pq; r.box_of[q] = (unsigned long long*)pq;
+            }
+        } else {
+            // the slabs of this process on their own devices: peer access, plain pointers
+            for (auto& a : R) for (auto& b : R) {
+                if (a.device != b.device) {
+                    HC(hipSetDevice(a.device));
+                    int can = 0; (void)hipDeviceCanAccessPeer(&can, a.device, b.device);
+                    if (can) { hipError_t e = hipDeviceEnablePeerAccess(b.device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0; (void)hipGetLastError(); }
+                    if (!can) throw EngineError(SPHMI_ERR_DEVICE, "SPHMI_EXCHANGE=mailbox needs peer access between the devices of the handle");
+                }
+                a.box_of[b.rank] = b.box;
+            }
+        }
+        double secs = 20.0;
+        if (const char* t = getenv("SPHMI_MBOX_TIMEOUT")) secs = atof(t) > 0 ? atof(t) : secs;
+        mbox_timeout = (unsigned long long)(secs * 1e8);            // s_memrealtime: 100 MHz
+        mbox_on = true;
     }
     ~MultiEngine() override {
         for (auto& r : R) {
@@ -627,6 +755,8 @@ struct MultiEngine final : EngineBase {
             stage_s.release(); stage_r.release();
             if (red_h) { (void)hipHostFree(red_h); red_h = nullptr; }
             for (DevBuf* b : {&r.cx, &r.flag, &r.pos, &r.idx[0], &r.idx[1], &r.idx[2], &r.idx[3], &r.rec_s[0], &r.rec_s[1], &r.rec_r[0], &r.rec_r[1], &r.cost}) b->release();
+            for (void* q : r.box_ipc) if (q) (void)hipIpcCloseMemHandle(q);
+            if (r.box) (void)hipFree(r.box);
             (void)hipFree(r.M); (void)hipFree(r.stage); (void)hipFree(r.mm_d); (void)hipHostFree(r.mm_h); (void)hipHostFree(r.cnt_h);
             if (r.ev_pack) { (void)hipEventDestroy(r.ev_pack); (void)hipEventDestroy(r.ev_edge); (void)hipEventDestroy(r.ev_red); }
             for (auto& e : r.ev_consumed) if (e) (void)hipEventDestroy(e);
@@ -1113,6 +1243,20 @@ struct MultiEngine final : EngineBase {
             r.e->serve_reschedules();
             if (!use_rccl) HC(hipEventRecord(r.ev_red, r.main));         // behind the last corrector (its edge tiles joined `main`)
         }
+        if (mbox_on) {
+            // post + wait + merge + control in ONE launch per slab (k_dd_mbox_merge_control); the host only counts the steps it queued
+            mbox_seq += 1;
+            for (auto& r : R) {
+                HC(hipSetDevice(r.device));
+                MboxArgs A{};
+                for (int q = 0; q < world && q < 16; ++q) A.dst[q] = r.box_of[q];
+                A.own = r.box; A.mine = r.e->red_d + 4 * p; A.world = world; A.me = r.rank; A.parity = p; A.seq = mbox_seq; A.timeout = mbox_timeout;
+                hipLaunchKernelGGL(k_dd_mbox_merge_control<T>, dim3(1), dim3(64), 0, r.main, r.M, A, r.e->red_d + 4 * (p ^ 1), r.e->ctrl_d, cfg.h, cfg.c0, cfg.CFL);
+                HC(hipGetLastError());
+                r.e->dd_control_queued(p ^ 1);
+            }
+            return;
+        }
         if (use_rccl && world > 1) {
             Rccl& N = Rccl::get();
             NCX("per-step allreduce", R[0].rank, -1, R[0].comm_red, N.GroupStart());
@@ -1198,6 +1342,7 @@ struct MultiEngine final : EngineBase {
                 const int64_t grown = (steps - steps0) + (st.need_rebuild ? 1 : 0) - (fresh && steps > steps0 ? 1 : 0);
                 if (steps > steps0) fresh = false;
                 if (grown > 0 && dx0 < cfg.h && st.delta_x > dx0) dx_rate = (st.delta_x - dx0) / (double)grown;
+                if (st.error == 4) throw EngineError(SPHMI_ERR_DEVICE, "SPHMI_EXCHANGE=mailbox: a peer slab did not post its maxima in time ($SPHMI_MBOX_TIMEOUT seconds)");
                 if (st.error == 2) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive density produced on some slab");
                 if (st.error) throw EngineError(SPHMI_ERR_NUMERIC, "non-positive or NaN dt");
                 if (st.need_rebuild) {
@@ -1482,6 +1627,7 @@ struct MultiEngine final : EngineBase {
         memset(o, 0, sizeof *o);
         o->world = world; o->n_local = (int32_t)R.size(); o->axis = axis; o->halo_width = halo_width; o->n_recuts = n_recuts;
         o->transport = shm ? 2 : (use_rccl ? 1 : 0);
+        o->reserved = mbox_on ? 1 : 0;                                   // how the per-step maxima travel: 0 the transport's collective, 1 mailboxes
         for (int r = 1; r < world && r < 16; ++r) o->cuts[r - 1] = plan.world() == world ? plan.lo[r] : 0;
         for (auto& r : R) if (r.e && r.rank < 16) o->n_live[r.rank] = r.e->N;
     }

@@ -44,7 +44,7 @@ def main():
     info = eng.multi_info()
     d = eng.download(("Position", "Density", "ID", "Velocity"))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), prog=np.array(prog, dtype=np.float64),
-             info=np.array([info.world, info.n_local, info.transport, info.axis, info.halo_width, info.n_recuts]), **d)
+             info=np.array([info.world, info.n_local, info.transport, info.axis, info.halo_width, info.n_recuts, info.reserved]), **d)
 
 
 if __name__ == "__main__":

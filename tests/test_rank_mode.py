@@ -19,9 +19,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "rank_worker.py")
 
 
-def _spawn(world, args_of, timeout=300):
+def _spawn(world, args_of, timeout=300, extra_env=None):
     uid = os.urandom(128).hex()
-    env = dict(os.environ, SPHMI_TRANSPORT="shm", SPHMI_SHM_TIMEOUT="60")
+    env = dict(os.environ, SPHMI_TRANSPORT="shm", SPHMI_SHM_TIMEOUT="60", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, WORKER, args_of(r)[0], uid, str(r), str(world)] + [str(a) for a in args_of(r)[1:]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     out = []
@@ -88,3 +88,26 @@ def test_rank_mode_processes_match_one_device(case, world, steps, fb, tol, calls
     r = _by_id(ref.download(("ID", "Density", "Position", "Velocity")))
     assert np.abs(got["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < tol
     assert np.abs(got["Position"] - r["Position"]).max() / np.abs(r["Position"]).max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,steps,fb,calls", [("dam_break_3d_shipped", 2, 60, 8, 2), ("dam_break_3d_shipped", 4, 40, 4, 1),
+                                                       ("moving_square", 2, 120, 8, 1), ("dam_break_2d_mdbc", 3, 40, 8, 1)])
+def test_mailbox_exchange_is_the_allreduce_bit_for_bit(case, world, steps, fb, calls, tmp_path):
+    """$SPHMI_EXCHANGE=mailbox (round-4 review, next-4): the four per-step maxima through mailboxes in device memory — posted by the control launch itself into
+    every peer's box (hipIpc between the rank processes), polled in its own — instead of the transport's collective (ncclAllReduce; here, on one GPU, the
+    host round trip of the shared-memory transport).  The same four words travel and the reduction is an integer maximum: every rank must end with the SAME
+    bits as under the default exchange — loop counters, clock, density, position — through rebuilds (a rebuild request cancels the rest of a batch: the
+    cancelled steps still post), several advance calls and moving bodies."""
+    runs = {}
+    for mode in ("allreduce", "mailbox"):
+        out = tmp_path / mode
+        out.mkdir()
+        res = _spawn(world, lambda r: ("run", case, steps, fb, str(out), calls, -1), extra_env={"SPHMI_EXCHANGE": mode, "SPHMI_MBOX_TIMEOUT": "30"})
+        for rc, o, e in res:
+            assert rc == 0, e[-3000:]
+        runs[mode] = [np.load(out / f"rank{r}.npz") for r in range(world)]
+    for a, b in zip(runs["allreduce"], runs["mailbox"]):
+        assert int(a["info"][6]) == 0 and int(b["info"][6]) == 1           # the second run DID go through the mailboxes
+        for k in ("prog", "ID", "Density", "Position", "Velocity"):
+            assert np.array_equal(a[k], b[k]), k
