@@ -47,15 +47,18 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def _one_handle_vs_one_device(p, s, fb, tol, devices, calls, transport=None, monkeypatch=None):
+def _one_handle_vs_one_device(p, s, fb, tol, devices, calls, transport=None, monkeypatch=None, exchange=None):
     from sphexample_amd.engine import make_engine
     if transport:
         monkeypatch.setenv("SPHMI_TRANSPORT", transport)
+    if exchange:
+        monkeypatch.setenv("SPHMI_EXCHANGE", exchange); monkeypatch.setenv("SPHMI_MBOX_TIMEOUT", "30")
     ref = make_engine(p, s, device_float_bytes=fb)
     dd = make_engine(p, s, device_float_bytes=fb, devices=devices)
     info = dd.multi_info()
     assert info.world == len(devices) and info.n_local == len(devices)
     assert info.transport == (0 if transport == "local" else 1)          # 1 = RCCL, 0 = stream-ordered (peer) copies
+    assert info.reserved == (1 if exchange == "mailbox" else 0)          # … and the per-step maxima through the collective / the mailboxes
     for steps in calls:
         pr, pd = ref.advance(1e9, max_steps=steps), dd.advance(1e9, max_steps=steps)
         assert (pd.iteration, pd.steps_done, pd.n_rebuilds, pd.index_counter) == (pr.iteration, pr.steps_done, pr.n_rebuilds, pr.index_counter)
@@ -78,6 +81,14 @@ def _one_handle_vs_one_device(p, s, fb, tol, devices, calls, transport=None, mon
 def test_two_devices_in_one_handle_match_one_device(case, steps, fb, tol, transport, request, monkeypatch):
     p, s = request.getfixturevalue(case)
     _one_handle_vs_one_device(p, s, fb, tol, [0, 1], (steps // 2, steps - steps // 2), transport, monkeypatch)
+
+
+@pytest.mark.parametrize("case,steps,fb,tol", [("dam_break_3d_shipped", 60, 8, 1e-9), ("moving_square", 150, 8, 1e-9)])
+def test_two_devices_in_one_handle_with_the_mailbox_exchange(case, steps, fb, tol, request, monkeypatch):
+    """$SPHMI_EXCHANGE=mailbox between two DEVICES of one process (peer access, the maxima posted over xGMI) instead of ncclAllReduce:
+    the first run of this path on real peers — on one GPU it is covered by the rank processes of tests/test_rank_mode.py."""
+    p, s = request.getfixturevalue(case)
+    _one_handle_vs_one_device(p, s, fb, tol, [0, 1], (steps // 2, steps - steps // 2), None, monkeypatch, exchange="mailbox")
 
 
 @pytest.mark.parametrize("fb,tol", [(8, 1e-9), (4, 1e-5)])
@@ -114,15 +125,17 @@ def _spawn_rccl(world, args_of, timeout=900):
     return out
 
 
+@pytest.mark.parametrize("exchange", ["allreduce", "mailbox"])
 @pytest.mark.parametrize("world", WORLDS)
 @pytest.mark.parametrize("case,steps,fb,tol", [("dam_break_3d_shipped", 40, 8, 1e-9), ("dam_break_3d_c3_flowing", 50, 4, 1e-5)])
-def test_rank_mode_over_rccl_matches_one_device(world, case, steps, fb, tol, tmp_path):
+def test_rank_mode_over_rccl_matches_one_device(world, case, steps, fb, tol, exchange, tmp_path, monkeypatch):
     """sphmi_create_rank, one process per GPU, the peers behind RCCL (info.transport == 1): the launch shape of
     `torchrun bench.py --gpus N`."""
     import conftest
     from sphexample_amd.engine import make_engine
     if case == "dam_break_3d_shipped" and world > 4:
         pytest.skip("17 k particles: too few cell columns for eight slabs")
+    monkeypatch.setenv("SPHMI_EXCHANGE", exchange); monkeypatch.setenv("SPHMI_MBOX_TIMEOUT", "60")      # (the workers inherit it: mailboxes through hipIpc)
     res = _spawn_rccl(world, lambda r: ("run", case, steps, fb, str(tmp_path), 1, -1))
     for rc, o, e in res:
         assert rc == 0, e[-3000:]
@@ -134,6 +147,7 @@ def test_rank_mode_over_rccl_matches_one_device(world, case, steps, fb, tol, tmp
         np.testing.assert_array_equal(q["prog"][0, :4], [pr.iteration, pr.steps_done, pr.n_rebuilds, pr.index_counter])
         np.testing.assert_allclose(q["prog"][0, 4:], [pr.total_time, pr.last_dt], rtol=1e-12 if fb == 8 else 1e-5)
         assert tuple(q["info"][:3]) == (world, 1, 1)                    # one local slab, RCCL
+        assert int(q["info"][6]) == (1 if exchange == "mailbox" else 0)
     ids = np.concatenate([q["ID"] for q in parts])
     assert len(ids) == len(p) and len(np.unique(ids)) == len(p)        # every particle owned exactly once
     got = _by_id({k: np.concatenate([q[k] for q in parts]) for k in ("ID", "Density", "Position", "Velocity")})
