@@ -82,7 +82,7 @@ typedef struct sphmi_config {
     int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
     int32_t kernel_output;       /* SPHMI_KOUT_* (KMode of SimulationMetaData)                   */
     int64_t n_particles;         /* length(SimParticles); below 2^27 (fp32 kernels) / 2^26 (fp64) per device: 32-bit gather offsets */
-    int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<27)  */
+    int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<30: 8 GB of cell arrays at the limit, allocated on demand) */
     /* SimulationConstants */
     double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;
     /* SPHKernelInstance */

@@ -696,7 +696,10 @@ struct Engine final : EngineBase {
             ncell *= grid.np[d];
         }
         sticky_grid = slack > 0;
-        const int64_t budget = cfg.max_cells > 0 ? cfg.max_cells : (1ll << 27);
+        // (the reference keeps its cells in a Dict and has no such limit; a dense grid is what the kernels index.  Round 5: 2^30 cells by default — two
+        // 4-GB arrays of a 288-GB device, allocated only when a run asks for them, and a scan of ≈3 ms per rebuild at that size: a run whose spray has
+        // flown far goes on, slower, instead of ending with SPHMI_ERR_DOMAIN at 2^27)
+        const int64_t budget = cfg.max_cells > 0 ? cfg.max_cells : (1ll << 30);
         if (ncell > budget) {
             char buf[200];
             snprintf(buf, sizeof(buf), "bounding cell grid %d x %d x %d = %lld cells exceeds max_cells = %lld "

@@ -203,6 +203,23 @@ def test_error_paths(dam_break_2d):
     assert ei.value.status == ERR_DOMAIN
 
 
+def test_a_far_flung_particle_does_not_end_the_run(dam_break_3d_shipped):
+    """The reference keeps its cells in a Dict (src/SPHCellList.jl:145-157) and never refuses a domain; the engine's dense bounding grid had a default budget
+    of 2^27 cells until round 5.  One fluid particle thrown far beyond the tank — a bounding grid of ≈2.9e8 cells, twice the old budget — must not end the
+    run: the step goes through, matches the oracle, and the lone particle falls freely."""
+    p, s = dam_break_3d_shipped
+    q = p.copy()
+    i = int(np.where(q.Type == 1)[0][-1])
+    q.Position[i] = [22.0, 20.0, 21.0]                    # H ≈ 0.069 m: ≈ 340 × 300 × 310 cells with the padding
+    eng, orc = engines(q, s, 8)
+    pe, po = eng.advance(1e9, max_steps=3), orc.advance(1e9, max_steps=3)
+    assert pe.iteration == po.iteration == 3 and pe.index_counter == po.index_counter
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < 1e-10 and relmax(e["Position"], o["Position"]) < 1e-12
+    k = int(np.where(e["ID"] == q.ID[i])[0][0])
+    assert e["Velocity"][k][2] < 0 and abs(e["Velocity"][k][0]) < 1e-12          # nobody near it: gravity only
+
+
 def test_full_size_properties():
     """BASELINE config 3 size (≈1.06 M particles, fp32): size-independent properties.
     Σ m·a = 0 before gravity, sortedness + stability of the cell order, run-to-run determinism."""

@@ -240,11 +240,11 @@ def test_fuzzed_switches_match_the_oracle(seed):
             # sign of ρ and must refuse).  The oracle shows it: the mDBC pass on the state at the start of every step of the call.
             if exc.status == ERR_DOMAIN:
                 # A blob that flies apart: the engine's cell list is a DENSE grid over the bounding box of the cloud (the reference
-                # sorts cell indices and has no such limit), and 2²⁷ cells is where it refuses — with a text that says so.  Legitimate
+                # sorts cell indices and has no such limit), and 2³⁰ cells is where it refuses — with a text that says so.  Legitimate
                 # iff the oracle's cloud spans that many cells by the end of the call.
                 x = orc.download(("Position",))["Position"]
                 span = np.floor(x.max(0) / s.SimKernel.H) - np.floor(x.min(0) / s.SimKernel.H) + 3
-                assert np.prod(span) > 2.0 ** 27 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
+                assert np.prod(span) > 2.0 ** 30 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
                 return
             assert exc.status == ERR_NUMERIC and mdbc, f"{what}: {exc}"
             seen = False
