@@ -217,8 +217,20 @@ def test_fuzzed_switches_match_the_oracle(seed):
     ie, io = np.argsort(eng.download(("ID",))["ID"], kind="stable"), np.argsort(orc.download(("ID",))["ID"], kind="stable")
     if fb == 8:
         np.testing.assert_array_equal(eng.download(("ID",))["ID"], orc.download(("ID",))["ID"], err_msg=what)
-    np.testing.assert_allclose(d1[ie], d2[io], rtol=0, atol=tol_f * max(np.abs(d2).max(), 1e-300), err_msg="drho " + what)
-    np.testing.assert_allclose(a1[ie], a2[io], rtol=0, atol=tol_f * max(np.abs(a2).max(), 1e-300), err_msg="acc " + what)
+    def close(x, y, name):
+        scale = max(np.abs(y).max(), 1e-300)
+        err = np.abs(x - y).reshape(len(x), -1).max(axis=1) / scale
+        if fb == 4 and s.SimKernel.k < 2.0:
+            # A kernel cut off BEFORE it vanishes (k < 2) switches a finite pair term at r = H (src/SPHCellList.jl:275), and fp32 rounds r² against H²: a pair
+            # that sits on the cut within 1e-7 is in for one precision and out for the other — both of its particles then differ by ONE pair's term (found by
+            # generation 117000, identical in round 4's tree: two particles of 2 500, 7e-3 of the field maximum).  That is why the library chooses fp64 kernels
+            # for such handles (sphmi_auto_device_float_bytes); forced to fp32 here, a handful of particles — pairs — may sit outside, each by at most one pair's share.
+            bad = err > tol_f
+            assert bad.sum() <= max(4, len(err) // 500) and err.max() < 0.05, f"{name} {what}: {int(bad.sum())} particles beyond {tol_f:.1e}, worst {err.max():.2e}"
+            return
+        np.testing.assert_allclose(x, y, rtol=0, atol=tol_f * scale, err_msg=name + " " + what)
+    close(d1[ie], d2[io], "drho")
+    close(a1[ie], a2[io], "acc")
     if fb == 4:
         return                                            # (K steps of a violent cloud in fp32: chaos, not parity)
     eng, orc = both()
