@@ -8,7 +8,7 @@
 # RunSimulation itself, logging, ProgressMeter, TimerOutputs, save_particles / save_grid and the VTKHDF writer stay the
 # reference's own code.  The method is MORE SPECIFIC than the reference's (concrete Union of tag types in the first
 # two arguments): dispatch picks it for ZeroViscosity / ArtificialViscosity / Laminar / LaminarSPS with
-# ZeroGravityLinear / Linear / Complex density diffusion and leaves user-defined SPHViscosity / SPHDensityDiffusion
+# Zero / ZeroGravityLinear / Linear / Complex density diffusion and leaves user-defined SPHViscosity / SPHDensityDiffusion
 # subtypes (example/Dambreak2dMDBC.jl:46-66) on the CPU path — no method is overwritten.
 #
 # What one call costs on the host (round 3): the device → host copies of the fields the engine carries
@@ -52,9 +52,9 @@ mutable struct SphmiProgress
 end
 
 const BuiltinViscosity = Union{ZeroViscosity,ArtificialViscosity,Laminar,LaminarSPS}
-const BuiltinDDT = Union{ZeroGravityLinearDensityDiffusion,LinearDensityDiffusion,ComplexDensityDiffusion}
+const BuiltinDDT = Union{ZeroDensityDiffusion,ZeroGravityLinearDensityDiffusion,LinearDensityDiffusion,ComplexDensityDiffusion}
 tag(::ZeroViscosity) = Int32(0); tag(::ArtificialViscosity) = Int32(1); tag(::Laminar) = Int32(2); tag(::LaminarSPS) = Int32(3)
-tag(::ZeroGravityLinearDensityDiffusion) = Int32(1); tag(::LinearDensityDiffusion) = Int32(2); tag(::ComplexDensityDiffusion) = Int32(3)
+tag(::ZeroDensityDiffusion) = Int32(0); tag(::ZeroGravityLinearDensityDiffusion) = Int32(1); tag(::LinearDensityDiffusion) = Int32(2); tag(::ComplexDensityDiffusion) = Int32(3)
 
 # per simulation: the engine handle and the host scratch that lives as long as it (page-locked once, reused every interval)
 mutable struct Session
