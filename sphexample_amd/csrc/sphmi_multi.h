@@ -583,6 +583,7 @@ struct MultiEngine final : EngineBase {
     double dx_rate = 0.0;
     int parity = 0;
     bool mbox_on = false; unsigned long long mbox_seq = 0, mbox_timeout = 0;
+    bool two_sorts = false;
     static constexpr int kBatch = 16;
     std::vector<int> dev_of;           // device of every global rank (one-process mode)
 
@@ -597,6 +598,7 @@ struct MultiEngine final : EngineBase {
         if (world < 1 || world > 16) throw EngineError(SPHMI_ERR_ARGUMENT, "1 to 16 slabs per handle");
         if (const char* w = getenv("SPHMI_DD_OVERLAP")) overlap = atoi(w) != 0;
         if (const char* w = getenv("SPHMI_DD_RECUT")) recut_imbalance = atof(w);
+        if (const char* w = getenv("SPHMI_DD_TWO_SORTS")) two_sorts = atoi(w) != 0;
         bool shared_device = false;
         if (rank_mode) {
             R.resize(1); R[0].rank = my_rank; R[0].device = c.device;
@@ -1051,7 +1053,11 @@ struct MultiEngine final : EngineBase {
             r.e->dd_kill_ghosts();
         }
         migrate(to_l, to_r, go_l, go_r, /*kill=*/true, 0, 0);
-        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); r.e->dd_rebuild(); }
+        // (rounds 2-4 sorted here — dead rows out, arrivals into cell order — and again behind the ghost layers.  Round 5: ONE sort.  Nothing below needs the
+        // order: the boundary columns are found by cell column on the unsorted rows (dead rows have type 0), and the in-cell order of the final sort is the
+        // order TAGS' on every slab — owned rows, arrivals and ghost copies alike carry the tags of the previous global order — so sender lists and ghost
+        // slots pair up exactly as after two sorts.  $SPHMI_DD_TWO_SORTS=1: the old sequence.)
+        if (two_sorts) for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); r.e->dd_rebuild(); }
         // 2. the first / last column(s) of the slab become the neighbours' ghost layer
         const int W = halo_width;
         std::vector<long long> n_bl(L, 0), n_br(L, 0);
