@@ -1086,8 +1086,9 @@ struct MultiEngine final : EngineBase {
                 h.n_send_l = h.n_send_r = h.n_slot_l = h.n_slot_r = 0;
                 if (r.has_left) where(r, kGhostMask, 0, false, -(1ll << 40), lo + w - 1, h.send_l, h.n_send_l);
                 if (r.has_right) where(r, kGhostMask, 0, false, hi - w + 1, 1ll << 40, h.send_r, h.n_send_r);
-                where(r, kGhostLeft, kGhostLeft, false, lo - w, 1ll << 40, h.slot_l, h.n_slot_l);
-                where(r, kGhostRight, kGhostRight, false, -(1ll << 40), hi + w, h.slot_r, h.n_slot_r);
+                // (a slab without a neighbour on a side holds no ghost copies from it: no list, no round trip for its length)
+                if (r.has_left) where(r, kGhostLeft, kGhostLeft, false, lo - w, 1ll << 40, h.slot_l, h.n_slot_l);
+                if (r.has_right) where(r, kGhostRight, kGhostRight, false, -(1ll << 40), hi + w, h.slot_r, h.n_slot_r);
                 if (k == 0 && (h.n_send_l != n_bl[q] || h.n_send_r != n_br[q] || h.n_slot_l != got_l[q] || h.n_slot_r != got_r[q]))
                     throw EngineError(SPHMI_ERR_STATE, "domain decomposition: boundary columns changed between the two sorts");
                 const size_t vb = 2 * sizeof(V4);
