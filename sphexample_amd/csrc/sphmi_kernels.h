@@ -74,9 +74,9 @@ constexpr int kWave = 64;
                                 // that serve the tile's 64 targets and split its chunks (rounds 2-4) — A/B builds only
 #endif
 #ifndef SPHMI_HALF_INTERLEAVE
-#define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate SINGLE candidates (2: the chunk is loaded permuted inside its groups of eight,
-                                // bit p of an entry is candidate 2p behind the entry's base — no index arithmetic per pair, and the two lanes gather neighbouring
-                                // records), alternate groups of FOUR candidates (1: round 4), or the lower / upper 32 of a chunk (0) — 0 / 1: A/B builds only
+#define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0: A/B builds).
+                                // (Round 5 built alternate SINGLE candidates — no index arithmetic per pair — and packed fp32 arithmetic for the pair; both measured
+                                // slower and live in profiles/r05_retired_switches.patch)
 #endif
 #ifndef SPHMI_SMALL_TRIMS
 #define SPHMI_SMALL_TRIMS 1     // launches of four and eight waves per tile (a few hundred waves, 10 µs): the epilogue's loads requested at the wave's start, no
@@ -88,14 +88,6 @@ constexpr int kWave = 64;
 #ifndef SPHMI_FAST_PAIR
 #define SPHMI_FAST_PAIR 1       // fp32 kernels of the compiled-in models: pair_fast (one reciprocal per pair, transcendentals back to back, lane constants out of
                                 // the loop — round 5); 0 = pair_core for every kernel (rounds 1-4), A/B builds
-#endif
-#ifndef SPHMI_PACKED
-#define SPHMI_PACKED 0          // pair_fast with {dx, dy}, {dvx, dvy}, {r², v·x}, {ax, ay} and {Σ continuity, Σ diffusion} in v_pk_*_f32 on the register pairs
-                                // the b128 gathers deliver: measured SLOWER (−1.3 %), kept as an A/B build
-#endif
-#ifndef SPHMI_ALIGN_LO
-#define SPHMI_ALIGN_LO 0        // half tiles with groups of four: the chunks of a row start at a multiple of four records, so that the four candidates a lane
-                                // takes in turn are ONE 128-byte line (four 32-byte records) instead of parts of two lines it shares with its partner lane
 #endif
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
@@ -342,26 +334,6 @@ __device__ __forceinline__ float step01(float s, float big) {
     float r; asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(s), "s"(big)); return r;
 }
 __device__ __forceinline__ double step01(double s, double) { return s > 0.0 ? 1.0 : 0.0; }
-
-// Packed fp32 (v_pk_*_f32: two lanes of a 64-bit register pair per instruction, at the price of ONE v_fma_f32 — tools/ubench/valu_rates2.hip).
-// Inline asm: the compiler's own packing (SLP, DAG combines) pairs values that sit in different register pairs and pays for it in v_mov /
-// v_pk_mov shuffles (-fno-slp-vectorize); here only operands that ARE adjacent — the {x, y} / {vx, vy} halves of a gathered b128, or
-// the results of two scalar instructions written side by side — are packed.  None of these reads the result of a transcendental (that
-// needs a wait state the compiler cannot see into an asm for).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-    f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
-}
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
-    f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d;
-}
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
-}
-// { a.x·b.x + c.x, a.x·b.y + c.y }: the LOW half of `a` multiplies both halves of `b` (op_sel_hi: no broadcast copy)
-__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
-}
 
 // 16-/32-byte packet gathers through buffer loads: 32-bit offsets, one address instruction per gather
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -650,16 +622,11 @@ k_neighbor_force(const ForceParams<T> P) {
     // hands lane half h the rows 8g + 4h + k (g = 0 … 7, k = 0 … 3) of a chunk loaded in natural order, so bit p = 4g + k is candidate
     // 8g + k = p + (p & ~3) behind the base cb + 4h — the two lanes of a target take alternate groups of four candidates and their
     // pair counts differ by a handful instead of by half a cell (one v_and + one v_add per pair)
-    // (round 5, kSingles: the chunk is loaded PERMUTED inside its groups of eight — the lane that feeds matrix row 8g + 4h + k loads candidate
-    // 8g + 2k + h — so bit p = 4g + k of lane half h is candidate 2p + h: the two lanes of a target take alternate single candidates, the
-    // record offset of a pair is ONE shift-add on the bit number, and the two lanes gather neighbouring 32-byte records at the same time)
     constexpr bool kInterleave = kHalf && SPHMI_HALF_INTERLEAVE != 0;
-    constexpr bool kSingles = kInterleave && SPHMI_HALF_INTERLEAVE == 2;
     // record offset of the candidate at the lowest set bit of m, for an entry whose bit 0 sits at record offset `base`
     auto rec_of = [](const unsigned m, const unsigned base) -> unsigned {
         const unsigned p = (unsigned)__builtin_ctz(m);
-        if constexpr (kSingles) return (p << (kRecShift + 1)) + base;
-        else if constexpr (kInterleave) return ((p + (p & 0x1Cu)) << kRecShift) + base;
+        if constexpr (kInterleave) return ((p + (p & 0x1Cu)) << kRecShift) + base;
         else return (p << kRecShift) + base;
     };
     // (record offsets of the target's cell [cs_ar, ce_ar) and of the record BEHIND the target, a_r1: what the orientation rule and the kernel output compare with)
@@ -809,39 +776,20 @@ k_neighbor_force(const ForceParams<T> P) {
     //    other factors — two (three) transcendentals become multiplies, and the remaining two are issued back to back (sqrt_and_rcp);
     //  * the density-diffusion sum runs without its lane constant Kd_a (applied once after the loop);
     //  * Pressure! of a neighbour's ρ⁺ (corrector) as ρ⁷·(Cb/γ/ρ₀⁷) − Cb/γ: no scaling multiply;
-    //  * SPHMI_PACKED (off): {dx, dy}, {dvx, dvy}, {r², v·x}, {ax, ay}, {Σ continuity, Σ diffusion} in v_pk_*_f32 — measured slower: on gfx950
-    //    v_fma_f32 runs at the double rate like v_mul / v_add, a packed instruction at the full rate, so two FMAs cost what one packed FMA costs, and a
-    //    packed instruction among double-rate ones slows its neighbours (tools/ubench/pk_rates.hip).
+    //  (packed fp32 for the head of the pair and the accumulators — 47 instead of 56 vector instructions — was built and measured 1.3 % slower: on gfx950 v_fma_f32 runs at
+    //  the double rate and v_pk_* at the full rate; profiles/r05_retired_switches.patch)
     constexpr bool kFast = kFoldKv2 && MODEL >= 0 && ((MODEL >> 4) & 15) == kDdtLinear && SPHMI_FAST_PAIR != 0;
     constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5;      // (the diagnostic builds that keep the arithmetic)
-    constexpr bool kPacked = kFast && SPHMI_PACKED != 0;
-    [[maybe_unused]] f32x2 p_txy, p_tvxy, p_axy = {0.0f, 0.0f}, p_scd = {0.0f, 0.0f};
-    if constexpr (kPacked) { p_txy = f32x2{(float)xa, (float)ya}; p_tvxy = f32x2{(float)q1.x, (float)q1.y}; }
     [[maybe_unused]] auto pair_fast = [&](const V4& n0, const V4& n1, const bool a_is_i) {
         if constexpr (kFast) {
-            float dx, dy, dz = 0.0f, r2, vdx;
-            [[maybe_unused]] f32x2 dxy;
-            if constexpr (kPacked) {
-                dxy = pk_sub(p_txy, f32x2{n0.x, n0.y});                                 // { dx, dy }
-                const f32x2 dvxy = pk_sub(p_tvxy, f32x2{n1.x, n1.y});                   // { dvx, dvy }
-                const f32x2 sq = pk_mul(dxy, dxy), ab = pk_mul(dxy, dvxy);              // { dx², dy² }, { dx·dvx, dy·dvy }
-                dx = dxy.x; dy = dxy.y;
-                if constexpr (D == 3) {
-                    const f32x2 dzz = {za - n0.z, q1.z - n1.z};                         // { dz, dvz }: two scalar subtracts written side by side
-                    float s2x = sq.x + sq.y, s2y = ab.x + ab.y;
-                    asm("" : "+v"(s2x), "+v"(s2y));     // (keeps the two adds scalar: combined into one v_pk_add_f32 they cost three v_mov to line the operands up)
-                    const f32x2 rv = pk_fma_lo(dzz, dzz, f32x2{s2x, s2y});              // { dz·dz + …, dz·dvz + … } = { r², vᵢⱼ·xᵢⱼ }
-                    dz = dzz.x; r2 = rv.x; vdx = rv.y;
-                } else { r2 = sq.x + sq.y; vdx = ab.x + ab.y; }
-            } else {
-                dx = xa - n0.x; dy = ya - n0.y;
-                const float dvx = q1.x - n1.x, dvy = q1.y - n1.y;
-                if constexpr (D == 3) {
-                    dz = za - n0.z;
-                    const float dvz = q1.z - n1.z;
-                    r2 = dx * dx + dy * dy + dz * dz; vdx = dvx * dx + dvy * dy + dvz * dz;
-                } else { r2 = dx * dx + dy * dy; vdx = dvx * dx + dvy * dy; }
-            }
+            float dz = 0.0f, r2, vdx;
+            const float dx = xa - n0.x, dy = ya - n0.y;
+            const float dvx = q1.x - n1.x, dvy = q1.y - n1.y;
+            if constexpr (D == 3) {
+                dz = za - n0.z;
+                const float dvz = q1.z - n1.z;
+                r2 = dx * dx + dy * dy + dz * dz; vdx = dvx * dx + dvy * dy + dvz * dz;
+            } else { r2 = dx * dx + dy * dy; vdx = dvx * dx + dvy * dy; }
             float rho_b, rhon_b, s_b;
             if constexpr (PASS == PASS_CORRECTOR) { rho_b = n0.w; rhon_b = absT(n1.w); s_b = n1.w; }
             else { rho_b = absT(n0.w); rhon_b = rho_b; s_b = n0.w; }
@@ -867,8 +815,7 @@ k_neighbor_force(const ForceParams<T> P) {
             const float inv_sel = a_is_i ? inv_rhon_b : inv_rhon_a;
             const float Dv = inv_sel * (drn * (fac * (r2 * inv_r2e)));
             const float on = step01(s_b, P.big);
-            if constexpr (kPacked) p_scd = pk_fma(f32x2{cairb, on}, f32x2{fac * vdx, Dv}, p_scd);    // (the continuity sum in units of c_a: no transcendental's result read by the asm)
-            else { sum_c += inv_rho_b * (fac * vdx); sum_d += Dv * on; }
+            sum_c += inv_rho_b * (fac * vdx); sum_d += Dv * on;
             // pressure (src/SPHCellList.jl:301-303) + ArtificialViscosity (src/SPHViscosityModels.jl:56-74)
             float Psum;
             if constexpr (PASS == PASS_CORRECTOR) {
@@ -878,10 +825,7 @@ k_neighbor_force(const ForceParams<T> P) {
             const float vneg = min_raw(vdx, 0.0f);
             float coef = Psum * cairb + vneg * inv_r2e_rs;
             coef *= fac;
-            if constexpr (kPacked) {
-                f32x2 c2; c2.x = coef;                       // (the high half is never read — op_sel_hi — and stays undefined: no copy)
-                p_axy = pk_fma_lo(c2, dxy, p_axy);
-            } else { ax += coef * dx; ay += coef * dy; }
+            ax += coef * dx; ay += coef * dy;
             if constexpr (D == 3) az += coef * dz;
         }
     };
@@ -1087,8 +1031,7 @@ k_neighbor_force(const ForceParams<T> P) {
     // column for 16 candidate rows per 32×32 block; their sign bits are shifted into a word with
     // v_alignbit (one op per result), and one v_permlane32_swap hands each target lane both halves.
     // The candidates are loaded lane-permuted so that bit b of the mask is candidate cb + b.
-    const int bperm = kSingles ? ((lane & ~7) | ((lane & 3) << 1) | ((lane >> 2) & 1))
-                    : kInterleave ? lane : (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
+    const int bperm = kInterleave ? lane : (((lane >> 2) & 1) << 5) | ((lane >> 5) << 4) | (((lane >> 3) & 3) << 2) | (lane & 3);
     float B0[2], B1[2], B2[2], A2;
     if constexpr (kHalf) {
         // lanes l and l + 32 hold the same target: the operand layout without an exchange, one target block
@@ -1175,17 +1118,13 @@ k_neighbor_force(const ForceParams<T> P) {
             hi_l = valid ? P.cstart[key_a + off + 2] : 0;
         }
         // keys are sorted, cstart is monotone: the union over the tile is [lo(first), hi(last))
-        const int LO = (SPHMI_ALIGN_LO != 0 && kInterleave) ? (rl_i(lo_l, 0) & ~(SPHMI_ALIGN_LO * 4 - 1)) : rl_i(lo_l, 0);
+        const int LO = rl_i(lo_l, 0);
         const int HI = rl_i(hi_l, last_lane);
         // kInterleave: this lane's candidates of the chunk at cb are cb + 4·hl + 8g + k (g = 0 … 7, k = 0 … 3); how many of them sit below a
         // bound X relative to cb + 4·hl: below(X) = 4·(X >> 3) + min(X & 7, 4) (floor shift: exact for negative X too), and a chunk further on
         // it is 32 less — so the range of MY cells' bits is worked out once per row and moved by 32 per chunk
         [[maybe_unused]] int row_b0 = 0, row_b1 = 0;
-        if constexpr (kSingles) {
-            // (this lane's candidates are cb + hl + 2p: below(X) = ceil(X / 2), floor shift: exact for negative X too)
-            auto below = [](const int X) -> int { return (X + 1) >> 1; };
-            row_b0 = below(lo_l - LO - hl); row_b1 = below(hi_l - LO - hl);
-        } else if constexpr (kInterleave) {
+        if constexpr (kInterleave) {
             auto below = [](const int X) -> int { return 4 * (X >> 3) + min(X & 7, 4); };
             row_b0 = below(lo_l - LO - 4 * hl); row_b1 = below(hi_l - LO - 4 * hl);
         }
@@ -1266,14 +1205,12 @@ k_neighbor_force(const ForceParams<T> P) {
                 continue;
             }
 #endif
-            if constexpr (kSingles) push_entry((unsigned)m, cb + hl);
-            else if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
+            if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
             else if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
             else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }
         }
     }
     run_pairs(0, true);
-    if constexpr (kPacked && kFastDiag) { ax = p_axy.x; ay = p_axy.y; sum_c = p_scd.x / c_a; sum_d = p_scd.y; }
     if constexpr (kFast && kFastDiag) sum_d *= Kd_a;
     if constexpr (kFoldKv2) { const T k = P.Kv2 * P.Cfac; ax *= k; ay *= k; az *= k; sum_c *= P.Cfac; sum_d *= P.Cfac; }
     drho = rm_a * sum_c + sum_d;                        // continuity (src/SPHCellList.jl:289-291) + density diffusion
