@@ -492,7 +492,9 @@ struct Engine final : EngineBase {
         P.m0 = (T)cfg.m0;
         P.Kddt = (T)(cfg.delta_phi * cfg.h * cfg.c0 * cfg.m0);
         P.linfac = (T)(cfg.rho0 * cfg.g * ((1.0 / (cfg.Cb * cfg.gamma)) * cfg.rho0));
-        P.eta2 = (T)cfg.eta2;
+        // (η² = 0 is legal in the reference — src/SPHKernels.jl: η² ≥ 0 — whose pair loop never meets i == j; the gather kernel's accept masks DO hold the
+        // self pair, every term of which is an exact zero as long as 1/(r² + η²) is finite: 1e-24·h² keeps it so and moves no other pair by an ulp, fp64 included)
+        P.eta2 = (T)std::max(cfg.eta2, 1e-24 * cfg.h * cfg.h);
         P.Kv2 = kv2();
         P.inv_Kv2 = kv2_foldable() ? T(1) / P.Kv2 : T(1);
         P.visc = cfg.viscosity; P.ddt = cfg.density_diffusion; P.shift = cfg.shifting == SPHMI_SHIFT_PLANAR;

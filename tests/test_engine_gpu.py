@@ -203,6 +203,27 @@ def test_error_paths(dam_break_2d):
     assert ei.value.status == ERR_DOMAIN
 
 
+@pytest.mark.parametrize("fb,tol", [(8, 1e-10), (4, 2e-4)])
+def test_eta_squared_zero(dam_break_2d, fb, tol):
+    """η² = 0 is a legal SPHKernelInstance (src/SPHKernels.jl:41: η² ≥ 0): the reference's pair loop never visits i == j, the engine's accept masks hold the self
+    pair — its terms must stay exact zeros, not 0·∞."""
+    import dataclasses
+    p, s = dam_break_2d
+    p = perturbed(p, seed=5)
+    p.Position += 0.513        # (Δt's viscous term divides by |x|² + η², src/TimeStepping.jl:30-37: a particle AT the origin is 0/0 in the reference too)
+    import copy
+    kern = copy.copy(s.SimKernel); kern.eta2 = 0.0
+    s0 = dataclasses.replace(s, SimKernel=kern)
+    eng, orc = engines(p, s0, fb)
+    d1, a1 = eng.forces_once(); d2, a2 = orc.forces_once()
+    i1, i2 = np.argsort(eng.download(("ID",))["ID"]), np.argsort(orc.download(("ID",))["ID"])
+    assert np.isfinite(d1).all() and np.isfinite(a1).all()
+    assert relmax(d1[i1], d2[i2]) < tol and relmax(a1[i1], a2[i2]) < tol
+    pe, po = eng.advance(1e9, max_steps=10), orc.advance(1e9, max_steps=10)
+    e, o = by_id(eng.download()), by_id(orc.download())
+    assert relmax(e["Density"], o["Density"]) < (1e-9 if fb == 8 else 1e-5)
+
+
 def test_a_far_flung_particle_does_not_end_the_run(dam_break_3d_shipped):
     """The reference keeps its cells in a Dict (src/SPHCellList.jl:145-157) and never refuses a domain; the engine's dense bounding grid had a default budget
     of 2^27 cells until round 5.  One fluid particle thrown far beyond the tank — a bounding grid of ≈2.9e8 cells, twice the old budget — must not end the
