@@ -67,14 +67,18 @@ def test_a_missing_rccl_is_an_error_not_a_crash():
         "buf = C.create_string_buffer(128)\n"
         "for k in range(2):\n"
         "    rc = lib.sphmi_rccl_unique_id(buf)\n"
-        "    print(rc, lib.sphmi_last_error(None).decode())\n" % ROOT)
+        "    print(rc, lib.sphmi_last_error(None).decode())\n"
+        "rc = lib.sphmi_rccl_probe()\n"
+        "print('probe', rc, lib.sphmi_last_error(None).decode())\n" % ROOT)
     env = dict(os.environ, SPHMI_RCCL_LIB="/nonexistent/librccl.so.1")
     pr = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert pr.returncode == 0, pr.stderr[-2000:]
     lines = pr.stdout.strip().splitlines()
-    assert len(lines) == 2
-    for ln in lines:
+    assert len(lines) == 3
+    for ln in lines[:2]:
         assert ln.startswith(f"{ERR_DEVICE} ") and "RCCL not found" in ln and "/nonexistent/librccl.so.1" in ln
+    # … and the probe (what the ranks that do not hand out the id call: no bootstrap root) says the same
+    assert lines[2].startswith(f"probe {ERR_DEVICE} ") and "RCCL not found" in lines[2]
 
 
 def test_struct_layout_matches_header():
