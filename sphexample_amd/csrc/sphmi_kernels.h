@@ -19,9 +19,11 @@
 //   phase 1  "who is within H".  For each of the 3^(D-1) cell rows around the tile the three x-adjacent
 //            cells of every target are one contiguous particle range (x is the fastest sort axis); the
 //            union over the tile is scanned in 64-candidate chunks, one candidate per lane, loaded
-//            coalesced.  The 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores
-//            (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain) in tile-local coordinates, for fp32 AND fp64 handles
-//            (the mask only has to be a superset; the pair loop is exact); every lane ends up with the results
+//            coalesced.  The 64×64 matrix |c−t|² − H'² of a chunk comes from the matrix cores in tile-local coordinates,
+//            for fp32 AND fp64 handles (the mask only has to be a superset; the pair loop is exact) — half tiles: ONE
+//            v_mfma_f32_32x32x16_f16 per 32×32 block on hi + lo split operands (the f32-input instruction runs on the
+//            vector ALU's multipliers and stalls every wave of the SIMD; scan_chunk16), full tiles: three
+//            v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain); every lane ends up with the results
 //            of ITS target, packs their sign bits with v_alignbit, clears the bits outside its own three cells
 //            and pushes each non-empty 32-candidate half as { mask, index of bit 0 } onto its private LDS queue.
 //   phase 2  "pair physics".  A lane fetches its next non-empty mask the moment the current one is used up,
@@ -57,9 +59,10 @@ template <class V> struct Half {
 
 constexpr int kWave = 64;
 // Build switches that remain.  Everything else that rounds 2 and 3 measured and left off (role bits in the queue entries, half
-// prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the f16 distance matrix, the predictor's masks handed to the
-// corrector, the sign bits on the matrix pipe) lives as patches under profiles/ (r03_raw/mask_mfma_experiment.patch,
-// r04_retired_switches.patch) with its figures in profiles/r03_pair_loop_experiments.md — not in this file.
+// prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the predictor's masks handed to the corrector, the sign bits
+// on the matrix pipe; round 5: packed fp32 arithmetic, lane pairs that gather one record per instruction) lives as patches under
+// profiles/ (r03_raw/mask_mfma_experiment.patch, r04_retired_switches.patch, r05_retired_switches.patch,
+// r05_pair_gather_experiment.patch) with its figures in profiles/r03_pair_loop_experiments.md and DESIGN §4.9 — not in this file.
 #ifndef SPHMI_LDS_STAGE
 #define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
@@ -72,6 +75,10 @@ constexpr int kWave = 64;
 #ifndef SPHMI_HALF4
 #define SPHMI_HALF4 1           // four-wave tiles: 1 = two half tiles of two waves each (the waves of a half deal its chunks alternately), 0 = four waves
                                 // that serve the tile's 64 targets and split its chunks (rounds 2-4) — A/B builds only
+#endif
+#ifndef SPHMI_F16_SCAN
+#define SPHMI_F16_SCAN 1        // half tiles: the distance matrix of phase 1 from ONE v_mfma_f32_32x32x16_f16 per 32x32 block instead of three
+                                // v_mfma_f32_32x32x2_f32 (see scan_chunk16).  0 = the f32-input form (A/B builds; what full tiles keep)
 #endif
 #ifndef SPHMI_HALF_INTERLEAVE
 #define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0: A/B builds).
@@ -404,6 +411,16 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v,
 // ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+// two floats -> one register of two halves, rounded towards zero (any rounding will do for a hi + lo split: lo takes what hi left)
+__device__ __forceinline__ unsigned pk_h2(float a, float b) { const h16x2 p = __builtin_amdgcn_cvt_pkrtz(a, b); return __builtin_bit_cast(unsigned, p); }
+__device__ __forceinline__ float lo_half_as_float(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[0]; }
+// v = hi + lo + O(2^-20 |v|): { hi, lo } in one register ...
+__device__ __forceinline__ unsigned split_hl(float v) { const unsigned h = pk_h2(v, 0.0f); return pk_h2(v, v - lo_half_as_float(h)); }
+// ... and as { hi, hi }, { lo, lo }
+__device__ __forceinline__ void split_hh_ll(float v, unsigned& hh, unsigned& ll) { hh = pk_h2(v, v); const float r = v - lo_half_as_float(hh); ll = pk_h2(r, r); }
 
 // v_permlane32_swap: returns { {p.lower, q.lower}, {p.upper, q.upper} } — the lane pattern both MFMA
 // operands want ("lanes 0-31: component k of item l, lanes 32-63: component k+1 of item l-32").
@@ -1043,6 +1060,60 @@ k_neighbor_force(const ForceParams<T> P) {
     B2[0] = -thr; B2[1] = 0.0f; swap_halves(B2[0], B2[1]);     //      {k4: |t|²−H'² | k5: 0}
     }
     A2 = lane < 32 ? 1.0f : 0.0f;                               // candidates: {k4: 1 | k5: 0}
+    // ---- half tiles: the same matrix from the f16-input matrix instruction ----------------------------------------------
+    // v_mfma_f32_32x32x2_f32 runs on the VECTOR ALU's fp32 multipliers: every one of the six per chunk keeps the SIMD's vector issue busy
+    // for ~80 cycles, for every wave on it (tools/ubench/poison_mix.hip: 1 per 32 double-rate instructions 95 -> 176 cycles per body, and
+    // the waves next to it pay the same) — a quarter of a launch.  v_mfma_f32_32x32x16_f16 costs ~15 (same benchmark).
+    // Tile-local coordinates scaled by sc = 16/H — or less, so that the reach of the tile stays below 192 and |c|^2 inside the half
+    // range; every coordinate is split into hi + lo halves (products of halves are exact in the fp32 accumulator), so that
+    // |c|^2 - 2 c.t + |t|^2 - (sc H)^2 (1 + eps)  is the sum of sixteen products:
+    //   lanes 0-31  (k 0...7):  cxh m2xh  cxh m2xl  cxl m2xh  cxl m2xl   cyh m2yh  cyh m2yl  cyl m2yh  cyl m2yl      (m2 = -2t)
+    //   lanes 32-63 (k 8...15): the same four for z,   cch 1   ccl 1   1 thh   1 thl                                (cc = |c|^2, th = |t|^2 - cut)
+    // eps = 3e-4 + 2.5e-5 R^2 + 0.03/(sc H)^2  (R = reach of the tile in units of H) covers the residual of the splits (2^-20 relative
+    // per value, both roundings towards zero), the fp32 accumulation and half-precision subnormals flushed by the matrix pipe (lo
+    // parts below 6e-5 times a partner of at most 384).  An ordinary tile reaches 4-5 H: eps ~ 1e-3, 0.15 % more candidates for the
+    // pair loop; a tile of spray that spans 100 H gets eps ~ 0.26.  The mask is a superset either way; the pair loop applies the exact cut.
+    constexpr bool kF16 = kHalf && SPHMI_F16_SCAN != 0;
+    [[maybe_unused]] u32x4s Bh = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] float hinv = 0.0f;
+    if constexpr (kF16) {
+        const float Hinv = __builtin_amdgcn_rsqf((float)P.H2);
+        const float Rs = fast_sqrt(wave_max(owned ? tt : 0.0f)) * Hinv + 3.0f;            // wave-uniform
+        hinv = Hinv * fminf(16.0f, 192.0f * fast_rcp(Rs));
+        const float thr_s = (hinv * hinv) * (float)P.H2;                                  // (sc H)^2: 256 for ordinary tiles
+        const float sx = owned ? txl * hinv : 0.0f, sy = owned ? tyl * hinv : 0.0f, sz = owned ? tzl * hinv : 0.0f;
+        const float tts = sx * sx + sy * sy + sz * sz;
+        const float eps16 = 3e-4f + 2.5e-5f * (Rs * Rs) + 0.03f * fast_rcp(thr_s);
+        const float th = owned ? tts - thr_s * (1.0f + eps16) : 60000.0f;
+        // (lanes l and l + 32 hold the same target: the lower one supplies k 0...7, the upper one k 8...15)
+        const unsigned bx = split_hl(-2.0f * sx), by = split_hl(-2.0f * sy), bz = split_hl(-2.0f * sz), bt = split_hl(th), one2 = pk_h2(1.0f, 1.0f);
+        Bh[0] = hl ? bz : bx; Bh[1] = Bh[0]; Bh[2] = hl ? one2 : by; Bh[3] = hl ? bt : by;
+    }
+    auto scan_chunk16 = [&](const int cb, const int HI, const V4& cpk) -> unsigned long long {
+        const int c = cb + bperm;
+        const bool cv = c < HI;
+        // (a lane beyond the row's end: coordinates 0 and |c|^2 far beyond the cut — every sum stays positive)
+        const float cx = cv ? (float)(cpk.x - ox) * hinv : 0.0f, cy = cv ? (float)(cpk.y - oy) * hinv : 0.0f, cz = cv ? (float)(cpk.z - oz) * hinv : 0.0f;
+        const float cc = cv ? cx * cx + cy * cy + cz * cz : 60000.0f;
+        unsigned X[4], Z[4];
+        split_hh_ll(cx, X[0], X[1]); split_hh_ll(cy, X[2], X[3]);
+        split_hh_ll(cz, Z[0], Z[1]); Z[2] = split_hl(cc); Z[3] = pk_h2(1.0f, 1.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) swap_halves(X[k], Z[k]);             // X: block of candidates 0...31, Z: block of candidates 32...63
+        unsigned W = 0u;
+#pragma unroll
+        for (int C = 1; C >= 0; --C) {
+            if (kInterleave && C == 1 && HI - cb <= 32) continue;       // (as in scan_chunk)
+            u32x4s aw; aw[0] = C ? Z[0] : X[0]; aw[1] = C ? Z[1] : X[1]; aw[2] = C ? Z[2] : X[2]; aw[3] = C ? Z[3] : X[3];
+            f32x16 d = {0};
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aw), __builtin_bit_cast(f16x8, Bh), d, 0, 0, 0);
+#pragma unroll
+            for (int r = 15; r >= 0; --r)
+                W = __builtin_amdgcn_alignbit(W, __float_as_uint(d[r]), 31);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return (unsigned long long)W;
+    };
     // (half tiles: through the buffer descriptor of the gathers — one address instruction instead of a compare, a select and 64-bit
     // pointer arithmetic; a lane beyond HI reads a record that phase 1 then discards (`cv`), one beyond the array reads zeros)
     auto chunk_packet = [&](const int cb, const int HI) -> V4 {
@@ -1148,7 +1219,8 @@ k_neighbor_force(const ForceParams<T> P) {
             unsigned long long m;
             {
                 const V4 cpk = chunk_packet(cb, HI);
-                m = scan_chunk(cb, HI, cpk);
+                if constexpr (kF16) m = scan_chunk16(cb, HI, cpk);
+                else m = scan_chunk(cb, HI, cpk);
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
                 // quirk Q1): bits [lo_l − cb, hi_l − cb) of the tile-wide mask
                 if constexpr (kInterleave) {

@@ -8,7 +8,7 @@
 #define F4 "v_mul_f32 %0,%0,%1\n v_fma_f32 %4,%4,%5,%5\n v_mul_f32 %2,%2,%3\n v_fma_f32 %6,%6,%7,%7\n"
 #define F8 F4 F4
 #define F32 F8 F8 F8 F8
-#define ASM(B) asm volatile(".rept 16\n" B "\n.endr" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83")
+#define ASM(B) asm volatile(".rept 16\n" B "\n.endr" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83")
 template <int SUSPECT>
 __global__ void __launch_bounds__(256) k_mix(float* sink, int dirty_mod) {       // dirty_mod: 0 = nobody, 1 = everybody, 2 = every second wave of every SIMD
     float a = threadIdx.x * 0.5f + 1.f, b = 1.0001f, c = 0.3f, d = 0.7f, e = 1.1f, f = 0.9f, g = 1.3f, h = 0.8f;
@@ -25,6 +25,12 @@ __global__ void __launch_bounds__(256) k_mix(float* sink, int dirty_mod) {      
             else if constexpr (SUSPECT == 1) ASM("v_mfma_f32_32x32x2_f32 v[68:83], %0, %1, v[68:83]\n" F32);
             else if constexpr (SUSPECT == 2) ASM("v_permlane32_swap_b32 %5, %6\n" F32);
             else if constexpr (SUSPECT == 3) ASM("v_rcp_f32 %1,%1\n" F8 "v_sqrt_f32 %3,%3\n" F8 "v_rcp_f32 %5,%5\n" F8 "v_rcp_f32 %7,%7\n" F8);      // one per 8
+            else if constexpr (SUSPECT == 5) ASM("v_rcp_f32 %1,%1\n s_nop 0\n" F32);                                   // … followed by a scalar instruction, as in the kernels
+            else if constexpr (SUSPECT == 6) ASM("v_sqrt_f32 %1,%1\n v_rcp_f32 %3,%3\n s_nop 0\n" F32 F8 F8 F8);            // the pair loop's ratio: 2 per 56
+            else if constexpr (SUSPECT == 7) ASM("v_mfma_f32_32x32x2_f32 v[68:83], %0, %1, v[68:83]\n s_nop 7\n" F32);
+            else if constexpr (SUSPECT == 8) ASM("v_mfma_f32_32x32x16_f16 v[68:83], v[60:63], v[64:67], v[68:83]\n s_nop 0\n" F32);   // the f16-input form: 8 passes
+            else if constexpr (SUSPECT == 9) ASM("v_mfma_f32_32x32x16_f16 v[68:83], v[60:63], v[64:67], v[68:83]\n v_mfma_f32_32x32x16_f16 v[68:83], v[60:63], v[64:67], v[68:83]\n s_nop 0\n" F32);
+            else if constexpr (SUSPECT == 10) ASM("v_mfma_f32_32x32x2_f32 v[68:83], %0, %1, v[68:83]\n v_mfma_f32_32x32x2_f32 v[68:83], %0, %1, v[68:83]\n s_nop 0\n" F32);
             else ASM("v_alignbit_b32 v60,v60,v61,31\n v_alignbit_b32 v60,v60,v62,31\n" F8 "v_alignbit_b32 v60,v60,v61,31\n v_alignbit_b32 v60,v60,v62,31\n" F8 "v_alignbit_b32 v60,v60,v61,31\n v_alignbit_b32 v60,v60,v62,31\n" F8 "v_alignbit_b32 v60,v60,v61,31\n v_alignbit_b32 v60,v60,v62,31\n" F8);
         }
     }
@@ -46,7 +52,7 @@ int main() {
     };
     for (int rep = 0; rep < 2; ++rep) {
         run("v_rcp_f32, 1 per 32", k_mix<0>); run("v_mfma_f32_32x32x2, 1 per 32", k_mix<1>); run("v_permlane32_swap, 1 per 32", k_mix<2>);
-        run("transcendental, 1 per 8", k_mix<3>); run("2 v_alignbit per 8 (control)", k_mix<4>);
+        run("transcendental, 1 per 8", k_mix<3>); run("v_rcp + s_nop, 1 per 32", k_mix<5>); run("sqrt, rcp, s_nop per 56", k_mix<6>); run("v_mfma + s_nop 7, 1 per 32", k_mix<7>); run("f16 mfma 32x32x16, 1 per 32", k_mix<8>); run("f16 mfma 32x32x16, 2 per 32", k_mix<9>); run("f32 mfma 32x32x2, 2 per 32", k_mix<10>); run("2 v_alignbit per 8 (control)", k_mix<4>);
     }
     return 0;
 }
