@@ -97,8 +97,8 @@ constexpr int kWave = 64;
                                 // the loop — round 5); 0 = pair_core for every kernel (rounds 1-4), A/B builds
 #endif
 #ifndef SPHMI_DIAG
-#define SPHMI_DIAG 0            // 1 / 2 / 4 / 5: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
-                                // neither / adjacent lanes sharing a gathered record
+#define SPHMI_DIAG 0            // 1 / 2 / 4 / 5 / 8: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
+                                // neither / adjacent lanes sharing a gathered record / adjacent lanes walking the union of their masks (§4.9)
 #endif
 
 // Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles
@@ -796,7 +796,7 @@ k_neighbor_force(const ForceParams<T> P) {
     //  (packed fp32 for the head of the pair and the accumulators — 47 instead of 56 vector instructions — was built and measured 1.3 % slower: on gfx950 v_fma_f32 runs at
     //  the double rate and v_pk_* at the full rate; profiles/r05_retired_switches.patch)
     constexpr bool kFast = kFoldKv2 && MODEL >= 0 && ((MODEL >> 4) & 15) == kDdtLinear && SPHMI_FAST_PAIR != 0;
-    constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5;      // (the diagnostic builds that keep the arithmetic)
+    constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5 || SPHMI_DIAG == 8;      // (the diagnostic builds that keep the arithmetic)
     [[maybe_unused]] auto pair_fast = [&](const V4& n0, const V4& n1, const bool a_is_i) {
         if constexpr (kFast) {
             float dz = 0.0f, r2, vdx;
@@ -1276,6 +1276,10 @@ k_neighbor_force(const ForceParams<T> P) {
                 }
                 continue;
             }
+#endif
+#if SPHMI_DIAG == 8
+            // DIAGNOSTIC BUILD (wrong results): adjacent lanes — adjacent targets — walk the UNION of their accept masks in step and gather the same record
+            m = (unsigned long long)((unsigned)m | (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)m, 0xB1, 0xF, 0xF, true));
 #endif
             if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
             else if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
