@@ -55,7 +55,8 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 # vector-ALU issue peak of the data sheet: 256 CUs × 4 SIMD-32, one wave64 instruction per 2 cycles each at 2.4 GHz (= the
 # 157.3 TFLOP/s fp32 vector peak when every instruction is an FMA; MI355X_MICROARCH.md).  The SQ "busy" counter charges a
 # quad-cycle per instruction instead (measured issue cost of most of this kernel's instructions: tools/ubench/valu_rates2.hip).
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+SHADER_CLOCK_HZ, N_CU = 2.4e9, 256
+VALU_ISSUE_PEAK = N_CU * 4 * SHADER_CLOCK_HZ / 2.0
 COUNTER_RECORD = "profiles/r05_counters.json"
 DP1 = 0.00425
 BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 2, 2>", "corrector": "k_neighbor_force<float, 3, 2, 33, 2, 2>"}
@@ -105,6 +106,18 @@ def counters_for(identity, n_local, kern_ms):
             "waves_per_simd_pmc": 0.5 * (c["predictor"]["waves_per_simd_mean"] + c["corrector"]["waves_per_simd_mean"]),
             "wave_time_on_waitcnt_pmc": 0.5 * (c["predictor"]["wave_time_parked_on_waitcnt"] + c["corrector"]["wave_time_parked_on_waitcnt"]),
             "unit": "wave64 vector instructions/s", "source": COUNTER_RECORD}
+    # The unit the launch runs out of since the middle of round 5: the texture path charges a wave-level gather by its lanes and
+    # segments, not by its bytes — tools/ubench/gather4.hip on this chip, CU-cycles per b128 instruction with the data in L1: 34 for 64 lanes
+    # with scattered records inside 4 KB, 26 for 32 lanes, 17 coalesced.  The kernels' gathers have ≈50 of 64 lanes switched on.
+    gathers = 0.5 * (c["predictor"].get("vmem_rd_insts", 0.0) + c["corrector"].get("vmem_rd_insts", 0.0)) * n_local / n_prof
+    cyc = kern_ms * 1e-3 * SHADER_CLOCK_HZ * N_CU / gathers if gathers > 0 and kern_ms > 0 else 0.0
+    if gathers > 0:
+        valu["gather"] = {"wave_gathers_per_launch": gathers, "cu_cycles_per_gather": cyc,
+                          "ubench_cu_cycles_per_gather": {"64 lanes scattered in 4 KB": 34.1, "32 lanes scattered": 26.5, "coalesced": 17.4},
+                          "frac_of_ubench_rate_64_lanes": 34.1 / cyc if cyc > 0 else None,
+                          "ta_busy_frac_pmc": 0.5 * (c["predictor"].get("ta_busy_frac", 0.0) + c["corrector"].get("ta_busy_frac", 0.0)),
+                          "l1_hit_frac_pmc": 0.5 * (c["predictor"].get("l1_hit_frac", 0.0) + c["corrector"].get("l1_hit_frac", 0.0)),
+                          "source": COUNTER_RECORD + ", profiles/r05_raw/gather4_l1.txt"}
     traffic = rec["traffic"]["bytes_per_particle_per_launch_corrected"] * n_local if "traffic" in rec else None
     return traffic, valu, None
 
@@ -469,8 +482,9 @@ def main():
                        "preconditioning": (f"{pre_steps} untimed steps of a scratch handle (≈{args.precondition_ms:.0f} ms of the same kernels) before the "
                                            f"{args.warmup} warm-up steps: clock governor out of its idle state; the measured handle ran {args.warmup} + {args.steps} "
                                            f"steps; value_cold is the same window without it") if pre_steps else "none"},
-            "roofline": {"bound": "valu_issue", "hbm_note": "achieved / peak / frac are the HBM figure BASELINE.json's metric asks for (algorithmic bytes ÷ kernel time "
-                                                            "÷ 8 TB/s); the kernel is bound by vector-ALU issue — `valu`",
+            "roofline": {"bound": "gather_issue", "hbm_note": "achieved / peak / frac are the HBM figure BASELINE.json's metric asks for (algorithmic bytes ÷ kernel time "
+                                                              "÷ 8 TB/s); the kernel is bound by the rate at which the texture path takes per-lane gathers — `valu.gather` — "
+                                                              "with vector-ALU issue 25 % behind (`valu`; until the middle of round 5 it was the other way round)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs if copy_gbs > 0 else None,
                          "peak_measured_source": "1 GiB device-to-device copy (read + write bytes) on this GPU, measured in this run before the warm-up steps",

@@ -38,7 +38,7 @@ def test_bench_line_single_gpu():
     assert j["vs_baseline"] is None and j["value"] > 0 and "workload" in j["config"]
     rf = j["roofline"]
     # `bound` names the binding resource; achieved / peak / frac stay the HBM figure the metric asks for
-    assert rf["bound"] == "valu_issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["bound"] == "gather_issue" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert j["value_excl_rebuild"] >= j["value"] and j["rebuild_ms_in_window"] >= 0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert rf["peak_measured"] > 1000.0 and rf["launches_expected"] == 2 * j["steps"] and rf["launch_time_samples"] > 0 and rf["avg_launch_ms"] > 0

@@ -530,7 +530,7 @@ def test_example_step_times_stay_in_their_class(case, limit_us):
 
 def test_config_3_kernel_time_stays_in_its_class():
     """The same guard on the headline: BASELINE config 3 (1 057 738 particles, fp32), the neighbour kernel's average launch — HIP events on the
-    engine's own stream, what bench.py's roofline divides by — stays below 0.47 ms (round 4: 0.445, round 5: 0.436) after the clock governor has
+    engine's own stream, what bench.py's roofline divides by — stays below 0.455 ms (round 4: 0.445, round 5: 0.436 with the f32-input matrix instructions in phase 1, 0.413-0.431 over five boxes with the f16-input one) after the clock governor has
     left its idle state."""
     from sphexample_amd.engine import make_generated_dam_break_engine
     eng = make_generated_dam_break_engine(0.00425, setup_dam_break_3d(0.00425), device_float_bytes=4)
@@ -542,7 +542,7 @@ def test_config_3_kernel_time_stays_in_its_class():
         ms, n = eng.force_kernel_stats()
         assert n > 0
         best = min(best, ms)
-    assert best < 0.47, f"{best:.4f} ms per launch"
+    assert best < 0.455, f"{best:.4f} ms per launch"
 
 
 @pytest.mark.parametrize("k", [1.5, 2.0, 2.5])
