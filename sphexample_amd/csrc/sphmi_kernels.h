@@ -62,7 +62,7 @@ constexpr int kWave = 64;
 // prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the predictor's masks handed to the corrector, the sign bits
 // on the matrix pipe; round 5: packed fp32 arithmetic, lane pairs that gather one record per instruction) lives as patches under
 // profiles/ (r03_raw/mask_mfma_experiment.patch, r04_retired_switches.patch, r05_retired_switches.patch,
-// r05_pair_gather_experiment.patch) with its figures in profiles/r03_pair_loop_experiments.md and DESIGN §4.9 — not in this file.
+// r05_pair_gather_experiment.patch, r05_deep_pair_experiment.patch) with its figures in profiles/r03_pair_loop_experiments.md and DESIGN §4.9 — not in this file.
 #ifndef SPHMI_LDS_STAGE
 #define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
