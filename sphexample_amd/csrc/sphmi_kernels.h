@@ -76,6 +76,10 @@ constexpr int kWave = 64;
 #define SPHMI_HALF4 1           // four-wave tiles: 1 = two half tiles of two waves each (the waves of a half deal its chunks alternately), 0 = four waves
                                 // that serve the tile's 64 targets and split its chunks (rounds 2-4) — A/B builds only
 #endif
+#ifndef SPHMI_BALANCE
+#define SPHMI_BALANCE 1         // interleaved half tiles: per chunk the lane of a target that has had FEWER pairs so far takes the larger of the two interleaved shares
+                                // (whole 32-bit words change hands; see the push of phase 1).  0 = every lane keeps the share the matrix layout hands it (A/B builds)
+#endif
 #ifndef SPHMI_F16_SCAN
 #define SPHMI_F16_SCAN 1        // half tiles: the distance matrix of phase 1 from ONE v_mfma_f32_32x32x16_f16 per 32x32 block instead of three
                                 // v_mfma_f32_32x32x2_f32 (see scan_chunk16).  0 = the f32-input form (A/B builds; what full tiles keep)
@@ -1172,6 +1176,7 @@ k_neighbor_force(const ForceParams<T> P) {
         }
         __syncthreads();
     }
+    [[maybe_unused]] int bal = 0;                       // SPHMI_BALANCE: pairs queued by the lower lane of this target so far − pairs queued by the upper one
     auto push_entry = [&](const unsigned bits, const int c0) {
         if (bits != 0) {
             *reinterpret_cast<uint2*>(s_qb + waddr) = make_uint2(bits, (unsigned)c0 << kRecShift); waddr = q_next(waddr); qn += 1;
@@ -1281,6 +1286,21 @@ k_neighbor_force(const ForceParams<T> P) {
             // DIAGNOSTIC BUILD (wrong results): adjacent lanes — adjacent targets — walk the UNION of their accept masks in step and gather the same record
             m = (unsigned long long)((unsigned)m | (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)m, 0xB1, 0xF, 0xF, true));
 #endif
+            if constexpr (kInterleave && SPHMI_BALANCE != 0) {
+                // Who takes which share.  The two lanes of a target get the candidates 8g + k and 8g + 4 + k of a chunk — a random half each, and a wave runs as many
+                // pair iterations as its fullest LANE needs: 79.8 per half tile at rest with 85 % of the lane slots busy, where two equal halves would need 72.5
+                // (tools/half_tile_balance_sim.py).  Every idle slot is texture-path time, so per chunk the lane that is BEHIND takes the larger of the two
+                // words: whole words change hands (a 128-byte line stays with one lane, one queue entry per lane and chunk as before), the running difference `bal` =
+                // pairs of the lower lane − pairs of the upper lane is kept identically on both.  Simulated: 74.5 iterations, 91 %.
+                unsigned wl = (unsigned)m, wu = (unsigned)m;
+                swap_halves(wl, wu);                                     // wl: the lower lane's word on both lanes, wu: the upper lane's
+                const int cl = __builtin_popcount(wl), cu = __builtin_popcount(wu);
+                const bool lower_takes_upper = (bal <= 0) != (cl >= cu);          // the lower lane is behind (or level) and its own word is the smaller one, or ahead and its own the larger
+                const int d = lower_takes_upper ? cu - cl : cl - cu;
+                bal += d;
+                const bool take_upper = lower_takes_upper != (hl != 0);
+                push_entry(take_upper ? wu : wl, cb + (take_upper ? 4 : 0));
+            } else
             if constexpr (kInterleave) push_entry((unsigned)m, cb + 4 * hl);
             else if constexpr (kHalf) push_entry((unsigned)m, cb + 32 * hl);
             else { push_entry((unsigned)m, cb); push_entry((unsigned)(m >> 32), cb + 32); }

@@ -55,6 +55,15 @@ def lane_entries(masks, mode):
         grp = (np.arange(64) >> 2) & 1
         if mode == "interleave":
             e = np.concatenate([m[:, grp == 0].sum(1), m[:, grp == 1].sum(1)])
+        elif mode == "swap":
+            # no splitting: per chunk the lane that is behind takes the LARGER of the two interleaved shares (whole words change hands: one entry per lane and chunk as now)
+            c0, c1 = m[:, grp == 0].sum(1), m[:, grp == 1].sum(1)
+            big, small = np.maximum(c0, c1), np.minimum(c0, c1)
+            lane0_big = flip <= 0                                  # flip = T0 - T1 so far
+            e0 = np.where(lane0_big, big, small); e1 = np.where(lane0_big, small, big)
+            flip = flip + e0 - e1
+            ent.append(np.concatenate([e0, e1]))
+            continue
         elif mode == "adaptive":
             # as greedy, the cut chosen per chunk among 8 / 16 / ... / 56 so that the totals end up closest
             a0, a1 = m[:, grp == 0], m[:, grp == 1]
@@ -116,7 +125,7 @@ def simulate(ent, QCAP=10):
     return iters, slots
 
 
-for mode in ("interleave", "halves", "greedy32", "adaptive"):
+for mode in ("interleave", "halves", "swap", "greedy32", "adaptive"):
     it = 0; sl = 0.0; lb = 0
     for ht in halves:
         ent = lane_entries(chunk_masks(ht), mode)
