@@ -113,10 +113,18 @@ constexpr int kWave = 64;
 // 14 → 1.037e9, 16 → 0.983e9 / 1.019e9: 12 entries = 6 KB per wave = six four-tile blocks (24 waves) per compute unit.
 // The fp64 kernels hold ≤ 16 waves per unit by their registers: 16 entries.
 // Eight waves per tile (the smallest cases; four waves per half tile) scan every fourth chunk of their half: eight entries.
+#ifndef SPHMI_QCAP_HALF2
+#define SPHMI_QCAP_HALF2 6      // fp32 half tiles of ONE wave per half, compiled-in models (the launches of 3 000 tiles and more: the bench)
+#endif
 template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
     // (fp64 half tiles: 10 / 12 / 16 / 20 entries all within 0.5 % of each other at 1.06 M / 159 k / 70 k particles: sixteen stay)
     // (half tiles of two / four waves per half: 8 / 10 / 12 / 16 and 6 / 8 / 10 / 12 entries within 1 % of each other from 273 to 2 482 tiles)
-    return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? 10 : 12));
+    // (round 5, after the two lanes of a target had learnt to share evenly (SPHMI_BALANCE): fp32 half tiles of one wave per half with a compiled-in model run
+    // 4 / 5 / 6 / 10 entries at 0.4161 / 0.4081 / 0.4093 / 0.4160 ms per launch at C3, five interleaved repetitions — more, shorter bursts of the pair loop,
+    // whose lanes drift less apart: 8.15 instead of 7.03 M gathers per launch at 30 instead of 36 CU-cycles each, the L1 hits 81-83 % instead of 77;
+    // it is the corrector's queue that matters (predictor 6 + corrector 10: no gain).  The run-time models lose 5-12 % with six and keep ten,
+    // every other class is within noise of its value: profiles/r05_raw/qcap_*.txt)
+    return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? (MODEL >= 0 ? SPHMI_QCAP_HALF2 : 10) : 12));
 }
 constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
 
