@@ -126,7 +126,9 @@ template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
     // every other class is within noise of its value: profiles/r05_raw/qcap_*.txt)
     return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? (MODEL >= 0 ? SPHMI_QCAP_HALF2 : 10) : 12));
 }
-constexpr int kQueueSlack = 1;     // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on
+// a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on: one, and two for the six-entry queues (0.4228 → 0.4192 ms per launch at C3,
+// six interleaved repetitions; applied to every class it moves the 82 instantiations by −0.8 % in the geometric mean and single ones by ±1.4 %: profiles/r05_raw/slack_*.txt)
+template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_slack() { return queue_entries<T, WPT, MODEL>() == SPHMI_QCAP_HALF2 && SPHMI_QCAP_HALF2 < 8 ? 2 : 1; }
 
 enum { PASS_FORCES_ONLY = 0, PASS_PREDICTOR = 1, PASS_CORRECTOR = 2 };
 // model tags (values of include/sphmi.h)
@@ -495,6 +497,7 @@ k_neighbor_force(const ForceParams<T> P) {
     using V4 = typename Vec4<T>::type;
     constexpr int NSEG = (D == 3) ? 9 : 3;
     constexpr int QCAP = queue_entries<T, WPT, MODEL>();         // per-lane queue of non-empty accept masks
+    constexpr int kQueueSlack = queue_slack<T, WPT, MODEL>();
     static_assert(QCAP >= 4 && kQueueSlack >= 1 && kQueueSlack <= QCAP - 1, "queue geometry");
     // entry = { 32-bit accept mask, record size × candidate index of its bit 0 }: 8 bytes, one ds_read_b64 per refill
     __shared__ uint2 s_q_all[SPHMI_LDS_STAGE ? 1 : WPT * TPB * QCAP * kWave];    // [wave][entry][lane]
