@@ -55,6 +55,13 @@ class Oracle(Backend):
     def isolated_step(self):
         self._check(self._lib.orc_isolated_step(self._h))
 
+    def half_step_density(self) -> np.ndarray:
+        """ρₙ⁺ of the last step taken (after LimitDensityAtBoundary!, src/SPHCellList.jl:778-781), in the oracle's row order."""
+        out = np.empty(self.N, dtype=np.float64)
+        self._lib.orc_half_step_density.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._lib.orc_half_step_density(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     @staticmethod
     def max_threads() -> int:
         return load().orc_max_threads()

@@ -932,6 +932,15 @@ int orc_unique_cells(orc_handle *o, int64_t *cells_out, int64_t capacity, int64_
     return SPHMI_OK;
 }
 
+/* ρₙ⁺ of the LAST step taken — the half-step density after LimitDensityAtBoundary! (src/SPHCellList.jl:778-781), which the reference feeds to
+ * Pressure! and the second NeighborLoop! and then forgets.  The reference carries on with a non-positive value there; an engine that keeps the
+ * MotionLimiter flag in the sign of ρ must refuse such a step — the tests ask the oracle whether that is what happened. */
+int orc_half_step_density(orc_handle *o, double *out) {
+    if (!o || !o->uploaded || !out) return SPHMI_ERR_STATE;
+    memcpy(out, o->rho_np, (size_t)o->N * 8);
+    return SPHMI_OK;
+}
+
 /* Stand-alone Δt for the upstream "time stepping" test (test/runtests.jl:6-16). */
 double orc_delta_t(orc_handle *o) { return delta_t(o); }
 

@@ -116,6 +116,9 @@ constexpr int kWave = 64;
 #ifndef SPHMI_QCAP_HALF2
 #define SPHMI_QCAP_HALF2 6      // fp32 half tiles of ONE wave per half, compiled-in models (the launches of 3 000 tiles and more: the bench)
 #endif
+#ifndef SPHMI_QCAP_HALF4
+#define SPHMI_QCAP_HALF4 6       // … and of TWO waves per half (330 … 3 000 tiles: 70 k / 102 k / 159 k particles −3.3 / −1.9 / −1.3 % per step against twelve; profiles/r05_raw/qcap4_ab.txt)
+#endif
 template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
     // (fp64 half tiles: 10 / 12 / 16 / 20 entries all within 0.5 % of each other at 1.06 M / 159 k / 70 k particles: sixteen stay)
     // (half tiles of two / four waves per half: 8 / 10 / 12 / 16 and 6 / 8 / 10 / 12 entries within 1 % of each other from 273 to 2 482 tiles)
@@ -124,7 +127,7 @@ template <class T, int WPT = 1, int MODEL = 0> constexpr int queue_entries() {
     // whose lanes drift less apart: 8.15 instead of 7.03 M gathers per launch at 30 instead of 36 CU-cycles each, the L1 hits 81-83 % instead of 77;
     // it is the corrector's queue that matters (predictor 6 + corrector 10: no gain).  The run-time models lose 5-12 % with six and keep ten,
     // every other class is within noise of its value: profiles/r05_raw/qcap_*.txt)
-    return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? (MODEL >= 0 ? SPHMI_QCAP_HALF2 : 10) : 12));
+    return WPT >= 8 ? 8 : (sizeof(T) == 8 ? 16 : (WPT == 2 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? (MODEL >= 0 ? SPHMI_QCAP_HALF2 : 10) : (WPT == 4 && MODEL >= 0 && SPHMI_HALF4 != 0 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0 ? SPHMI_QCAP_HALF4 : 12)));
 }
 // a full queue is consumed down to QUEUE − 1 − slack entries before scanning goes on: one, and two for the six-entry queues (0.4228 → 0.4192 ms per launch at C3,
 // six interleaved repetitions; applied to every class it moves the 82 instantiations by −0.8 % in the geometric mean and single ones by ±1.4 %: profiles/r05_raw/slack_*.txt)

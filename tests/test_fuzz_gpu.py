@@ -258,7 +258,10 @@ def test_fuzzed_switches_match_the_oracle(seed):
                 span = np.floor(x.max(0) / s.SimKernel.H) - np.floor(x.min(0) / s.SimKernel.H) + 3
                 assert np.prod(span) > 2.0 ** 30 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
                 return
-            assert exc.status == ERR_NUMERIC and mdbc, f"{what}: {exc}"
+                # … or if the HALF-STEP density ρₙ⁺ of some particle was non-positive in one of the steps (a violent cloud does that: the reference feeds
+                # it to Pressure! and the second NeighborLoop! and the full step may well end positive again).  The oracle keeps ρₙ⁺ of its last step.
+                # (Found by generation 172000: a sheet with LaminarSPS and a k = 1.41 kernel — the same refusal in round 4's tree.)
+            assert exc.status == ERR_NUMERIC, f"{what}: {exc}"
             seen = False
             for k in range(done, done + steps):
                 o1 = make_oracle(p, s)
@@ -266,9 +269,19 @@ def test_fuzzed_switches_match_the_oracle(seed):
                     o1.set_motions(p.geometries)
                 if k:
                     o1.advance(1e9, max_steps=k)
-                o1.forces_once(apply_mdbc=True)
-                seen = seen or bool((o1.download(("Density",))["Density"] <= 0).any())
-            assert seen, f"the engine refused a run in which mDBC never produces a non-positive density in the oracle ({what}): {exc}"
+                o2 = None
+                if mdbc:
+                    o1.forces_once(apply_mdbc=True)
+                    seen = seen or bool((o1.download(("Density",))["Density"] <= 0).any())
+                    o2 = make_oracle(p, s)
+                    if getattr(p, "geometries", None) is not None:
+                        o2.set_motions(p.geometries)
+                    if k:
+                        o2.advance(1e9, max_steps=k)
+                o2 = o2 or o1
+                o2.advance(1e9, max_steps=1)
+                seen = seen or bool((o2.half_step_density() <= 0).any())
+            assert seen, f"the engine refused a run in which neither mDBC nor the half step produces a non-positive density in the oracle ({what}): {exc}"
             return
         done += steps
         assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter), what
