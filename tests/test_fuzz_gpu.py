@@ -220,11 +220,15 @@ def test_fuzzed_switches_match_the_oracle(seed):
     def close(x, y, name):
         scale = max(np.abs(y).max(), 1e-300)
         err = np.abs(x - y).reshape(len(x), -1).max(axis=1) / scale
-        if fb == 4 and s.SimKernel.k < 2.0:
+        if fb == 4 and (s.SimKernel.k < 2.0 or mdbc):
             # A kernel cut off BEFORE it vanishes (k < 2) switches a finite pair term at r = H (src/SPHCellList.jl:275), and fp32 rounds r² against H²: a pair
             # that sits on the cut within 1e-7 is in for one precision and out for the other — both of its particles then differ by ONE pair's term (found by
             # generation 117000, identical in round 4's tree: two particles of 2 500, 7e-3 of the field maximum).  That is why the library chooses fp64 kernels
             # for such handles (sphmi_auto_device_float_bytes); forced to fp32 here, a handful of particles — pairs — may sit outside, each by at most one pair's share.
+            # The same for mDBC handles forced to fp32: ApplyMDBCCorrection (:598-622) takes one of its fallback branches for a lone neighbour at r ~ H or a
+            # determinant next to 1e-3, a boundary particle then carries another density and its few neighbours another pair term (generation 182500, one
+            # particle of 777 at 1.15 x the tolerance, identical in round 4's tree and with every waves-per-tile choice; tests/test_example_precision_gpu.py
+            # holds the record behind the policy).
             bad = err > tol_f
             assert bad.sum() <= max(4, len(err) // 500) and err.max() < 0.05, f"{name} {what}: {int(bad.sum())} particles beyond {tol_f:.1e}, worst {err.max():.2e}"
             return
