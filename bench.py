@@ -108,12 +108,13 @@ def counters_for(identity, n_local, kern_ms):
             "unit": "wave64 vector instructions/s", "source": COUNTER_RECORD}
     # The unit the launch runs out of since the middle of round 5: the texture path charges a wave-level gather by its lanes and
     # segments, not by its bytes — tools/ubench/gather4.hip on this chip, CU-cycles per b128 instruction with the data in L1: 34 for 64 lanes
-    # with scattered records inside 4 KB, 26 for 32 lanes, 17 coalesced.  The kernels' gathers have ≈50 of 64 lanes switched on.
+    # with scattered records inside 4 KB, 24.5 inside 256 B, 26 for 32 lanes, 17 coalesced.  The kernels' gathers have ≈55 of 64 lanes switched on
+    # and, with six-entry queues, lanes that stay close together: ≈30 cycles.
     gathers = 0.5 * (c["predictor"].get("vmem_rd_insts", 0.0) + c["corrector"].get("vmem_rd_insts", 0.0)) * n_local / n_prof
     cyc = kern_ms * 1e-3 * SHADER_CLOCK_HZ * N_CU / gathers if gathers > 0 and kern_ms > 0 else 0.0
     if gathers > 0:
         valu["gather"] = {"wave_gathers_per_launch": gathers, "cu_cycles_per_gather": cyc,
-                          "ubench_cu_cycles_per_gather": {"64 lanes scattered in 4 KB": 34.1, "32 lanes scattered": 26.5, "coalesced": 17.4},
+                          "ubench_cu_cycles_per_gather": {"64 lanes scattered in 4 KB": 34.1, "64 lanes scattered in 256 B": 24.5, "32 lanes scattered": 26.5, "coalesced": 17.4},
                           "frac_of_ubench_rate_64_lanes": 34.1 / cyc if cyc > 0 else None,
                           "ta_busy_frac_pmc": 0.5 * (c["predictor"].get("ta_busy_frac", 0.0) + c["corrector"].get("ta_busy_frac", 0.0)),
                           "l1_hit_frac_pmc": 0.5 * (c["predictor"].get("l1_hit_frac", 0.0) + c["corrector"].get("l1_hit_frac", 0.0)),
