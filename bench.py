@@ -28,7 +28,9 @@ Objects on the JSON line beyond the contract's keys:
   roofline     — dominant kernel (k_neighbor_force): ALGORITHMIC bytes per launch ÷ its average launch duration (HIP events
                  on the engine's stream) against the 8 TB/s HBM peak: `achieved`, `peak`, `frac` are that HBM figure.
                  (11·D+5)·4+2 = 154 B per particle-update = 77 B per particle per launch.  `bound` names the
-                 resource that actually binds the kernel — vector-ALU issue — and `valu` prices it from the committed
+                 resource that actually binds the kernel — since the middle of round 5 the rate at which the texture path takes
+                 per-lane gathers (`valu.gather`: wave-level gathers per launch and CU-cycles per gather next to the
+                 micro-benchmark's figures), with vector-ALU issue 20-25 % behind (`valu`) — priced from the committed
                  counters of the shipped kernel.  Counters are only quoted when the ISA of the loaded library's two bench
                  kernels hashes to what the counter record was taken on (tools/isa_report.py): otherwise `traffic` and
                  `valu` are null and `counters_refused` says why.
