@@ -260,7 +260,8 @@ def test_fuzzed_switches_match_the_oracle(seed):
                 # iff the oracle's cloud spans that many cells by the end of the call.
                 x = orc.download(("Position",))["Position"]
                 span = np.floor(x.max(0) / s.SimKernel.H) - np.floor(x.min(0) / s.SimKernel.H) + 3
-                assert np.prod(span) > 2.0 ** 30 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
+                # (+ 4: a handle that rebuilds on the device keeps two empty cell layers on either side of the box, kStickySlack — generation 199000 met the limit within 1 %)
+                assert np.prod(span + 4) > 2.0 ** 30 and "max_cells" in str(exc), f"{what}: {exc} (oracle spans {span})"
                 return
                 # … or if the HALF-STEP density ρₙ⁺ of some particle was non-positive in one of the steps (a violent cloud does that: the reference feeds
                 # it to Pressure! and the second NeighborLoop! and the full step may well end positive again).  The oracle keeps ρₙ⁺ of its last step.
@@ -285,7 +286,10 @@ def test_fuzzed_switches_match_the_oracle(seed):
                 o2 = o2 or o1
                 o2.advance(1e9, max_steps=1)
                 seen = seen or bool((o2.half_step_density() <= 0).any())
-            assert seen, f"the engine refused a run in which neither mDBC nor the half step produces a non-positive density in the oracle ({what}): {exc}"
+                # … or the density at the END of one of the steps: ρ·(2 − ε)/(2 + ε) (DensityEpsi!, :796) of a boundary particle may come out non-positive
+                # and the next step's LimitDensityAtBoundary! (:794) lifts it back to ρ₀ — the oracle's state after the CALL is sane (generation 198500, same in round 4's tree)
+                seen = seen or bool((o2.download(("Density",))["Density"] <= 0).any())
+            assert seen, f"the engine refused a run in which neither mDBC, nor a half step, nor the end of a step produces a non-positive density in the oracle ({what}): {exc}"
             return
         done += steps
         assert (pe.iteration, pe.n_rebuilds, pe.index_counter) == (po.iteration, po.n_rebuilds, po.index_counter), what
