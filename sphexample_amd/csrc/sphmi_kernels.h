@@ -80,6 +80,10 @@ constexpr int kWave = 64;
 #define SPHMI_BALANCE 1         // interleaved half tiles: per chunk the lane of a target that has had FEWER pairs so far takes the larger of the two interleaved shares
                                 // (whole 32-bit words change hands; see the push of phase 1).  0 = every lane keeps the share the matrix layout hands it (A/B builds)
 #endif
+#ifndef SPHMI_PAIR_FETCH64
+#define SPHMI_PAIR_FETCH64 1    // fp64 half tiles of one wave per half, compiled-in models: adjacent lanes fetch the two 16-byte halves of ONE packet per instruction
+                                // (run_pairs_piped, kPairFetch64).  0 = four gathers of a lane's own record (A/B builds; what every other kernel does)
+#endif
 #ifndef SPHMI_F16_SCAN
 #define SPHMI_F16_SCAN 1        // half tiles: the distance matrix of phase 1 from ONE v_mfma_f32_32x32x16_f16 per 32x32 block instead of three
                                 // v_mfma_f32_32x32x2_f32 (see scan_chunk16).  0 = the f32-input form (A/B builds; what full tiles keep)
@@ -970,6 +974,9 @@ k_neighbor_force(const ForceParams<T> P) {
     [[maybe_unused]] unsigned pjr = 0;
     // (round 5: the loop test — a compare, a ballot and a branch — once per TWO iterations, SPHMI_LOOP_UNROLL: a burst may run one iteration longer than it
     // had to, which only moves a pair from the next burst into this one; the copy that rotated `cm` goes with it)
+    // (the run-time-model kernels lose 5-12 % with it at 1 098 tiles: registers — compiled-in models only)
+    constexpr bool kPairFetch64 = SPHMI_PAIR_FETCH64 != 0 && sizeof(T) == 8 && kHalf && MODEL >= 0 && SPHMI_DIAG == 0;
+    [[maybe_unused]] const unsigned pf_c = (lane & 1) ? 16u : 0u, pf_self = a_r1 - (1u << kRecShift);
     auto run_pairs_piped = [&](const int keep, const bool drain) __attribute__((always_inline)) {
         unsigned qf = qn != 0 ? 1u : 0u;
         auto iteration = [&]() __attribute__((always_inline)) {
@@ -981,6 +988,19 @@ k_neighbor_force(const ForceParams<T> P) {
             const unsigned jr = pjr;
             const bool v = pv;
             V4 n0, n1;
+            [[maybe_unused]] u32x4_t A, B, Cq, Dq;
+            if constexpr (kPairFetch64) {
+                // An fp64 record is 64 bytes = four 16-byte gathers per pair, and the texture path charges the instruction: 40 CU-cycles each for 64 scattered
+                // lanes, 22 when adjacent lanes read the two halves of one 32-byte segment (tools/ubench/gather4.hip).  Four instructions still, but each fetches
+                // one PACKET of 32 records: packets 0 and 1 of the even lanes' records, then of the odd lanes'; a lane holds half of every packet it needs and
+                // its neighbour the other half — sixteen v_cndmask_b32_dpp hand them over (step 3).  1.06 M / 470 k / 159 k particles: 1 795 → 1 552, 806 → 691,
+                // 293 → 253 µs per step (−14 %).  The fp32 version of the trade (two gathers of 34 cycles against eight exchanges) lost: profiles/r05_pair_gather_experiment.patch.
+                const unsigned js = v ? jr : pf_self;                                                     // (a lane without a pair: any valid record)
+                const unsigned jE = (unsigned)__builtin_amdgcn_mov_dpp((int)js, 0xA0, 0xF, 0xF, true) + pf_c;      // quad_perm [0, 0, 2, 2]
+                const unsigned jO = (unsigned)__builtin_amdgcn_mov_dpp((int)js, 0xF5, 0xF, 0xF, true) + pf_c;      // quad_perm [1, 1, 3, 3]
+                A = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)jE, 0, 0); B = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)(jE + 32u), 0, 0);
+                Cq = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)jO, 0, 0); Dq = __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)(jO + 32u), 0, 0);
+            } else
 #if SPHMI_DIAG == 5
             // DIAGNOSTIC BUILD (wrong results): every odd lane gathers the record its even neighbour gathers — what the texture path
             // charges when the two lanes of a pair address the same 32 bytes (the lane-pair design of DESIGN §4.6)
@@ -990,7 +1010,7 @@ k_neighbor_force(const ForceParams<T> P) {
             // DIAGNOSTIC BUILD (wrong results): the arithmetic without the gathers — the floor set by the vector ALU
             if (v) { n0 = q0; n1 = q1; n0.x += __uint_as_float(jr) * T(1e-30); n0.y += T(0.003); n0.w = q0.w + T(1); }
 #else
-            if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); }
+            { if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); } }
 #endif
             // 2. while they fly: the next pair of this lane — refill when the mask is used up, lowest set bit, record offset
             unsigned m = cm;
@@ -1008,6 +1028,29 @@ k_neighbor_force(const ForceParams<T> P) {
             // `v_ffbl_b32`, defined for 0, pins the LDS wait in front of the arithmetic and measured −0.5 %.)
             pjr = rec_of(m, cbase);
             // 3. the arithmetic
+            if constexpr (kPairFetch64) {
+                // even lane: packet 0 = { A, its neighbour's A }, packet 1 = { B, its neighbour's B };  odd lane: packet 0 = { its neighbour's C, C }, packet 1 = { its neighbour's D, D }
+                unsigned w[16];
+#define SPHMI_PF(d, x, y) "v_cndmask_b32_dpp %" #d ", %" #x ", %" #y ", vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                // low halves (bytes 0..15 of a packet), vcc = even lanes: even ? own first-record load : the even neighbour's second-record load
+                asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_nop 1\n\t"
+                             SPHMI_PF(0, 16, 8) SPHMI_PF(1, 17, 9) SPHMI_PF(2, 18, 10) SPHMI_PF(3, 19, 11)
+                             SPHMI_PF(4, 20, 12) SPHMI_PF(5, 21, 13) SPHMI_PF(6, 22, 14) SPHMI_PF(7, 23, 15)
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])
+                             : "v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w),
+                               "v"(Cq.x), "v"(Cq.y), "v"(Cq.z), "v"(Cq.w), "v"(Dq.x), "v"(Dq.y), "v"(Dq.z), "v"(Dq.w) : "vcc");
+                // high halves (bytes 16..31), vcc = odd lanes: odd ? own second-record load : the odd neighbour's first-record load
+                asm volatile("s_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\ts_nop 1\n\t"
+                             SPHMI_PF(0, 8, 16) SPHMI_PF(1, 9, 17) SPHMI_PF(2, 10, 18) SPHMI_PF(3, 11, 19)
+                             SPHMI_PF(4, 12, 20) SPHMI_PF(5, 13, 21) SPHMI_PF(6, 14, 22) SPHMI_PF(7, 15, 23)
+                             : "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[12]), "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15])
+                             : "v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w),
+                               "v"(Cq.x), "v"(Cq.y), "v"(Cq.z), "v"(Cq.w), "v"(Dq.x), "v"(Dq.y), "v"(Dq.z), "v"(Dq.w) : "vcc");
+#undef SPHMI_PF
+                auto dbl = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+                n0.x = dbl(w[0], w[1]); n0.y = dbl(w[2], w[3]); n0.z = dbl(w[4], w[5]); n0.w = dbl(w[6], w[7]);
+                n1.x = dbl(w[8], w[9]); n1.y = dbl(w[10], w[11]); n1.z = dbl(w[12], w[13]); n1.w = dbl(w[14], w[15]);
+            }
             if (v) pair(jr, n0, n1, plays_i(jr));
         };
         if (__builtin_amdgcn_ballot_w64(drain ? (pv | ((qf | cm) != 0u)) : (qn > keep)) != 0) do {
