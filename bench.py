@@ -30,7 +30,7 @@ Objects on the JSON line beyond the contract's keys:
                  (11·D+5)·4+2 = 154 B per particle-update = 77 B per particle per launch.  `bound` names the
                  resource that actually binds the kernel — since the middle of round 5 the rate at which the texture path takes
                  per-lane gathers (`valu.gather`: wave-level gathers per launch and CU-cycles per gather next to the
-                 micro-benchmark's figures), with vector-ALU issue 20-25 % behind (`valu`) — priced from the committed
+                 micro-benchmark's figures), with vector-ALU issue ≈10 % behind (`valu`) — priced from the committed
                  counters of the shipped kernel.  Counters are only quoted when the ISA of the loaded library's two bench
                  kernels hashes to what the counter record was taken on (tools/isa_report.py): otherwise `traffic` and
                  `valu` are null and `counters_refused` says why.
@@ -487,7 +487,7 @@ def main():
                                            f"steps; value_cold is the same window without it") if pre_steps else "none"},
             "roofline": {"bound": "gather_issue", "hbm_note": "achieved / peak / frac are the HBM figure BASELINE.json's metric asks for (algorithmic bytes ÷ kernel time "
                                                               "÷ 8 TB/s); the kernel is bound by the rate at which the texture path takes per-lane gathers — `valu.gather` — "
-                                                              "with vector-ALU issue 25 % behind (`valu`; until the middle of round 5 it was the other way round)",
+                                                              "with vector-ALU issue ≈10 % behind (`valu`; until the middle of round 5 it was the other way round)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs if copy_gbs > 0 else None,
                          "peak_measured_source": "1 GiB device-to-device copy (read + write bytes) on this GPU, measured in this run before the warm-up steps",
