@@ -82,7 +82,7 @@ typedef struct sphmi_config {
     int32_t shifting;            /* SPHMI_SHIFT_* (SMode of SimulationMetaData)                  */
     int32_t kernel_output;       /* SPHMI_KOUT_* (KMode of SimulationMetaData)                   */
     int64_t n_particles;         /* length(SimParticles); below 2^27 (fp32 kernels) / 2^26 (fp64) per device: 32-bit gather offsets */
-    int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<30: 8 GB of cell arrays at the limit, allocated on demand) */
+    int64_t max_cells;           /* cell budget of the dense bounding grid; 0 = default (1<<30: two 4-byte arrays with 25 % headroom, 10.7 GB at the limit, allocated on demand; SPHMI_ERR_DOMAIN when the device cannot hold them) */
     /* SimulationConstants */
     double rho0, dx, m0, alpha, g, c0, gamma, delta_phi, CFL, Cb, nu0;
     /* SPHKernelInstance */
@@ -131,7 +131,9 @@ int sphmi_create(const sphmi_config* cfg, sphmi_handle** out);
  * kernels) when the kernel is cut off before it vanishes (k < 2: example/DucklingMDBC.jl, example/MovingSquare2d.jl) or mDBC is on
  * (src/SPHCellList.jl:598-622: "no neighbour -> keep", the Shepard fallback and the |det A| >= 1e-3 switch are discontinuities) — there
  * an fp32 trajectory takes the other branch a step early or late and leaves the reference's state by more than 1e-5 on single
- * particles.  sphmi_device_float_bytes: what a handle runs. */
+ * particles.  ("H >= 2h" is tested with a relative slack of 1e-12: H = k*h is formed in floating point on the caller's side.)  A handle too
+ * large for the fp64 kernels (more than 2^26 - 1 particles per device) stays with fp32 whatever the policy says.
+ * sphmi_device_float_bytes: what a handle runs. */
 int32_t sphmi_auto_device_float_bytes(const sphmi_config* cfg);
 int sphmi_device_float_bytes(const sphmi_handle* h, int32_t* device_float_bytes_out);
 int sphmi_destroy(sphmi_handle* h);

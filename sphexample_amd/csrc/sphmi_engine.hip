@@ -470,7 +470,9 @@ struct Engine final : EngineBase {
     bool kv2_foldable() const { const T k = kv2(); return std::isnormal(k) && std::isfinite(T(1) / k) && std::isnormal(T(1) / k); }
     // … and evaluate Pressure! of a neighbour as ρ⁷·(Cb/γ/ρ₀⁷) − Cb/γ (fp32 kernels: ρ⁷ must stay finite up to 4ρ₀, the constant normal)
     T cbe7() const { return (T)(((cfg.c0 * cfg.c0 * cfg.rho0) / 7.0) / std::pow(cfg.rho0, 7.0)); }
-    bool eos_foldable() const { return sizeof(T) == 8 || (std::pow(4.0 * cfg.rho0, 7.0) < 1e37 && std::isnormal(cbe7())); }
+    // (fp32: ρ⁷ must neither overflow at 4 ρ₀ nor fall into the subnormals at ρ₀ / 4 — unit systems with ρ₀ ≈ 1e-6 — where ρ⁷·Cbe7 would lose the
+    // neighbour pressure without a word; such handles take the run-time variant, which forms (ρ/ρ₀)⁷)
+    bool eos_foldable() const { return sizeof(T) == 8 || (std::pow(4.0 * cfg.rho0, 7.0) < 1e37 && std::pow(0.25 * cfg.rho0, 7.0) > 1e-30 && std::isnormal(cbe7())); }
     bool compiled_in_model() const {
         // the models of the stock examples; a kernel cut off before it vanishes (k < 2) takes the variant with the per-pair cut
         return cfg.viscosity == SPHMI_VISC_ARTIFICIAL && cfg.density_diffusion == SPHMI_DDT_LINEAR && cfg.shifting == SPHMI_SHIFT_NONE &&
@@ -710,10 +712,26 @@ struct Engine final : EngineBase {
         }
         grid.ncell = (int)ncell;
         if (ncell + 2 > cell_cap) {
+            // The old arrays go first (at 2^30 cells the two generations do not have to fit side by side) and the handle never keeps a pointer to freed
+            // memory: pointers and capacity are cleared BEFORE the allocations, so a failed hipMalloc — a busy device, several slabs or rank processes on
+            // one GPU — leaves a handle whose next rebuild allocates again and whose destructor frees nothing twice (round-5 advisor finding).
             (void)hipFree(count); (void)hipFree(cstart); (void)hipFree(tsum);
-            cell_cap = (ncell + 2) + (ncell + 2) / 4;
-            HC(hipMalloc(&count, cell_cap * 4)); HC(hipMalloc(&cstart, cell_cap * 4));
-            HC(hipMalloc(&tsum, ((cell_cap + kScanTile - 1) / kScanTile + 1) * 4));
+            count = cstart = tsum = nullptr; cell_cap = 0;
+            const int64_t want = (ncell + 2) + (ncell + 2) / 4;
+            int *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;
+            const bool ok = hipMalloc(&c0, (size_t)want * 4) == hipSuccess && hipMalloc(&c1, (size_t)want * 4) == hipSuccess &&
+                            hipMalloc(&c2, (size_t)((want + kScanTile - 1) / kScanTile + 1) * 4) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                (void)hipFree(c0); (void)hipFree(c1); (void)hipFree(c2);
+                have_grid = false;
+                char buf[260];
+                snprintf(buf, sizeof(buf), "no device memory for a cell grid of %d x %d x %d = %lld cells (%.1f GB for the two cell arrays): a particle far from "
+                         "the others inflates the bounding grid — set sphmi_config.max_cells to bound it", grid.np[0], grid.np[1], grid.np[2], (long long)ncell,
+                         2.0 * 4.0 * (double)want / 1e9);
+                throw EngineError(SPHMI_ERR_DOMAIN, buf);
+            }
+            count = c0; cstart = c1; tsum = c2; cell_cap = want;
         }
         HC(hipMemsetAsync(count, 0, (size_t)(ncell + 2) * 4, stream));
         HC(hipMemsetAsync(misc_d, 0, 8 * 4, stream));
@@ -1690,7 +1708,13 @@ static int create_any(const sphmi_config* cfg, int32_t rank, int32_t world, cons
         return fail(SPHMI_ERR_ARGUMENT, "sphmi_create: struct_size / abi_version mismatch");
     // device_float_bytes = 0: the library chooses the arithmetic (sphmi_auto_device_float_bytes, include/sphmi.h)
     sphmi_config resolved = *cfg;
-    if (resolved.device_float_bytes == 0) resolved.device_float_bytes = sphmi_auto_device_float_bytes(cfg);
+    if (resolved.device_float_bytes == 0) {
+        resolved.device_float_bytes = sphmi_auto_device_float_bytes(cfg);
+        // the policy never turns a handle the fp32 kernels can hold into an error: beyond the fp64 kernels' 2^26 particles per device it stays with fp32
+        const int64_t slabs = rank >= 0 ? std::max(world, 1) : std::max(cfg->n_devices, 1);
+        const int64_t per = (cfg->n_particles + slabs - 1) / slabs;
+        if (resolved.device_float_bytes == 8 && per > (1ll << 26) - 1 && per <= (1ll << 27) - 1) resolved.device_float_bytes = 4;
+    }
     cfg = &resolved;
     // slabs the particle set is spread over: sphmi_create_rank's world, or the device list of sphmi_create
     if (int st = check_config(cfg, rank >= 0 ? std::max(world, 1) : std::max(cfg->n_devices, 1), why)) return fail(st, why);

@@ -614,8 +614,12 @@ struct MultiEngine final : EngineBase {
         // (a one-rank world under sphmi_create_rank still runs its allreduce through RCCL: the binding is exercised)
         const bool want_shm = tr && !strcmp(tr, "shm");
         if (want_shm && !rank_mode) throw EngineError(SPHMI_ERR_ARGUMENT, "SPHMI_TRANSPORT=shm is the transport of sphmi_create_rank (one slab per process)");
-        use_rccl = (rank_mode && !want_shm) || (!rank_mode && world > 1 && !shared_device && !(tr && !strcmp(tr, "local")));
-        if (tr && !strcmp(tr, "rccl") && shared_device) throw EngineError(SPHMI_ERR_ARGUMENT, "RCCL cannot run two ranks on one device");
+        // RCCL itself refuses two ranks on one device; a SUBSTITUTE library ($SPHMI_RCCL_LIB: the checking double of tests/mock_rccl/) may not,
+        // and SPHMI_TRANSPORT=rccl then sends the slabs of a one-process handle that share a device through the ncclCommInitAll branch below
+        const char* sub = getenv("SPHMI_RCCL_LIB");
+        const bool want_rccl = tr && !strcmp(tr, "rccl"), substitute = sub && *sub;
+        use_rccl = (rank_mode && !want_shm) || (!rank_mode && world > 1 && !(tr && !strcmp(tr, "local")) && (!shared_device || (want_rccl && substitute)));
+        if (want_rccl && shared_device && !substitute) throw EngineError(SPHMI_ERR_ARGUMENT, "RCCL cannot run two ranks on one device");
         if (want_shm) {
             if (!unique_id) throw EngineError(SPHMI_ERR_ARGUMENT, "sphmi_create_rank: null unique id");
             shm.reset(new ShmWorld(unique_id, 128, my_rank, world));
@@ -691,7 +695,10 @@ struct MultiEngine final : EngineBase {
         if (world < 2 || (!use_rccl && !shm)) return;
         for (auto& r : R) {
             HC(hipSetDevice(r.device));
-            HC(hipMalloc(&r.box, kMboxWords * 8));
+            // FINE-GRAINED device memory: a peer device (or process) writes the box over xGMI / hipIpc WHILE this slab's control kernel polls it, and
+            // coarse-grained allocations are only guaranteed coherent across devices at kernel boundaries — a poll served from the local L2 could
+            // stay stale until the deadline (round-5 advisor finding)
+            HC(hipExtMallocWithFlags((void**)&r.box, kMboxWords * 8, hipDeviceMallocFinegrained));
             HC(hipMemset(r.box, 0, kMboxWords * 8));
             HC(hipDeviceSynchronize());
         }
@@ -1257,7 +1264,9 @@ struct MultiEngine final : EngineBase {
                 HC(hipSetDevice(r.device));
                 MboxArgs A{};
                 for (int q = 0; q < world && q < 16; ++q) A.dst[q] = r.box_of[q];
-                A.own = r.box; A.mine = r.e->red_d + 4 * p; A.world = world; A.me = r.rank; A.parity = p; A.seq = mbox_seq; A.timeout = mbox_timeout;
+                // (the box parity follows the SEQUENCE number, not the step parity: upload() restarts the step parity while the sequence keeps counting, and two
+                // consecutive posts must never share a half of the box)
+                A.own = r.box; A.mine = r.e->red_d + 4 * p; A.world = world; A.me = r.rank; A.parity = (int)(mbox_seq & 1ull); A.seq = mbox_seq; A.timeout = mbox_timeout;
                 hipLaunchKernelGGL(k_dd_mbox_merge_control<T>, dim3(1), dim3(64), 0, r.main, r.M, A, r.e->red_d + 4 * (p ^ 1), r.e->ctrl_d, cfg.h, cfg.c0, cfg.CFL);
                 HC(hipGetLastError());
                 r.e->dd_control_queued(p ^ 1);

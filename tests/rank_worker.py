@@ -2,9 +2,11 @@
 
   python rank_worker.py selftest <unique id, hex> <rank> <world> <bytes per message>
   python rank_worker.py run <unique id, hex> <rank> <world> <case> <steps> <float bytes> <out dir> <advance calls> <slab axis | -1>
+  python rank_worker.py run_slabs <unused> 0 <world> <case> …          (one process holding all `world` slabs on GPU 0)
 
-`run` creates slab `rank` of the case on GPU 0 with SPHMI_TRANSPORT=shm (the environment of the spawner) — or, with
-$SPHMI_TEST_DEVICE_PER_RANK=1 (tests/test_multi_device_gpu.py on a box with several GPUs), on GPU `rank` over RCCL —
+`run` creates slab `rank` of the case on GPU 0 with SPHMI_TRANSPORT=shm (the environment of the spawner) — or through the RCCL branch
+with the checking double behind $SPHMI_RCCL_LIB (tests/test_mock_rccl_gpu.py), or, with $SPHMI_TEST_DEVICE_PER_RANK=1
+(tests/test_multi_device_gpu.py on a box with several GPUs), on GPU `rank` over the real RCCL —
 advances it and stores what this process owns plus the loop counters; the spawner compares the union with a one-device handle.
 """
 import ctypes as C
@@ -35,16 +37,36 @@ def main():
     from sphexample_amd.engine import make_engine
     p, s = getattr(conftest, "load_" + case)()
     device = rank if os.environ.get("SPHMI_TEST_DEVICE_PER_RANK") == "1" else 0
-    eng = make_engine(p, s, device_float_bytes=fb, device=device, rank=rank, world=world, unique_id=uid,
-                      slab_axis=None if axis < 0 else axis)
+    if mode == "run_slabs":        # ONE process, `world` slabs sharing GPU 0 (with SPHMI_TRANSPORT=rccl + a substitute library: the ncclCommInitAll branch)
+        eng = make_engine(p, s, device_float_bytes=fb, devices=[0] * world, slab_axis=None if axis < 0 else axis)
+    else:
+        eng = make_engine(p, s, device_float_bytes=fb, device=device, rank=rank, world=world, unique_id=uid,
+                          slab_axis=None if axis < 0 else axis)
     prog = []
     for _ in range(calls):
         pr = eng.advance(1e9, max_steps=steps // calls)
         prog.append([pr.iteration, pr.steps_done, pr.n_rebuilds, pr.index_counter, pr.total_time, pr.last_dt])
     info = eng.multi_info()
+    info = np.array([info.world, info.n_local, info.transport, info.axis, info.halo_width, info.n_recuts, info.reserved])
     d = eng.download(("Position", "Density", "ID", "Velocity"))
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), prog=np.array(prog, dtype=np.float64),
-             info=np.array([info.world, info.n_local, info.transport, info.axis, info.halo_width, info.n_recuts, info.reserved]), **d)
+    if os.environ.get("SPHMI_TEST_FORCES_ONCE") == "1":        # the parity hook on slabs: one more collective rebuild + a forces-only pass
+        d["drhodt"], d["acc"] = eng.forces_once()
+        n_own = eng.owned_count() if mode == "run" else len(d["drhodt"])
+        d["drhodt"], d["acc"] = d["drhodt"][:n_own], d["acc"][:n_own]
+        d["ID_forces"] = eng.download(("ID",))["ID"]
+    mock = np.zeros(14, dtype=np.uint64)
+    sub = os.environ.get("SPHMI_RCCL_LIB")
+    if sub:
+        # the substitute library's own counters AFTER the handle is gone (ncclCommDestroy checks for unreceived messages and open groups):
+        # dlopen of the same path returns the copy libsphmi bound
+        eng.close()
+        m = C.CDLL(sub)
+        if hasattr(m, "mockrccl_stats"):
+            m.mockrccl_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+            v = (C.c_uint64 * 14)()
+            m.mockrccl_stats(v, 14)
+            mock = np.array(list(v), dtype=np.uint64)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), prog=np.array(prog, dtype=np.float64), info=info, mock=mock, **d)
 
 
 if __name__ == "__main__":
