@@ -39,7 +39,8 @@ def mock_lib():
 
 def _spawn(mock, world, args_of, mode="run", timeout=600, extra_env=None, n_procs=None):
     uid = os.urandom(128).hex()
-    env = dict(os.environ, SPHMI_RCCL_LIB=mock, MOCK_RCCL_TIMEOUT="90", **(extra_env or {}))
+    env = dict(os.environ, SPHMI_RCCL_LIB=mock, MOCK_RCCL_TIMEOUT="90")
+    env.update(extra_env or {})
     if mode == "run":
         env.pop("SPHMI_TRANSPORT", None)                 # rank mode without SPHMI_TRANSPORT=shm IS the RCCL branch
     else:
