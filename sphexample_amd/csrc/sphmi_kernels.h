@@ -107,6 +107,25 @@ constexpr int kWave = 64;
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5 / 8: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
                                 // neither / adjacent lanes sharing a gathered record / adjacent lanes walking the union of their masks (§4.9)
+                                // 16 (round 6): the PRICE of an LDS record ring under the per-lane queues — the pair loop of the fp32 half-tile kernels of one wave per half
+                                // reads both packets of a neighbour with two ds_read_b128 from a ring in LDS, at the address its record index maps to, instead of gathering
+                                // them through the texture path.  SPHMI_RING_RECORDS (a power of two) records of 32 bytes per WAVE, or per four-wave BLOCK with
+                                // SPHMI_RING_SHARED=1 — the LDS allocation, and with it the occupancy, of the real design; SPHMI_RING_STAGE=1 adds what filling the ring costs
+                                // (the second packet of every scanned chunk loaded with the first, two ds_write_b128 per lane and chunk; shared ring: by one wave in four).
+                                // Nothing guarantees that the slot still holds the record: wrong results.  profiles/r06_lds_ring_price.md
+#endif
+#ifndef SPHMI_RING_RECORDS
+#define SPHMI_RING_RECORDS 128
+#endif
+#ifndef SPHMI_RING_SHARED
+#define SPHMI_RING_SHARED 0
+#endif
+#ifndef SPHMI_RING_STAGE
+#define SPHMI_RING_STAGE 0
+#endif
+#ifndef SPHMI_RING_SOA
+#define SPHMI_RING_SOA 0        // the ring as two arrays of packets (16-byte stride: sixteen bank positions for the sixteen lanes of a ds_read_b128 group) instead of
+                                // records (32-byte stride: eight)
 #endif
 
 // Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles
@@ -511,8 +530,18 @@ k_neighbor_force(const ForceParams<T> P) {
     // SPHMI_LDS_STAGE: the two packets of the 64 candidates of the chunk being worked on, per wave (2 / 4 KB in fp32 / fp64)
     __shared__ V4 s_stage_all[SPHMI_LDS_STAGE ? WPT * TPB * 2 * kWave : 1];
 
+    // SPHMI_DIAG == 16: the record ring whose price is being taken (fp32 half tiles of one wave per half, compiled-in models: the bench's kernels)
+    constexpr bool kRing = SPHMI_DIAG == 16 && sizeof(T) == 4 && WPT == 2 && MODEL >= 0 && SPHMI_HALF_TILE != 0 && SPHMI_LDS_STAGE == 0;
+    constexpr int kRingRec = SPHMI_RING_RECORDS;
+    static_assert((kRingRec & (kRingRec - 1)) == 0 && kRingRec >= 64, "ring: a power of two of at least one chunk");
+    __shared__ V4 s_ring_all[kRing ? 2 * kRingRec * (SPHMI_RING_SHARED ? 1 : WPT * TPB) : 1];
+
     const int lane = threadIdx.x & (kWave - 1);
     const int wvb = threadIdx.x >> 6;                      // wave of the block
+    [[maybe_unused]] char* const s_ringb = reinterpret_cast<char*>(s_ring_all + (kRing && !SPHMI_RING_SHARED ? wvb * 2 * kRingRec : 0));
+    // byte offsets of the two packets of the record whose offset in the record array is jr (= 32 × index)
+    [[maybe_unused]] auto ring_off0 = [](const unsigned jr) -> unsigned { return SPHMI_RING_SOA ? ((jr >> 1) & (unsigned)(kRingRec * 16 - 1)) : (jr & (unsigned)(kRingRec * 32 - 1)); };
+    [[maybe_unused]] constexpr unsigned kRingOff1 = SPHMI_RING_SOA ? (unsigned)kRingRec * 16u : 16u;
     // wave of the tile, tile of the block.  Two tiles of two waves (the launches that fit the chip at once): a workgroup of
     // FOUR waves puts one wave on each SIMD of its compute unit, so every SIMD of a unit holds the same number of waves —
     // workgroups of two left the SIMDs with 4 … 9 waves and 35 % more work on the fullest than on average, and the launch
@@ -579,6 +608,14 @@ k_neighbor_force(const ForceParams<T> P) {
     const V4 q0 = P.src0[ac];
     const V4 q1 = P.src1[ac];
     const T xa = q0.x, ya = q0.y, za = q0.z;
+    if constexpr (kRing) {
+        // finite values in every slot (the lane's own record): what the loop reads is wrong, but it is not a NaN from a previous kernel's LDS
+        for (int k = lane; k < kRingRec; k += kWave) {
+            *reinterpret_cast<V4*>(s_ringb + ring_off0((unsigned)k << 5)) = q0;
+            *reinterpret_cast<V4*>(s_ringb + ring_off0((unsigned)k << 5) + kRingOff1) = q1;
+        }
+        // (a shared ring: every wave fills ALL of it — waves of a block may have left already, so no barrier; whoever writes, the values are finite)
+    }
     T rho_a, rhon_a, P_a, s_a;
     if constexpr (PASS == PASS_CORRECTOR) {
         rho_a = q0.w;                                   // ρ⁺
@@ -818,7 +855,7 @@ k_neighbor_force(const ForceParams<T> P) {
     //  (packed fp32 for the head of the pair and the accumulators — 47 instead of 56 vector instructions — was built and measured 1.3 % slower: on gfx950 v_fma_f32 runs at
     //  the double rate and v_pk_* at the full rate; profiles/r05_retired_switches.patch)
     constexpr bool kFast = kFoldKv2 && MODEL >= 0 && ((MODEL >> 4) & 15) == kDdtLinear && SPHMI_FAST_PAIR != 0;
-    constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5 || SPHMI_DIAG == 8;      // (the diagnostic builds that keep the arithmetic)
+    constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5 || SPHMI_DIAG == 8 || SPHMI_DIAG == 16;      // (the diagnostic builds that keep the arithmetic)
     [[maybe_unused]] auto pair_fast = [&](const V4& n0, const V4& n1, const bool a_is_i) {
         if constexpr (kFast) {
             float dz = 0.0f, r2, vdx;
@@ -1009,6 +1046,10 @@ k_neighbor_force(const ForceParams<T> P) {
 #elif SPHMI_DIAG == 2 || SPHMI_DIAG == 4
             // DIAGNOSTIC BUILD (wrong results): the arithmetic without the gathers — the floor set by the vector ALU
             if (v) { n0 = q0; n1 = q1; n0.x += __uint_as_float(jr) * T(1e-30); n0.y += T(0.003); n0.w = q0.w + T(1); }
+#elif SPHMI_DIAG == 16
+            // DIAGNOSTIC BUILD (wrong results): both packets from the LDS ring, at the slot the record index maps to
+            if constexpr (kRing) { if (v) { const unsigned ro = ring_off0(jr); n0 = *reinterpret_cast<const V4*>(s_ringb + ro); n1 = *reinterpret_cast<const V4*>(s_ringb + ro + kRingOff1); } }
+            else { if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); } }
 #else
             { if (v) { n0 = gather_packet(rs0, jr, 0, T()); n1 = gather_packet(rs0, jr, 1, T()); } }
 #endif
@@ -1281,6 +1322,16 @@ k_neighbor_force(const ForceParams<T> P) {
             unsigned long long m;
             {
                 const V4 cpk = chunk_packet(cb, HI);
+                if constexpr (kRing && SPHMI_RING_STAGE != 0) {
+                    // what filling the ring costs: the chunk's second packets loaded with the first, both parked at the records' slots
+                    // (a ring shared by the four waves of a block: each of them stages a quarter of the chunks)
+                    if (SPHMI_RING_SHARED == 0 || ((cb >> 6) & 3) == wvb) {
+                        const unsigned cr = (unsigned)(cb + bperm) << kRecShift;
+                        const V4 cpk1 = gather_packet(rs0, cr, 1, T());
+                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr)) = cpk;
+                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr) + kRingOff1) = cpk1;
+                    }
+                }
                 if constexpr (kF16) m = scan_chunk16(cb, HI, cpk);
                 else m = scan_chunk(cb, HI, cpk);
                 // keep only the candidates of MY three cells of this row (the reference's stale cell list,
