@@ -42,6 +42,9 @@ Objects on the JSON line beyond the contract's keys:
                  the reference re-arms Δx at src/SPHCellList.jl:739).
   fp64, developed_window, parity — secondary measurements (the reference's own arithmetic; 200 steps at t ≈ 0.4 s; a short
                  fp32-vs-oracle check).  `--no-extras` skips them and value_cold.
+  value_end_to_end / end_to_end — the reference's RunSimulation call pattern at the headline size: one sphmi_advance per 0.01 s of
+                 simulated time, every call followed by the asynchronous download of all carried fields, t = 0 → 0.05 s on a cold
+                 handle; updates/s over the whole run (host work between the calls included).
 """
 import argparse
 import json
@@ -243,6 +246,49 @@ def extra_developed(device, t_target=0.4, window=200):
     return {"value": n * window / (t3 - t2), "unit": "particle-updates/s", "ms_per_step": (t3 - t2) / window * 1e3,
             "steps": window, "sim_time": pw.total_time, "rebuilds_in_window": int(pw.n_rebuilds - r0), "kernel_avg_launch_ms": kms,
             "run_up": {"steps": int(it0), "rebuilds": int(r0), "seconds": t1 - t0, "value": n * it0 / (t1 - t0)}}
+
+
+def extra_end_to_end(device, t_end=0.05, interval=0.01):
+    """What a `RunSimulation` of the reference sees at the headline size (src/SPHCellList.jl:881-929): ONE sphmi_advance per output interval
+    (`OutputTimes` = 0.01 s of simulated time, example/Dambreak3d.jl) — each opening with a cell-list rebuild, each followed by the download
+    of every SimParticles field the engine carries into the caller's Float64 arrays (asynchronously: the copies of interval k travel while
+    interval k + 1 is computed, sphmi_download_begin / _end) and by the sort's permutation for the passive columns — from t = 0 to `t_end`,
+    on a handle that starts cold.  updates/s over the WHOLE run, host work between the calls included: where `value` (warm clock, one call)
+    and `value_cold` bracket what a user gets.  The full 0 → 0.4 s run: tools/examples_end_to_end.py dam_break_3d_c3, profiles/r06_examples_end_to_end.md."""
+    import types
+
+    import numpy as np
+    import torch
+    from sphexample_amd.cases import setup_dam_break_3d
+    from sphexample_amd.engine import dam_break_3d_count, make_generated_dam_break_engine
+    eng = make_generated_dam_break_engine(DP1, setup_dam_break_3d(DP1), device_float_bytes=4, device=device)
+    n = sum(dam_break_3d_count(DP1))
+    P = types.SimpleNamespace(Position=np.zeros((n, 3)), Velocity=np.zeros((n, 3)), Acceleration=np.zeros((n, 3)), Density=np.zeros(n), Pressure=np.zeros(n),
+                              ID=np.zeros(n, dtype=np.int64), Type=np.zeros(n, dtype=np.uint8), GroupMarker=np.zeros(n, dtype=np.uint64),
+                              GhostPoints=np.zeros((n, 3)), Cells=np.zeros((n, 3), dtype=np.int64))
+    eng.pin(P)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k, pending, dl = 1, False, 0.0
+    while True:
+        prog = eng.advance(interval * k)                    # next_output_time(SimMetaData) = OutputTimes × counter, :687-698
+        td = time.perf_counter()
+        if pending:
+            eng.download_end()
+        eng.download_into_begin(P); pending = True
+        eng.download_permutation()
+        dl += time.perf_counter() - td
+        k += 1
+        if prog.total_time > t_end:
+            break
+    eng.download_end()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"value": n * prog.iteration / el, "unit": "particle-updates/s", "steps": int(prog.iteration), "intervals": k - 1, "sim_time": prog.total_time,
+           "seconds": el, "host_seconds_in_output_calls": dl, "rebuilds": int(prog.n_rebuilds),
+           "pattern": f"one sphmi_advance per {interval} s of simulated time + asynchronous download of all carried fields into page-locked Float64 arrays + sphmi_download_permutation"}
+    eng.unpin(); eng.close()
+    return out
 
 
 def extra_parity(device, dp=0.0085, steps=10):
@@ -511,11 +557,14 @@ def main():
             out["fallback_from_failed_ranks_exit_code"] = spawn_failure        # (the line below was measured by ONE process: its ranks could not be started)
         if plain and not args.no_extras and not args.dp:
             for name, fn in (("fp64", lambda: extra_fp64(device, args.warmup, args.steps)),
-                             ("developed_window", lambda: extra_developed(device)), ("parity", lambda: extra_parity(device))):
+                             ("developed_window", lambda: extra_developed(device)), ("end_to_end", lambda: extra_end_to_end(device)),
+                             ("parity", lambda: extra_parity(device))):
                 try:
                     out[name] = fn()
                 except Exception as exc:                                  # noqa: BLE001 — a secondary object must not cost the line
                     out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            if isinstance(out.get("end_to_end"), dict) and "value" in out["end_to_end"]:
+                out["value_end_to_end"] = out["end_to_end"]["value"]      # next to value and value_cold: what RunSimulation's call pattern sees
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

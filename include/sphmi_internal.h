@@ -32,6 +32,12 @@ int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* 
  * cells, summed over the local slabs.  cost_out: ncols uint64 on the HOST. */
 int sphmi_multi_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_out);
 
+/* What the scaling prediction of DESIGN.md section 7 is computed from (tools/scaling_inputs.py): ten words per local slab of a multi-device
+ * handle — { slab, rows held (owned + ghost copies), halo records sent to the left / right neighbour with state A, the same with the half-step
+ * state H, tiles of the interior launch, tiles of the slab-edge launch, blocks per XCD run of the two launches }.  A halo record is two packets
+ * (32 bytes with fp32 kernels, 64 with fp64). */
+int sphmi_multi_halo_info(sphmi_handle* h, int64_t* out, int32_t capacity_words, int32_t* n_words_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1859,6 +1859,14 @@ int sphmi_multi_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64
         else throw sphmi::EngineError(SPHMI_ERR_STATE, "sphmi_multi_column_cost: not a multi-device handle");
     }()));
 }
+int sphmi_multi_halo_info(sphmi_handle* h, int64_t* out, int32_t capacity_words, int32_t* n_words_out) {
+    if (!out || !n_words_out || capacity_words < 10) return SPHMI_ERR_ARGUMENT;
+    SPHMI_GUARD(h, ([&] {
+        if (auto* m = dynamic_cast<sphmi::MultiEngine<float>*>(h->e)) *n_words_out = m->halo_info(out, capacity_words);
+        else if (auto* d = dynamic_cast<sphmi::MultiEngine<double>*>(h->e)) *n_words_out = d->halo_info(out, capacity_words);
+        else throw sphmi::EngineError(SPHMI_ERR_STATE, "sphmi_multi_halo_info: not a multi-device handle");
+    }()));
+}
 int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* ghost_points, int64_t n, int32_t world,
                      int32_t* axis_out, int32_t* halo_width_out, int64_t* cuts_out, int64_t* owned_out, int64_t* capacity_out) {
     using namespace sphmi;

@@ -1328,8 +1328,12 @@ k_neighbor_force(const ForceParams<T> P) {
                     if (SPHMI_RING_SHARED == 0 || ((cb >> 6) & 3) == wvb) {
                         const unsigned cr = (unsigned)(cb + bperm) << kRecShift;
                         const V4 cpk1 = gather_packet(rs0, cr, 1, T());
-                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr)) = cpk;
-                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr) + kRingOff1) = cpk1;
+                        // (a lane beyond the array loads zeros — ρ = 0 would put an infinity into sums that the closing multiply by zero turns into NaN: its own record instead)
+                        const bool in = cb + bperm < P.N;
+                        V4 w0 = cpk, w1 = cpk1;
+                        if (!in) { w0 = q0; w1 = q1; }
+                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr)) = w0;
+                        *reinterpret_cast<V4*>(s_ringb + ring_off0(cr) + kRingOff1) = w1;
                     }
                 }
                 if constexpr (kF16) m = scan_chunk16(cb, HI, cpk);

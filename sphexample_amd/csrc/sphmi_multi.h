@@ -1637,6 +1637,21 @@ struct MultiEngine final : EngineBase {
             for (int c = 0; c < ncols; ++c) out[c] += h[(size_t)c];
         }
     }
+    // test / measurement hook (sphmi_multi_halo_info): what the scaling prediction of DESIGN §7 is computed from — per local slab
+    // { slab, rows held (owned + ghost copies), halo records sent left / right with state A, with the half-step state H, tiles of the interior launch, tiles of the
+    //   slab-edge launch, blocks per XCD run of the two launches }
+    static constexpr int kHaloInfoWords = 10;
+    int halo_info(int64_t* out, int cap_words) {
+        int k = 0;
+        for (auto& r : R) {
+            if (!r.e || k + kHaloInfoWords > cap_words) break;
+            const int64_t v[kHaloInfoWords] = {r.rank, r.e->N, r.halo[0].n_send_l, r.halo[0].n_send_r, r.halo[1].n_send_l, r.halo[1].n_send_r,
+                                               r.e->list_tiles[0], r.e->list_tiles[1], r.e->part_max[0], r.e->part_max[1]};
+            for (int i = 0; i < kHaloInfoWords; ++i) out[k + i] = v[i];
+            k += kHaloInfoWords;
+        }
+        return k;
+    }
     void reset_count() override {}
     int64_t owned_count() override { return owned_count_impl(); }
     void multi_info(sphmi_multi_info* o) {

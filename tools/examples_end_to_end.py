@@ -28,6 +28,10 @@ SHORT = "--short" in sys.argv
 def load(name):
     if name == "dam_break_3d_dx0.0085":                       # example/Dambreak3d.jl:8 (the input files of that resolution are not in the checkout: generated)
         return dam_break_3d(0.0085), setup_dam_break_3d(0.0085)
+    if name == "dam_break_3d_c3":                             # round 6: the headline size (BASELINE config 3, dp = 0.00425, 1.06 M particles), 0 → 0.4 s, output every 0.01 s
+        import dataclasses
+        s = setup_dam_break_3d(0.00425)
+        return dam_break_3d(0.00425), dataclasses.replace(s, SimMetaData=dataclasses.replace(s.SimMetaData, SimulationTime=0.4))
     return getattr(conftest, "load_" + name)()
 
 
