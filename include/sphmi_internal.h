@@ -32,10 +32,12 @@ int sphmi_plan_slabs(const sphmi_config* cfg, const void* position, const void* 
  * cells, summed over the local slabs.  cost_out: ncols uint64 on the HOST. */
 int sphmi_multi_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64_t* cost_out);
 
-/* What the scaling prediction of DESIGN.md section 7 is computed from (tools/scaling_inputs.py): ten words per local slab of a multi-device
+/* What the scaling prediction of DESIGN.md section 7 is computed from (tools/scaling_inputs.py): twelve words per local slab of a multi-device
  * handle — { slab, rows held (owned + ghost copies), halo records sent to the left / right neighbour with state A, the same with the half-step
- * state H, tiles of the interior launch, tiles of the slab-edge launch, blocks per XCD run of the two launches }.  A halo record is two packets
- * (32 bytes with fp32 kernels, 64 with fp64). */
+ * state H, tiles of the interior launch, tiles of the slab-edge launch, blocks per XCD run of the two launches, and — with
+ * $SPHMI_DD_ONE_SLAB_AT_A_TIME=1, a measurement mode in which the slabs of a handle that share one GPU take their passes one after the other —
+ * the mean nanoseconds of the slab's pass 1 / pass 2 (interior launch beside unpack + slab-edge launch) with the chip to itself }.  A halo record
+ * is two packets (32 bytes with fp32 kernels, 64 with fp64). */
 int sphmi_multi_halo_info(sphmi_handle* h, int64_t* out, int32_t capacity_words, int32_t* n_words_out);
 
 #ifdef __cplusplus

@@ -238,6 +238,12 @@ struct Engine final : EngineBase {
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
+    // Round 6: the slab-edge launch of an OVERLAPPED pass shares the chip with the interior launch of the same pass (side stream ‖ main stream), so the two
+    // together are the launch that has to fill the chip: the waves per tile of the edge list follow the SUM of the two lists there.  Until round 6 the edge
+    // list chose for itself — 2 850 edge tiles of a C4 slab ran four waves per tile (72 ns of device time per tile against 59 for the interior's two-wave tiles,
+    // tools/slab_device_time.py: 4 % of a slab's step).  $SPHMI_EDGE_WPT_JOINT=0: the old choice.
+    bool edge_wpt_joint = true;
+    bool edge_overlapped = false;      // set by dd_pass around an edge launch that runs beside the interior launch
     // XCD shares of the estimated tile cost, moved towards equal finishing times: one corrector launch per rebuild
     // interval records when each XCD ran out of tiles ($SPHMI_XCD_FEEDBACK=0 switches it off)
     int xcd_feedback = 1; bool xcd_sampled = false;
@@ -309,6 +315,7 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(c.device));
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) force_wpt = v; }
+        if (const char* w = getenv("SPHMI_EDGE_WPT_JOINT")) edge_wpt_joint = atoi(w) != 0;
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
         xcd_trace = getenv("SPHMI_XCD_TRACE") != nullptr;          // one line per sampled launch on stderr: finishing time of each XCD ÷ mean, shares
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
@@ -563,7 +570,8 @@ struct Engine final : EngineBase {
         P.order = tile_order[list]; P.part = part_d + 16 * list; P.trace = trace_d;
         // waves per tile: enough waves for several rounds of the 8192 wave slots of the chip (per list: the
         // slab-edge list of a domain-decomposed pass is much shorter than the interior list)
-        const int ntile = list_tiles[list];        // fixed at the rebuild: the choice must not follow the measured run lengths
+        // (fixed at the rebuild: the choice must not follow the measured run lengths; an overlapped edge launch counts the interior tiles it runs beside)
+        const int ntile = (list == 1 && edge_overlapped && edge_wpt_joint) ? list_tiles[0] + list_tiles[1] : list_tiles[list];
         const int wpt = waves_per_tile(ntile, MODEL < 0);
         bool resched_after = false;
         // (the XCD finishing times may also be taken by the SECOND step of the batch whose first step measured the work — the schedule made
@@ -1625,7 +1633,10 @@ struct Engine final : EngineBase {
         }
         if ((part == 0 || part == 2) && part_max[1] > 0) {
             Ev e = begin_phase(which == 1 ? PH_PASS1_EDGE : PH_PASS2_EDGE);
-            if (which == 1) launch_force<PASS_PREDICTOR>(P, 1); else launch_force<PASS_CORRECTOR>(P, 1);
+            edge_overlapped = part == 2;
+            try { if (which == 1) launch_force<PASS_PREDICTOR>(P, 1); else launch_force<PASS_CORRECTOR>(P, 1); }
+            catch (...) { edge_overlapped = false; throw; }
+            edge_overlapped = false;
             end_phase(e);
         }
         if (which == 2 && part != 1) {
@@ -1860,7 +1871,7 @@ int sphmi_multi_column_cost(sphmi_handle* h, int64_t col0, int32_t ncols, uint64
     }()));
 }
 int sphmi_multi_halo_info(sphmi_handle* h, int64_t* out, int32_t capacity_words, int32_t* n_words_out) {
-    if (!out || !n_words_out || capacity_words < 10) return SPHMI_ERR_ARGUMENT;
+    if (!out || !n_words_out || capacity_words < 12) return SPHMI_ERR_ARGUMENT;
     SPHMI_GUARD(h, ([&] {
         if (auto* m = dynamic_cast<sphmi::MultiEngine<float>*>(h->e)) *n_words_out = m->halo_info(out, capacity_words);
         else if (auto* d = dynamic_cast<sphmi::MultiEngine<double>*>(h->e)) *n_words_out = d->halo_info(out, capacity_words);

@@ -22,6 +22,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <array>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <numeric>
@@ -599,6 +601,7 @@ struct MultiEngine final : EngineBase {
         if (const char* w = getenv("SPHMI_DD_OVERLAP")) overlap = atoi(w) != 0;
         if (const char* w = getenv("SPHMI_DD_RECUT")) recut_imbalance = atof(w);
         if (const char* w = getenv("SPHMI_DD_TWO_SORTS")) two_sorts = atoi(w) != 0;
+        if (const char* w = getenv("SPHMI_DD_ONE_SLAB_AT_A_TIME")) one_at_a_time = atoi(w) != 0;
         bool shared_device = false;
         if (rank_mode) {
             R.resize(1); R[0].rank = my_rank; R[0].device = c.device;
@@ -1188,7 +1191,64 @@ struct MultiEngine final : EngineBase {
             if (r.has_right && h.n_slot_r) msgs.push_back({r.rank + 1, r.rank, nullptr, h.rb_r.p, (size_t)h.n_slot_r * vb, which * 4 + 0});
         }
     }
+    // $SPHMI_DD_ONE_SLAB_AT_A_TIME=1 (measurement only, tools/slab_pass_time.py): the slabs of a one-process handle that share ONE GPU take their passes one after
+    // the other — all slabs pack, the messages are copied, then slab by slab: interior launch on the main stream ‖ unpack + slab-edge launch on the side stream,
+    // and the host waits for both before the next slab starts.  A slab's own two launches still overlap each other, but no other slab's work is on the chip:
+    // the time between the two host synchronisations is what a GPU of its own would spend on the pass with the halo already landed.  `pass_us[q][which-1]` adds it up.
+    bool one_at_a_time = false;
+    std::vector<std::array<double, 2>> pass_us; std::vector<std::array<long long, 2>> pass_n;
+    void pass_one_at_a_time(int which) {
+        const int set = which - 1;
+        std::vector<Msg> msgs;
+        for (auto& r : R) {
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            if (moving) e.dd_progress_motion();
+            Halo& h = r.halo[set];
+            const int n = h.n_send_l + h.n_send_r;
+            wait_consumed(r, set * 4 + 0); wait_consumed(r, set * 4 + 1);
+            if (n) {
+                const int s_ = set == 0 ? e.iA : e.iH;
+                hipLaunchKernelGGL(k_halo_pack2<T>, dim3((n + 255) / 256), dim3(256), 0, r.main, e.pk0[s_], e.pk1[s_],
+                                   (const int*)h.send_l.p, h.n_send_l, (V4*)h.sb_l.p, (const int*)h.send_r.p, h.n_send_r, (V4*)h.sb_r.p);
+                HC(hipGetLastError());
+            }
+            HC(hipEventRecord(r.ev_pack, r.main));
+        }
+        halo_msgs(set, msgs);
+        exchange(pair_up(msgs), false);
+        for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); HC(hipStreamSynchronize(r.side)); }
+        if (pass_us.size() != R.size()) { pass_us.assign(R.size(), {0.0, 0.0}); pass_n.assign(R.size(), {0, 0}); }
+        for (size_t q = 0; q < R.size(); ++q) {
+            Rank& r = R[q];
+            HC(hipSetDevice(r.device));
+            Engine<T>& e = *r.e;
+            Halo& h = r.halo[set];
+            const int n = h.n_slot_l + h.n_slot_r;
+            const auto t0 = std::chrono::steady_clock::now();
+            HC(hipEventRecord(r.ev_pack, r.main));
+            HC(hipStreamWaitEvent(r.side, r.ev_pack, 0));
+            e.dd_pass(which, 0.0, 1);
+            e.stream = r.side;
+            try {
+                if (n) {
+                    const int s_ = set == 0 ? e.iA : e.iH;
+                    hipLaunchKernelGGL(k_halo_unpack2<T>, dim3((n + 255) / 256), dim3(256), 0, r.side, e.pk0[s_], e.pk1[s_],
+                                       (const int*)h.slot_l.p, h.n_slot_l, (const V4*)h.rb_l.p, (const int*)h.slot_r.p, h.n_slot_r, (const V4*)h.rb_r.p);
+                    HC(hipGetLastError());
+                }
+                e.dd_pass(which, 0.0, 2);
+                HC(hipEventRecord(r.ev_edge, r.side));
+                HC(hipStreamWaitEvent(r.main, r.ev_edge, 0));
+            } catch (...) { e.stream = r.main; throw; }
+            e.stream = r.main;
+            HC(hipStreamSynchronize(r.main));
+            pass_us[q][set] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            pass_n[q][set] += 1;
+        }
+    }
     void pass(int which) {
+        if (one_at_a_time && cfg.mdbc == SPHMI_MDBC_NONE && !use_rccl && !shm) { pass_one_at_a_time(which); return; }
         const int set = which - 1;
         bool serial = !overlap || (cfg.mdbc == SPHMI_MDBC_SIMPLE && which == 1);
         // (no local slab sends or receives anything — a one-slab world: the whole pass is one launch on the main stream, without the
@@ -1640,13 +1700,17 @@ struct MultiEngine final : EngineBase {
     // test / measurement hook (sphmi_multi_halo_info): what the scaling prediction of DESIGN §7 is computed from — per local slab
     // { slab, rows held (owned + ghost copies), halo records sent left / right with state A, with the half-step state H, tiles of the interior launch, tiles of the
     //   slab-edge launch, blocks per XCD run of the two launches }
-    static constexpr int kHaloInfoWords = 10;
+    static constexpr int kHaloInfoWords = 12;    // (words 10, 11: $SPHMI_DD_ONE_SLAB_AT_A_TIME — mean host-timed nanoseconds of the slab's pass 1 / pass 2 run alone on the chip, 0 otherwise)
     int halo_info(int64_t* out, int cap_words) {
         int k = 0;
         for (auto& r : R) {
             if (!r.e || k + kHaloInfoWords > cap_words) break;
+            const size_t q = (size_t)(&r - &R[0]);
+            const bool timed = one_at_a_time && q < pass_us.size();
             const int64_t v[kHaloInfoWords] = {r.rank, r.e->N, r.halo[0].n_send_l, r.halo[0].n_send_r, r.halo[1].n_send_l, r.halo[1].n_send_r,
-                                               r.e->list_tiles[0], r.e->list_tiles[1], r.e->part_max[0], r.e->part_max[1]};
+                                               r.e->list_tiles[0], r.e->list_tiles[1], r.e->part_max[0], r.e->part_max[1],
+                                               timed && pass_n[q][0] ? (int64_t)(1e3 * pass_us[q][0] / (double)pass_n[q][0]) : 0,
+                                               timed && pass_n[q][1] ? (int64_t)(1e3 * pass_us[q][1] / (double)pass_n[q][1]) : 0};
             for (int i = 0; i < kHaloInfoWords; ++i) out[k + i] = v[i];
             k += kHaloInfoWords;
         }

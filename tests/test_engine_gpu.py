@@ -5,6 +5,8 @@ Tolerances (north_star: "density/position error vs. CPU reference < 1e-5 relativ
   fp32 kernels vs fp64 oracle : single force evaluation 2e-4 of the field maximum (fp32 cancellation
                                 in Σ of O(100) pair terms), K-step density and position 1e-5 relative
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -506,13 +508,21 @@ def test_moving_square_example(moving_square, fb, tol):
     assert relmax(e["Position"], o["Position"]) < tol and relmax(e["Density"], o["Density"]) < tol
 
 
+PERF_GUARDS = os.environ.get("SPHMI_PERF_GUARDS") == "1"
+
+
 @pytest.mark.parametrize("case,limit_us", [("moving_square", 55.0), ("duckling", 100.0), ("dam_break_3d_shipped", 62.0), ("dam_break_2d", 28.0)])
 def test_example_step_times_stay_in_their_class(case, limit_us):
-    """A guard, 1.3 × the step times recorded in BASELINE.md §6 (fp32: MovingSquare2d 41 µs, DucklingMDBC 76, Dambreak3d Dp0.02 47, the 2-D dam
-    break 21; round 4 allowed 2.5 ×): parity tests do not see a kernel that spills its accumulators to scratch — round 3 carried a five-fold
+    """A guard on the step times recorded in BASELINE.md §6 (fp32: MovingSquare2d 41 µs, DucklingMDBC 76, Dambreak3d Dp0.02 47, the 2-D dam
+    break 21): parity tests do not see a kernel that spills its accumulators to scratch — round 3 carried a five-fold
     slowdown of the run-time-model kernels with four and eight waves per tile (MovingSquare2d 55 → 272 µs per step) through every green suite
-    until `tools/bench_examples.py` was compared with round 2's figures."""
+    until `tools/bench_examples.py` was compared with round 2's figures.
+    Wall-clock limits depend on the box and its clock governor (round-5 advice): by default the limit is 2.5 × the record — a change of CLASS, which
+    is what the guard is for (the structural half of it, no scratch in any kernel, is a CPU test: tests/test_bench_contract.py) — and the tight
+    1.3 × only with $SPHMI_PERF_GUARDS=1 (the round's own measurement runs, tools/full_gpu_check.sh)."""
     import time
+    if not PERF_GUARDS:
+        limit_us = limit_us / 1.3 * 2.5
     import conftest
     from sphexample_amd.engine import make_engine
     p, s = getattr(conftest, "load_" + case)()
@@ -542,7 +552,8 @@ def test_config_3_kernel_time_stays_in_its_class():
         ms, n = eng.force_kernel_stats()
         assert n > 0
         best = min(best, ms)
-    assert best < 0.455, f"{best:.4f} ms per launch"
+    limit = 0.455 if PERF_GUARDS else 0.80          # (2 × the record by default: a class guard; the tight one is opt-in, see above)
+    assert best < limit, f"{best:.4f} ms per launch"
 
 
 @pytest.mark.parametrize("k", [1.5, 2.0, 2.5])

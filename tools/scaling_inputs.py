@@ -36,12 +36,12 @@ def step_ms(e, n):
 
 
 def halo_info(e, world):
-    out = (C.c_int64 * (10 * world))()
+    out = (C.c_int64 * (12 * world))()
     n = C.c_int32()
     e._lib.sphmi_multi_halo_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]
-    e._check(e._lib.sphmi_multi_halo_info(e._h, out, 10 * world, C.byref(n)))
-    keys = ("slab", "rows", "send_l_A", "send_r_A", "send_l_H", "send_r_H", "tiles_interior", "tiles_edge", "run_interior", "run_edge")
-    return [dict(zip(keys, out[10 * k:10 * k + 10])) for k in range(n.value // 10)]
+    e._check(e._lib.sphmi_multi_halo_info(e._h, out, 12 * world, C.byref(n)))
+    keys = ("slab", "rows", "send_l_A", "send_r_A", "send_l_H", "send_r_H", "tiles_interior", "tiles_edge", "run_interior", "run_edge", "pass1_alone_ns", "pass2_alone_ns")
+    return [dict(zip(keys, out[12 * k:12 * k + 12])) for k in range(n.value // 12)]
 
 
 res = {"steps": steps, "record_bytes": 32, "runs": []}
