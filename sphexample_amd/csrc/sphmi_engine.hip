@@ -238,11 +238,13 @@ struct Engine final : EngineBase {
     double dx_rate = 0.0;              // Δx per step over the last batch: the next batch ends at the step expected to ask for a rebuild
     int part_max[2] = {0, 0};          // tiles in the longest XCD run of each list (grid = 8 × part_max blocks)
     int force_wpt = 0;                 // $SPHMI_WPT: waves per tile override (experiments)
-    // Round 6: the slab-edge launch of an OVERLAPPED pass shares the chip with the interior launch of the same pass (side stream ‖ main stream), so the two
-    // together are the launch that has to fill the chip: the waves per tile of the edge list follow the SUM of the two lists there.  Until round 6 the edge
-    // list chose for itself — 2 850 edge tiles of a C4 slab ran four waves per tile (72 ns of device time per tile against 59 for the interior's two-wave tiles,
-    // tools/slab_device_time.py: 4 % of a slab's step).  $SPHMI_EDGE_WPT_JOINT=0: the old choice.
-    bool edge_wpt_joint = true;
+    // Round 6, $SPHMI_EDGE_WPT_JOINT=1 (off): the slab-edge launch of an OVERLAPPED pass shares the chip with the interior launch of the same pass (side stream ‖
+    // main stream), so the waves per tile of the edge list may follow the SUM of the two lists instead of the edge list's own length — 2 850 edge tiles of a C4 slab
+    // run four waves per tile (72 ns of device time per tile against 59 for the interior's two-wave tiles, tools/slab_device_time.py).  Measured with every slab's
+    // pass alone on the chip (tools/slab_pass_time.py, three runs): the MEAN pass of a slab gets 1-2 % shorter at 2 / 4 / 8 slabs, but the SLOWEST slab — the one a
+    // step waits for — −1 % / +2.4 % / ±0: its few long-lived edge waves start late and stretch the tail.  Not a gain where it counts; left as a switch for the
+    // first real multi-GPU run.
+    bool edge_wpt_joint = false;
     bool edge_overlapped = false;      // set by dd_pass around an edge launch that runs beside the interior launch
     // XCD shares of the estimated tile cost, moved towards equal finishing times: one corrector launch per rebuild
     // interval records when each XCD ran out of tiles ($SPHMI_XCD_FEEDBACK=0 switches it off)
@@ -1521,7 +1523,7 @@ struct Engine final : EngineBase {
         HC(hipSetDevice(cfg.device));
         progress_motion(0.0, ctrl_d);
     }
-    // mDBC (:772) for every boundary particle held, ghost copies included: with a halo wide enough (distributed.py)
+    // mDBC (:772) for every boundary particle held, ghost copies included: with a halo wide enough (tests/slab_planner_reference.py holds the planner in numpy)
     // the copies a pass can see get the owner's value up to summation order, and nothing has to travel twice
     void dd_mdbc() {
         if (cfg.mdbc != SPHMI_MDBC_SIMPLE) return;

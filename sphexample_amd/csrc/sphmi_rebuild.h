@@ -1360,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_progress_motion(Half<typename Vec4<T>::
     }
 }
 
-// ---- domain decomposition (one process per GPU, x-slabs; sphexample_amd/distributed.py) -----------
+// ---- domain decomposition (one process per GPU, x-slabs; csrc/sphmi_multi.h) -----------
 // global cell index along the slab axis of every particle, current order
 template <class T>
 __global__ void __launch_bounds__(256) k_dd_cellx(Half<const typename Vec4<T>::type> pk0, int N, T inv_cutoff, int axis, int* out) {

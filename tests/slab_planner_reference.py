@@ -1,4 +1,5 @@
 """The slab PLANNER in Python — the independent reference the C++ planner of libsphmi.so is tested against.
+TEST INFRASTRUCTURE (it lived in the product package as sphexample_amd/distributed.py until round 6; nothing in the package used it).
 
 The product path for more than one GPU lives inside the library (csrc/sphmi_multi.h): `sphmi_create` with a device list
 (one process, what the reference's Julia caller needs) or `sphmi_create_rank` (one process per GPU, what bench.py uses).
@@ -24,7 +25,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from ._abi import SphmiConfig
+from sphexample_amd._abi import SphmiConfig
 
 GHOST_LEFT, GHOST_RIGHT, GHOST_MASK = 0x80, 0x40, 0xC0
 

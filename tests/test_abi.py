@@ -39,7 +39,7 @@ def test_the_public_header_is_the_boundary_only():
     assert not [s for s in declared_symbols() if s.startswith("sphmi_dd_")]
     for gone in ("sphmi_dd_pass", "sphmi_dd_upload", "sphmi_dd_rebuild", "sphmi_dd_halo_pack"):
         assert not hasattr(lib, gone)
-    assert set(declared_symbols(INTERNAL)) == {"sphmi_shm_selftest", "sphmi_multi_set_cuts", "sphmi_plan_slabs", "sphmi_multi_column_cost"}
+    assert set(declared_symbols(INTERNAL)) == {"sphmi_shm_selftest", "sphmi_multi_set_cuts", "sphmi_plan_slabs", "sphmi_multi_column_cost", "sphmi_multi_halo_info"}
     assert not set(declared_symbols(INTERNAL)) & set(declared_symbols())
 
 

