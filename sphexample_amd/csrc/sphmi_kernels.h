@@ -97,6 +97,9 @@ constexpr int kWave = 64;
 #define SPHMI_SMALL_TRIMS 1     // launches of four and eight waves per tile (a few hundred waves, 10 µs): the epilogue's loads requested at the wave's start, no
                                 // pre-test in front of the reduction atomics (round 5); 0: A/B builds
 #endif
+#ifndef SPHMI_PREFETCH_RANGES
+#define SPHMI_PREFETCH_RANGES 1 // launches of four and eight waves per tile: the cell ranges of all rows requested at once, parked in a private LDS column (round 6; 0: one exposed look-up per row)
+#endif
 #ifndef SPHMI_LOOP_UNROLL
 #define SPHMI_LOOP_UNROLL 2     // fp32 pair loop (one pair per iteration): iterations per loop test (1: rounds 1-4)
 #endif
@@ -1263,6 +1266,13 @@ k_neighbor_force(const ForceParams<T> P) {
     // and share them in LDS (two-wave tiles keep their own look-ups: sharing costs them 6 %).
     constexpr bool kShareRanges = WPT >= 4 && !kHalf;
     __shared__ int2 s_rng[kShareRanges ? NSEG * kWave : 1];
+    // Round 6: half tiles of several waves per half (every launch of four and eight waves per tile since round 4) lost that sharing with the full tiles it was
+    // written for, and each wave was back to one exposed round trip per cell row — nine in 3-D — in launches whose whole life is 10–40 µs.  They now request the
+    // ranges of ALL rows at once and park them in a private LDS column ([wave][row][lane]: no barrier, no other wave reads it): one round trip instead of NSEG.
+    // (-DSPHMI_PREFETCH_RANGES=0: A/B builds)
+    constexpr bool kPrefetchRanges = SPHMI_PREFETCH_RANGES != 0 && WPT >= 4 && kHalf;
+    __shared__ int2 s_rng_own[kPrefetchRanges ? WPT * TPB * NSEG * kWave : 1];
+    [[maybe_unused]] int2* const s_rng_w = s_rng_own + (kPrefetchRanges ? wvb * NSEG * kWave + lane : 0);
     if constexpr (kShareRanges) {
 #pragma unroll
         for (int k = 0; k < (NSEG + WPT - 1) / WPT; ++k) {
@@ -1281,11 +1291,24 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     };
     const int nseg = dead ? 0 : NSEG;                   // (a dead wave scans nothing: empty queues, zero sums, no stores — it only keeps the barriers whole)
+    if constexpr (kPrefetchRanges) {
+        if (!dead) {
+            int2 rg[NSEG];
+#pragma unroll
+            for (int seg = 0; seg < NSEG; ++seg) {
+                const int off = row_offset(seg);
+                rg[seg] = make_int2(valid ? P.cstart[key_a + off - 1] : 0, valid ? P.cstart[key_a + off + 2] : 0);
+            }
+#pragma unroll
+            for (int seg = 0; seg < NSEG; ++seg) s_rng_w[seg * kWave] = rg[seg];
+        }
+    }
 #pragma unroll 1
     for (int seg = 0; seg < nseg; ++seg) {
         // the three x-adjacent cells of a row are one contiguous index range (x is the fastest sort axis)
         int lo_l, hi_l;
         if constexpr (kShareRanges) { const int2 rg = s_rng[seg * kWave + lane]; lo_l = rg.x; hi_l = rg.y; }
+        else if constexpr (kPrefetchRanges) { const int2 rg = s_rng_w[seg * kWave]; lo_l = rg.x; hi_l = rg.y; }
         else {
             const int off = row_offset(seg);
             lo_l = valid ? P.cstart[key_a + off - 1] : 0;
