@@ -1270,7 +1270,9 @@ k_neighbor_force(const ForceParams<T> P) {
     // written for, and each wave was back to one exposed round trip per cell row — nine in 3-D — in launches whose whole life is 10–40 µs.  They now request the
     // ranges of ALL rows at once and park them in a private LDS column ([wave][row][lane]: no barrier, no other wave reads it): one round trip instead of NSEG.
     // (-DSPHMI_PREFETCH_RANGES=0: A/B builds)
-    constexpr bool kPrefetchRanges = SPHMI_PREFETCH_RANGES != 0 && WPT >= 4 && kHalf;
+    // (compiled-in models only: the run-time-model kernels of four waves per tile sit at 127 registers and pay 12–31 % for the eighteen more — 158 791 particles
+    // Laminar 193 → 233 µs per step, 70 262 with PlanarShifting 94 → 123: profiles/r06_raw/prefetch_ranges_sizes_ab.txt)
+    constexpr bool kPrefetchRanges = SPHMI_PREFETCH_RANGES != 0 && WPT >= 4 && kHalf && MODEL >= 0;
     __shared__ int2 s_rng_own[kPrefetchRanges ? WPT * TPB * NSEG * kWave : 1];
     [[maybe_unused]] int2* const s_rng_w = s_rng_own + (kPrefetchRanges ? wvb * NSEG * kWave + lane : 0);
     if constexpr (kShareRanges) {
