@@ -945,7 +945,7 @@ struct MultiEngine final : EngineBase {
                            (const int64_t*)pi.data(), groups ? (const uint64_t*)pg.data() : nullptr,
                            ghost_points ? ph.data() : nullptr, mine.data());
         }
-        uploaded = true; have_halo = false; dx_rate = 0.0; parity = 0;
+        uploaded = true; have_halo = false; recut_ready = false; dx_rate = 0.0; parity = 0;
     }
 
     SlabPlan given_plan;               // test hook (sphmi_multi_set_cuts): start from these cuts instead of the balanced ones
@@ -999,7 +999,9 @@ struct MultiEngine final : EngineBase {
         for (auto& r : R) { HC(hipSetDevice(r.device)); cellx(r); }
         // 0. load balance by WORK (candidates per particle on the cell list of the previous rebuild): the rebuild is the
         //    only time particles change cells, so it is also when the cuts may move
-        if (world > 1 && recut_imbalance > 0 && n_rebuilds > 0) {
+        // (`recut_ready`: the slab engines hold a cell list — false until the first rebuild after an upload, which makes NEW slab engines; until round 6 the
+        // test was n_rebuilds > 0, and a second sphmi_upload on a multi-device handle ended in "sphmi_dd_column_cost before the first rebuild")
+        if (world > 1 && recut_imbalance > 0 && recut_ready) {
             std::vector<long long> ext((size_t)L * 2);
             for (int q = 0; q < L; ++q) {
                 Rank& r = R[q]; HC(hipSetDevice(r.device));
@@ -1118,8 +1120,10 @@ struct MultiEngine final : EngineBase {
         }
         for (auto& r : R) { HC(hipSetDevice(r.device)); HC(hipStreamSynchronize(r.main)); }
         have_halo = true;
+        recut_ready = true;
         n_rebuilds += 1;
     }
+    bool recut_ready = false;
 
     // full records of the listed particles to the adjacent ranks; arrivals are appended with `flag`
     void migrate(const std::vector<long long>& n_l, const std::vector<long long>& n_r, const std::vector<int*>& idx_l,

@@ -43,6 +43,10 @@ def main():
         eng = make_engine(p, s, device_float_bytes=fb, device=device, rank=rank, world=world, unique_id=uid,
                           slab_axis=None if axis < 0 else axis)
     prog = []
+    if os.environ.get("SPHMI_TEST_REUPLOAD"):
+        # an ODD number of steps, then the same particle set again: the step parity restarts, the mailbox sequence does not (round-5 advice)
+        eng.advance(1e9, max_steps=int(os.environ["SPHMI_TEST_REUPLOAD"]))
+        eng.upload_particles(p)
     for _ in range(calls):
         pr = eng.advance(1e9, max_steps=steps // calls)
         prog.append([pr.iteration, pr.steps_done, pr.n_rebuilds, pr.index_counter, pr.total_time, pr.last_dt])

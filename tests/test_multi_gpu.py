@@ -185,6 +185,34 @@ def test_serial_halo_path(request, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,world", [("dam_break_3d_shipped", 3), ("moving_square", 2)])
+def test_one_slab_at_a_time_measurement_mode_changes_no_result(case, world, request, monkeypatch):
+    """SPHMI_DD_ONE_SLAB_AT_A_TIME=1 (tools/slab_pass_time.py: every slab's pass alone on the chip, timed by the host — the input of DESIGN §7's
+    scaling prediction): a different ORDER of the same launches and copies, so the state must be the default path's, and the hook reports times."""
+    info = _compare(case, 30, 8, 1e-9, None, world, request, env={"SPHMI_DD_ONE_SLAB_AT_A_TIME": "1"}, monkeypatch=monkeypatch)
+    assert info.world == world
+
+
+@pytest.mark.gpu
+def test_a_second_upload_on_a_multi_slab_handle(dam_break_3d_shipped):
+    """sphmi_upload makes new slab engines; the collective rebuild that follows must not ask them for the work histogram of a cell list they do not
+    have yet (round 6: it did — "sphmi_dd_column_cost before the first rebuild" — whenever the handle had rebuilt before).  Same state as a one-device
+    handle that is uploaded twice."""
+    from sphexample_amd.engine import make_engine
+    p, s = dam_break_3d_shipped
+    one, dd = make_engine(p, s, device_float_bytes=8), make_engine(p, s, device_float_bytes=8, devices=[0, 0, 0])
+    for e in (one, dd):
+        e.advance(1e9, max_steps=7)
+        e.upload_particles(p)
+    pr, pd = one.advance(1e9, max_steps=30), dd.advance(1e9, max_steps=30)
+    assert (pd.steps_done, pd.index_counter) == (pr.steps_done, pr.index_counter) and pd.last_dt == pytest.approx(pr.last_dt, rel=1e-12)
+    a, b = one.download(("ID", "Density", "Position")), dd.download(("ID", "Density", "Position"))
+    np.testing.assert_array_equal(a["ID"], b["ID"])
+    assert np.abs(a["Density"] - b["Density"]).max() < 1e-9 * np.abs(a["Density"]).max()
+    assert np.abs(a["Position"] - b["Position"]).max() < 1e-9 * np.abs(a["Position"]).max()
+
+
+@pytest.mark.gpu
 def test_cuts_move_with_the_work(request):
     """Start four columns off balance: the first rebuilds move the cuts back (particles migrate, ghost layers and halo
     lists are rebuilt) and the result is still the one-device one."""

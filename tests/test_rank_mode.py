@@ -111,3 +111,30 @@ def test_mailbox_exchange_is_the_allreduce_bit_for_bit(case, world, steps, fb, c
         assert int(a["info"][6]) == 0 and int(b["info"][6]) == 1           # the second run DID go through the mailboxes
         for k in ("prog", "ID", "Density", "Position", "Velocity"):
             assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_mailbox_exchange_survives_a_second_upload(request, tmp_path):
+    """Round-5 advice: `sphmi_upload` restarts the step parity while the mailbox sequence number keeps counting, so after an ODD number of steps two
+    consecutive posts shared one half of a box (only host latency kept that safe).  The half now follows the sequence number: seven steps, the same
+    particle set uploaded again, forty more — three ranks, mailbox exchange — against the one-device handle doing the same."""
+    from sphexample_amd.engine import make_engine
+    case, world, steps, odd = "dam_break_3d_shipped", 3, 40, 7
+    res = _spawn(world, lambda r: ("run", case, steps, 8, str(tmp_path), 1, -1), extra_env={"SPHMI_EXCHANGE": "mailbox", "SPHMI_MBOX_TIMEOUT": "30", "SPHMI_TEST_REUPLOAD": str(odd)})
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+    p, s = request.getfixturevalue(case)
+    ref = make_engine(p, s, device_float_bytes=8)
+    ref.advance(1e9, max_steps=odd)
+    ref.upload_particles(p)
+    pr = ref.advance(1e9, max_steps=steps)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for q in parts:
+        assert int(q["info"][6]) == 1
+        np.testing.assert_array_equal(q["prog"][0, 1:4], [pr.steps_done, pr.n_rebuilds, pr.index_counter])
+        np.testing.assert_allclose(q["prog"][0, 5], pr.last_dt, rtol=1e-12)
+    got = _by_id({k: np.concatenate([q[k] for q in parts]) for k in ("ID", "Density", "Position")})
+    r = _by_id(ref.download(("ID", "Density", "Position")))
+    np.testing.assert_array_equal(got["ID"], r["ID"])
+    assert np.abs(got["Density"] - r["Density"]).max() / np.abs(r["Density"]).max() < 1e-9
+    assert np.abs(got["Position"] - r["Position"]).max() / np.abs(r["Position"]).max() < 1e-9
