@@ -111,7 +111,7 @@ def counters_for(identity, n_local, kern_ms):
             "waves_per_simd_pmc": 0.5 * (c["predictor"]["waves_per_simd_mean"] + c["corrector"]["waves_per_simd_mean"]),
             "wave_time_on_waitcnt_pmc": 0.5 * (c["predictor"]["wave_time_parked_on_waitcnt"] + c["corrector"]["wave_time_parked_on_waitcnt"]),
             "unit": "wave64 vector instructions/s", "source": COUNTER_RECORD}
-    # The unit the launch runs out of since the middle of round 5: the texture path charges a wave-level gather by its lanes and
+    # The unit the launch runs out of since the middle of round 5 (profiles/HISTORY.md §4.9): the texture path charges a wave-level gather by its lanes and
     # segments, not by its bytes — tools/ubench/gather4.hip on this chip, CU-cycles per b128 instruction with the data in L1: 34 for 64 lanes
     # with scattered records inside 4 KB, 24.5 inside 256 B, 26 for 32 lanes, 17 coalesced.  The kernels' gathers have ≈55 of 64 lanes switched on
     # and, with six-entry queues, lanes that stay close together: ≈30 cycles.

@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
 # the snapshot): every test that loads a library other than LIB loads one of these, so the driver can rebuild what it runs.
 VARIANT_DIR = os.path.join(os.path.dirname(_HERE), "build", "variants")
 VARIANTS = {
-    # BASELINE config 3 names "LDS cell-tile staging on": the ablation build of DESIGN §4.5 (measured, off) — tests/test_lds_stage_variant_gpu.py
+    # BASELINE config 3 names "LDS cell-tile staging on": the ablation build of profiles/HISTORY.md §4.5 (measured, off) — tests/test_lds_stage_variant_gpu.py
     "ldsstage": ("-DSPHMI_LDS_STAGE=1",),
 }
 

@@ -14,7 +14,7 @@
 // the cell list — sphmi_rebuild.h).  The kernels of two, four and eight waves per tile — every default launch since the second half
 // of round 4 — serve a tile as two HALF TILES: a wave holds 32 targets with TWO LANES PER TARGET (lanes l and l + 32), which take
 // alternate groups of four candidates of every chunk the wave scans and add their sums after the loop; a half is worked off by one,
-// two or four waves that deal its chunks in turn (`kHalf`).  One wave per tile with one lane per target is the
+// two or four waves that deal its chunks in turn (`kHalf`, profiles/HISTORY.md §4.8).  One wave per tile with one lane per target is the
 // organisation of rounds 1–4 ($SPHMI_WPT=1; the description below is written for it, the phases are the same):
 //   phase 1  "who is within H".  For each of the 3^(D-1) cell rows around the tile the three x-adjacent
 //            cells of every target are one contiguous particle range (x is the fastest sort axis); the
@@ -32,7 +32,7 @@
 //            written once.  Phase 1 resumes when some lane's queue is full.
 //   epilogue predictor or corrector fused in; wave-level max-reductions for Δt / Δx (consumed on the device by
 //            k_step_control).
-// Measured history and the experiments behind these choices: DESIGN.md §4.
+// What ships: DESIGN.md §4.  Measured history and the experiments behind these choices: profiles/HISTORY.md §4.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,7 +62,7 @@ constexpr int kWave = 64;
 // prefetch, two neighbours in flight, phase 1 pipelined, s_setprio, the predictor's masks handed to the corrector, the sign bits
 // on the matrix pipe; round 5: packed fp32 arithmetic, lane pairs that gather one record per instruction) lives as patches under
 // profiles/ (r03_raw/mask_mfma_experiment.patch, r04_retired_switches.patch, r05_retired_switches.patch,
-// r05_pair_gather_experiment.patch, r05_deep_pair_experiment.patch) with its figures in profiles/r03_pair_loop_experiments.md and DESIGN §4.9 — not in this file.
+// r05_pair_gather_experiment.patch, r05_deep_pair_experiment.patch) with its figures in profiles/r03_pair_loop_experiments.md and profiles/HISTORY.md §4.9 — not in this file.
 #ifndef SPHMI_LDS_STAGE
 #define SPHMI_LDS_STAGE 0       // ABLATION BUILD (BASELINE config 3: "LDS cell-tile staging on"): the candidate records of a chunk are staged in LDS
                                 // and the pair loop reads them from there, chunk by chunk, instead of gathering from L1 through per-lane mask queues
@@ -91,7 +91,7 @@ constexpr int kWave = 64;
 #ifndef SPHMI_HALF_INTERLEAVE
 #define SPHMI_HALF_INTERLEAVE 1 // half tiles: the two lanes of a target take alternate groups of FOUR candidates (1) or the lower / upper 32 of a chunk (0: A/B builds).
                                 // (Round 5 built alternate SINGLE candidates — no index arithmetic per pair — and packed fp32 arithmetic for the pair; both measured
-                                // slower and live in profiles/r05_retired_switches.patch)
+                                // slower and live in profiles/r05_retired_switches.patch, profiles/HISTORY.md §4.9.)
 #endif
 #ifndef SPHMI_SMALL_TRIMS
 #define SPHMI_SMALL_TRIMS 1     // launches of four and eight waves per tile (a few hundred waves, 10 µs): the epilogue's loads requested at the wave's start, no
@@ -109,7 +109,7 @@ constexpr int kWave = 64;
 #endif
 #ifndef SPHMI_DIAG
 #define SPHMI_DIAG 0            // 1 / 2 / 4 / 5 / 8: diagnostic builds with WRONG results — gathers without arithmetic / arithmetic without gathers /
-                                // neither / adjacent lanes sharing a gathered record / adjacent lanes walking the union of their masks (§4.9)
+                                // neither / adjacent lanes sharing a gathered record (profiles/HISTORY.md §4.6) / adjacent lanes walking the union of their masks (§4.9)
                                 // 16 (round 6): the PRICE of an LDS record ring under the per-lane queues — the pair loop of the fp32 half-tile kernels of one wave per half
                                 // reads both packets of a neighbour with two ds_read_b128 from a ring in LDS, at the address its record index maps to, instead of gathering
                                 // them through the texture path.  SPHMI_RING_RECORDS (a power of two) records of 32 bytes per WAVE, or per four-wave BLOCK with
@@ -131,7 +131,7 @@ constexpr int kWave = 64;
                                 // records (32-byte stride: eight)
 #endif
 
-// Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles
+// Queue depth of the per-lane queues of non-empty 32-candidate accept masks.  A simulation of the queues on real tiles (profiles/HISTORY.md §4.4)
 // and the loop counters of the kernel agree: with 8 entries drained by 4 (round 1) the lanes of a wave are busy in 70–72 % of the
 // pair-loop iterations (the bound set by the lane with the most neighbours is 88 %); 8 drained by 1: 75 %; 10: 82 %; 12: 87 %; 16: 88 %.
 // LDS pays for the depth — 160 KB per compute unit over the resident waves.  Measured at 1.06 M / 2.85 M particles (updates/s, fp32):
@@ -850,13 +850,13 @@ k_neighbor_force(const ForceParams<T> P) {
         }
     };
     // ---- the same pair for the fp32 kernels of the compiled-in models (ArtificialViscosity + LinearDensityDiffusion, kFoldKv2): round 5.
-    // Same terms as pair_core; what differs is how they are evaluated:
+    // Same terms as pair_core; what differs is how they are evaluated (profiles/HISTORY.md §4.9):
     //  * ONE reciprocal per pair: inv = 1/(ρ_b·(r²+η²)(ρ̄ₐ+ρ̄_b)) [corrector: ·ρⁿ_b as well]; 1/ρ_b, 1/((r²+η²)ρ̄) [and 1/ρⁿ_b] are inv times the
     //    other factors — two (three) transcendentals become multiplies, and the remaining two are issued back to back (sqrt_and_rcp);
     //  * the density-diffusion sum runs without its lane constant Kd_a (applied once after the loop);
     //  * Pressure! of a neighbour's ρ⁺ (corrector) as ρ⁷·(Cb/γ/ρ₀⁷) − Cb/γ: no scaling multiply;
     //  (packed fp32 for the head of the pair and the accumulators — 47 instead of 56 vector instructions — was built and measured 1.3 % slower: on gfx950 v_fma_f32 runs at
-    //  the double rate and v_pk_* at the full rate; profiles/r05_retired_switches.patch)
+    //  the double rate and v_pk_* at the full rate; profiles/r05_retired_switches.patch, profiles/HISTORY.md §4.9)
     constexpr bool kFast = kFoldKv2 && MODEL >= 0 && ((MODEL >> 4) & 15) == kDdtLinear && SPHMI_FAST_PAIR != 0;
     constexpr bool kFastDiag = SPHMI_DIAG == 0 || SPHMI_DIAG == 2 || SPHMI_DIAG == 5 || SPHMI_DIAG == 8 || SPHMI_DIAG == 16;      // (the diagnostic builds that keep the arithmetic)
     [[maybe_unused]] auto pair_fast = [&](const V4& n0, const V4& n1, const bool a_is_i) {
@@ -1003,7 +1003,7 @@ k_neighbor_force(const ForceParams<T> P) {
     };
     // The pair loop software-pipelined by ONE address: the queue refill (LDS read), the bit walk and the record offset of the NEXT
     // neighbour are worked out while the two gathers of the current one are in flight (no further load in flight, one more
-    // register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links (1.0673 → 1.0999e9
+    // register) — the chain LDS → v_ffbl → offset → gather → arithmetic loses its first three links (profiles/HISTORY.md §4.6: 1.0673 → 1.0999e9
     // updates/s at C3).  (pv, pjr) = the pair this lane takes NEXT (valid flag, record offset); the state survives between the
     // bursts of the pair loop like the queue itself.
     // fp64 kernels: in the kernels of two waves per tile only.  Measured (µs per step, compiled-in / run-time models): 158 k
@@ -1043,7 +1043,7 @@ k_neighbor_force(const ForceParams<T> P) {
             } else
 #if SPHMI_DIAG == 5
             // DIAGNOSTIC BUILD (wrong results): every odd lane gathers the record its even neighbour gathers — what the texture path
-            // charges when the two lanes of a pair address the same 32 bytes (the lane-pair design of DESIGN §4.6)
+            // charges when the two lanes of a pair address the same 32 bytes (the lane-pair design of profiles/HISTORY.md §4.6)
             if (v) { const unsigned js = (unsigned)__builtin_amdgcn_mov_dpp((int)jr, 0xA0, 0xF, 0xF, true);      // quad_perm [0, 0, 2, 2]
                      n0 = gather_packet(rs0, js, 0, T()); n1 = gather_packet(rs0, js, 1, T()); }
 #elif SPHMI_DIAG == 2 || SPHMI_DIAG == 4
@@ -1392,7 +1392,7 @@ k_neighbor_force(const ForceParams<T> P) {
 #endif
 #if SPHMI_LDS_STAGE
             {
-                // Chunk-synchronous LDS staging (the design BASELINE config 3 names; DESIGN.md §4.4 and profiles/r03_lds_stage_ablation.md
+                // Chunk-synchronous LDS staging (the design BASELINE config 3 names; profiles/HISTORY.md §4.4 and profiles/r03_lds_stage_ablation.md
                 // for why it is not what ships): every lane loads the record of ONE candidate, coalesced, and parks it in LDS; then
                 // the wave walks the accept masks of THIS chunk — a lane reads its neighbour's two packets with two ds_read_b128 —
                 // until the lane with the most accepted candidates in the chunk is done; lanes with fewer idle.  No mask queues.
@@ -1426,7 +1426,7 @@ k_neighbor_force(const ForceParams<T> P) {
             if constexpr (kInterleave && SPHMI_BALANCE != 0) {
                 // Who takes which share.  The two lanes of a target get the candidates 8g + k and 8g + 4 + k of a chunk — a random half each, and a wave runs as many
                 // pair iterations as its fullest LANE needs: 79.8 per half tile at rest with 85 % of the lane slots busy, where two equal halves would need 72.5
-                // (tools/half_tile_balance_sim.py).  Every idle slot is texture-path time, so per chunk the lane that is BEHIND takes the larger of the two
+                // (tools/half_tile_balance_sim.py).  Every idle slot is texture-path time (profiles/HISTORY.md §4.9), so per chunk the lane that is BEHIND takes the larger of the two
                 // words: whole words change hands (a 128-byte line stays with one lane, one queue entry per lane and chunk as before), the running difference `bal` =
                 // pairs of the lower lane − pairs of the upper lane is kept identically on both.  Simulated: 74.5 iterations, 91 %.
                 unsigned wl = (unsigned)m, wu = (unsigned)m;

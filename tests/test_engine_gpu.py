@@ -738,7 +738,7 @@ def test_download_begin_advance_end_hands_out_the_snapshot(dam_break_2d, pinned)
     """The contract of sphmi_download_begin / _end with BOTH kinds of destination: arrays the caller page-locked
     (sphmi_host_register) are written by the copy engine while the run goes on, any other array is filled from the device-side
     snapshot inside sphmi_download_end through the handle's bounce buffer (the library hands no pageable pointer to the
-    runtime).  Either way the arrays hold the state of the moment of `begin`, whatever was advanced in between —
+    runtime, profiles/HISTORY.md §4.6).  Either way the arrays hold the state of the moment of `begin`, whatever was advanced in between —
     and a second begin without an end delivers the first snapshot first."""
     from sphexample_amd.engine import make_engine
     p, s = dam_break_2d
@@ -1058,7 +1058,7 @@ def test_a_particle_leaving_the_sticky_grid_sends_the_rebuild_to_the_host(dims, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wpt", ["2", "4", "8"])
 def test_half_tiles_with_several_waves_per_half_on_crowds(wpt, dam_break_3d_shipped, dam_break_2d_mdbc, monkeypatch):
-    """Every kernel of two, four or eight waves per tile serves half tiles (32 targets, two lanes each); with four / eight
+    """Every kernel of two, four or eight waves per tile serves half tiles (32 targets, two lanes each; profiles/HISTORY.md §4.8); with four / eight
     waves the two / four waves of a half deal its chunks alternately and hand their sums to the first through LDS.  Each is forced
     here on crowds whose rows hold dozens of chunks (so that every wave of a half gets several, and the queues drain in bursts) and
     over K steps of a dense and of a sparse layout (Dambreak3d Dp0.02; Dambreak2dMDBC, four particles per cell), against the oracle."""
@@ -1102,7 +1102,7 @@ def test_half_tiles_with_several_waves_per_half_on_crowds(wpt, dam_break_3d_ship
 @pytest.mark.parametrize("wpt", ["2", "4", "8"])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 64, 65, 97, 130, 1000])
 def test_half_tiles_on_ragged_sizes(n, wpt, monkeypatch):
-    """Half tiles of 32 targets with two lanes per target, one, two or four waves per half: forced here on particle counts
+    """Half tiles of 32 targets with two lanes per target (profiles/HISTORY.md §4.8), one, two or four waves per half: forced here on particle counts
     whose last tile leaves the waves of the second half with no target, one target, or a partial set, in 2-D and 3-D, fp32 and fp64 —
     forces of one evaluation and the state after three steps against the oracle."""
     from test_oracle import default_2d_setup

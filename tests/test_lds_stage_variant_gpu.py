@@ -1,5 +1,5 @@
 """BASELINE config 3 names "LDS cell-tile staging on".  The shipped kernel gathers its neighbours from L1 through per-lane queues
-of accept masks instead (0.506 against 1.025 ms per launch); the staging design is kept as an ABLATION build of the
+of accept masks instead (profiles/HISTORY.md §4.5: 0.506 against 1.025 ms per launch); the staging design is kept as an ABLATION build of the
 same kernel source, `-DSPHMI_LDS_STAGE=1` (sphmi_kernels.h), which `__graft_entry__.build()` compiles into
 build/variants/libsphmi_ldsstage.so.  These tests hold that build to the same parity bar as the shipped library — the measurement
 in profiles/r03_lds_stage_ablation.md compares two CORRECT kernels."""

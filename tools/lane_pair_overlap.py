@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How many neighbours do two ADJACENT particles of the sorted order share?  (The lane-pair design of DESIGN §4.6 / VERDICT round 3,
+"""How many neighbours do two ADJACENT particles of the sorted order share?  (The lane-pair design of profiles/HISTORY.md §4.6 / VERDICT round 3,
 next-5: two targets per lane, one gather and one bit walk per record of the UNION of their neighbour sets, two pair evaluations per
 record.)  Adjacent = rows 2k, 2k+1 of the cell-sorted order.  Two orders: the lattice's own (file order inside a cell: the dam break at
 rest) and a random order inside every cell (the developed flow: the in-cell order is the history of a few hundred stable sorts).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Queue simulation behind the depth of the per-lane mask queues of k_neighbor_force.  CPU only.
+"""Queue simulation behind the depth of the per-lane mask queues of k_neighbor_force (profiles/HISTORY.md §4.4).  CPU only.
 
 For a sample of tiles of the generated 3-D dam break (dp = 0.0085) it rebuilds what phase 1 pushes — per lane, the bit
 counts of the non-empty 32-candidate accept masks, in scan order — and replays the kernel's policy (scan until a queue

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Re-takes the measurements behind DESIGN.md §4.5 / §4.6 and profiles/r03_* in two stages.
+# Re-takes the measurements behind profiles/HISTORY.md §4.5 / §4.6 and profiles/r03_* in two stages.
 #
 #   stage 1 (HERE, no GPU: hipcc cross-compiles):   tools/reproduce_round3.sh build
 #   stage 2 (on an MI355X box, e.g. through gpurun): tools/reproduce_round3.sh run [what ...]

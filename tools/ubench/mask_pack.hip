@@ -1,4 +1,4 @@
-// Feasibility probe for DESIGN §8's phase-1 design: the sign bits of a 32×32 accumulator block gathered ON THE MATRIX PIPE.
+// Feasibility probe for the phase-1 design of profiles/HISTORY.md §8: the sign bits of a 32×32 accumulator block gathered ON THE MATRIX PIPE.
 //  (1) `v_cvt_pknorm_u16_f32 dst, -a, -b` on values pre-scaled so that every non-zero magnitude is ≥ 1: each half is exactly
 //      0x0000 or 0xffff (0xffff iff the input is negative; ±0, +inf and NaN give 0).  (`v_cvt_pkrtz_f16_f32 … clamp` assembles
 //      but the clamp is IGNORED by the hardware: the halves come out as ±65504 — first version of this probe.)

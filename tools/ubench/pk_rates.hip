@@ -36,7 +36,7 @@ DEFK(k_head_scalar, 12, "v_sub_f32 %0,%0,%1\n v_sub_f32 %1,%1,%2\n v_mul_f32 %2,
 DEFK(k_head_packed, 9,  "v_pk_add_f32 %4,%4,%5 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %5,%5,%6 neg_lo:[0,1] neg_hi:[0,1]\n v_sub_f32 %0,%0,%1\n v_pk_mul_f32 %6,%4,%4\n v_pk_mul_f32 %7,%4,%5\n"
                         "v_sub_f32 %1,%1,%2\n v_add_f32 %2,%2,%3\n v_add_f32 %3,%3,%0\n v_pk_fma_f32 %7,%4,%4,%6 op_sel_hi:[0,1,1]")
 
-// the other instruction kinds of the pair loop and of phase 1 (re-measured on this hardware: DESIGN §4.3's table had v_fma at 4.4)
+// the other instruction kinds of the pair loop and of phase 1 (re-measured on this hardware: profiles/HISTORY.md §4.3's table had v_fma at 4.4)
 #define DEFI(NAME, NI, BODY)                                                                              \
     __global__ void __launch_bounds__(64) NAME(float* sink) {                                             \
         float a = threadIdx.x * 0.5f + 1.f, b = 1.0001f, c = 0.3f, d = 0.7f;                              \
