@@ -259,6 +259,10 @@ struct Engine final : EngineBase {
     // measured (both with the order from measured work): 108 tiles 4 > 2 > 1; 2481 … 6344 tiles 2 > 1 (+6 … +2 %);
     // 10512 tiles 2 = 1; 14032 / 16528 / 24676 tiles 1 > 2 (+3 / +5 / +7 %)
     // cost classes of the tile order (sphmi_rebuild.h): fine where the launch fits the chip at once, coarse where it does not
+    // the end of every XCD run ordered again by sixteen classes of its own cost range (k_tile_order, `tail_permille`): launches of several rounds of the wave
+    // slots only — where the launch fits the chip at once every tile starts at t = 0 and the classes are fine already.  $SPHMI_TAIL_SORT = per mille (0: off)
+    int tail_sort = 200;
+    int tail_sort_permille(int ntile) const { return ntile < classes_fine_below ? 0 : tail_sort; }
     int tile_classes(int ntile) const { return ntile < classes_fine_below ? SPHMI_TILE_CLASSES_ONE_ROUND : SPHMI_TILE_CLASSES; }
     // waves per tile by tile count (measured with the paired two-wave launches and sixteen classes, updates/s WPT 2 / WPT 1:
     // 2 481 tiles 8.03 / 7.16e8, 3 454: 8.47 / 8.22, 5 050: 9.19 / 9.02, 6 985: 9.62 / 9.80, 9 428: 9.76e8 / 1.022e9,
@@ -318,6 +322,7 @@ struct Engine final : EngineBase {
         HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         if (const char* w = getenv("SPHMI_WPT")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) force_wpt = v; }
         if (const char* w = getenv("SPHMI_EDGE_WPT_JOINT")) edge_wpt_joint = atoi(w) != 0;
+        if (const char* w = getenv("SPHMI_TAIL_SORT")) { const int v = atoi(w); if (v >= 0 && v <= 1000) tail_sort = v; }
         if (const char* w = getenv("SPHMI_XCD_FEEDBACK")) xcd_feedback = atoi(w);
         xcd_trace = getenv("SPHMI_XCD_TRACE") != nullptr;          // one line per sampled launch on stderr: finishing time of each XCD ÷ mean, shares
         if (const char* w = getenv("SPHMI_TPB")) { const int v = atoi(w); if (v == 1 || v == 2 || v == 4) tpb = v; }
@@ -811,7 +816,7 @@ struct Engine final : EngineBase {
                 // (with the measured re-schedule the shares belong to IT: the estimate-based order lives for one step)
                 for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(l == 0 && !resched ? xcd_w[x] : 0.125);
                 W.cum[8] = 1.0f;
-                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W, 0, tile_classes(ntile));
+                hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, tile_cost[l], tile_scan, ntile, tile_order[l], part_d + 16 * l, nseg, W, 0, tile_classes(ntile), tail_sort_permille(ntile), 16);
             }
             HC(hipGetLastError());
             HC(hipMemcpyAsync(part_h, part_d, 32 * 4, hipMemcpyDeviceToHost, stream));
@@ -939,7 +944,7 @@ struct Engine final : EngineBase {
         XcdShares W{};
         for (int x = 0; x < 8; ++x) W.cum[x + 1] = W.cum[x] + (float)(list == 0 ? xcd_w[x] : 0.125);
         W.cum[8] = 1.0f;
-        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, work, tile_scan, ntile, tile_order[list], part_d + 16 * list, nseg, W, 1, tile_classes(ntile));
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, stream, work, tile_scan, ntile, tile_order[list], part_d + 16 * list, nseg, W, 1, tile_classes(ntile), tail_sort_permille(ntile), 16);
         HC(hipGetLastError());
         // the grid of the following launches needs the longest run: one short host round trip per rebuild interval
         // (≈30 µs every ≈40 steps); a sample whose step was cancelled left the table as it was

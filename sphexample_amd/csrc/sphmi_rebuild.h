@@ -330,8 +330,12 @@ __global__ void __launch_bounds__(256) k_tile_cost(const int* key, const int* cs
 // by cost tripled the HBM fetch of the neighbour kernel).
 // cost: this list's tile costs (0 = tile not in the list); cscan: their exclusive scan, ntile + 1 entries
 struct XcdShares { float cum[9]; };      // cumulative share of the estimated cost per XCD: cum[0] = 0 … cum[8] = 1
+// `tail_permille` > 0 (round 6): the LAST tail_permille / 1000 of a run are ordered again, by `tail_classes` cost classes of THEIR cost range, most expensive first.
+// A launch ends when its last wave does: with four coarse classes the last tiles an XCD starts still include tiles of 40–70 µs, and the run's slots empty while
+// they finish (tools/trace_tiles.py: the last 10 % of a C3 launch hold 43 % of the resident waves of the rest).  Sorting the end of the run puts the short tiles
+// last; the tail of a run is the only place where that costs no locality worth having (list-scheduling simulation on the traced lifetimes: −1.5 … −3.4 % per XCD run).
 __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int* cscan, int ntile, int* order,
-                                                     int* part, int nseg, XcdShares W, int keep_if_empty, int nclass) {
+                                                     int* part, int nseg, XcdShares W, int keep_if_empty, int nclass, int tail_permille = 0, int tail_classes = 16) {
     // nseg contiguous segments per XCD, dealt round-robin (segment s of 8·nseg equal-cost segments goes to XCD s % 8):
     // with nseg = 1 an XCD's run is one stretch of the domain, and a stretch of interior fluid has no cheap tiles to
     // end its launch with.  The XCD's tiles are written to order[x·ntile …].
@@ -396,6 +400,39 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int* cost, const int*
         }
     }
     if (threadIdx.x == 0) { part[x] = out0; part[8 + x] = s_off - out0; }    // run start in order[], tiles in the run
+    // ---- the end of the run once more, finer ------------------------------------------------------------------------------------------
+    __shared__ int s_tail[2048], s_tcls[2048], s_tmin, s_tmax;
+    __syncthreads();
+    const int nrun = s_off - out0;
+    int nt = tail_permille > 0 ? (int)((long long)nrun * tail_permille / 1000) : 0;
+    nt = min(nt, 2048);
+    if (nt < 64 || tail_classes < 2) return;
+    const int tb = out0 + nrun - nt;
+    if (threadIdx.x == 0) { s_tmin = INT32_MAX; s_tmax = INT32_MIN; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += 1024) {
+        const int t = order[tb + k]; const int c = cost[t];
+        s_tail[k] = t; s_tcls[k] = c;
+        atomicMin(&s_tmin, c); atomicMax(&s_tmax, c);
+    }
+    __syncthreads();
+    const int tmin = s_tmin;
+    const float tscale = s_tmax > tmin ? (float)tail_classes / (float)(s_tmax - tmin + 1) : 0.f;
+    for (int k = threadIdx.x; k < nt; k += 1024) s_tcls[k] = tail_classes - 1 - min(tail_classes - 1, (int)((float)(s_tcls[k] - tmin) * tscale));
+    __syncthreads();
+    // stable counting sort by class: one thread per class walks the ≤ 2 048 entries (sixteen classes, a few µs once per rebuild)
+    __shared__ int s_cnt[64];
+    if ((int)threadIdx.x < tail_classes && threadIdx.x < 64) {
+        int n = 0;
+        for (int k = 0; k < nt; ++k) n += s_tcls[k] == (int)threadIdx.x ? 1 : 0;
+        s_cnt[threadIdx.x] = n;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tail_classes && threadIdx.x < 64) {
+        int off = 0;
+        for (int q = 0; q < (int)threadIdx.x; ++q) off += s_cnt[q];
+        for (int k = 0; k < nt; ++k) if (s_tcls[k] == (int)threadIdx.x) order[tb + off++] = s_tail[k];
+    }
 }
 
 // The tile schedule of a SMALL handle (≤ kSmallMaxTiles tiles, no slab) in ONE launch: k_tile_cost + the three scan launches +

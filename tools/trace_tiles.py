@@ -22,6 +22,8 @@ raw = np.fromfile(fn, dtype=np.uint64); raw = raw[: 4 * (len(raw) // 36)].reshap
 raw = raw[raw[:, 1] > 0]
 xcd = (raw[:, 1] >> np.uint64(60)).astype(np.int64)                 # the block's XCD rides in the top bits of the end clock
 t = np.stack([raw[:, 0], raw[:, 1] & np.uint64((1 << 60) - 1)], axis=1).astype(np.int64)
+if os.environ.get("SPHMI_TRACE_DUMP"):                       # the raw table for off-line schedule simulations (tools/tail_sim.py)
+    np.savez(os.environ["SPHMI_TRACE_DUMP"], start=t[:, 0], end=t[:, 1], xcd=xcd)
 t0, t1 = t[:, 0].min(), t[:, 1].max()
 span = t1 - t0
 print(f"tiles {len(t)}  span {span} ticks (100 MHz: {span / 100:.1f} us)  mean tile life {np.mean(t[:, 1] - t[:, 0]) / 100:.1f} us")
