@@ -1707,7 +1707,7 @@ static_assert(SPHMI_ABI_VERSION == 5, "update the text of sphmi_backend_info");
 const char* sphmi_backend_info(void) {
     return "sphmi abi 5 | HIP gfx950 (CDNA4, wave64) | kernels: neighbor_force<fp32|fp64, 2D|3D>, "
            "counting-sort cell list, mDBC, moving bodies, shifting | multi-device handles: slabs over device copies / RCCL "
-           "(RCCL transport not yet run with more than one rank) | no CPU fallback";
+           "(the real RCCL has run with one rank only; the RCCL branch with 2-4 ranks through a checking double) | no CPU fallback";
 }
 
 const char* sphmi_last_error(const sphmi_handle* h) {
