@@ -249,6 +249,12 @@ struct Engine final : EngineBase {
     // XCD shares of the estimated tile cost, moved towards equal finishing times: one corrector launch per rebuild
     // interval records when each XCD ran out of tiles ($SPHMI_XCD_FEEDBACK=0 switches it off)
     int xcd_feedback = 1; bool xcd_sampled = false;
+    // Round 6: the XCD-share feedback is for launches of a round or two of the wave slots.  Re-measured on the current kernels ($SPHMI_XCD_FEEDBACK=0/1 side by side,
+    // profiles/r06_raw/xcd_feedback_*.txt): from 7 339 tiles up equal shares are FASTER — C3 bench +2.4 % over four interleaved pairs, developed flow +1.5 %, the
+    // 470 k-particle instantiations −0.5 … −6.5 % per step — the finishing times it equalises are set by the tails of the runs, not by their work, and moving work to
+    // match them lengthens the launch; below that (159 k particles and less) the two are level, with single instantiations ±2 … 4 % either way.  $SPHMI_XCD_FEEDBACK=2: every size.
+    int xcd_feedback_max_tiles = 5000;
+    bool xcd_feedback_for(int ntile) const { return xcd_feedback == 2 || (xcd_feedback == 1 && ntile < xcd_feedback_max_tiles); }
     // after a rebuild: 1 = the next eligible corrector launch measures the work of every tile and the schedule of the rest
     // of the interval is rebuilt from it; 2 = the one after that records the XCD finishing times; 0 = nothing pending
     int sched_state = 0; int resched = 1; int* tile_work_d = nullptr;
@@ -590,8 +596,8 @@ struct Engine final : EngineBase {
                 HC(hipMemsetAsync(tile_work_d, 0, (size_t)((N + kWave - 1) / kWave) * 4, stream));
                 P.tile_work = tile_work_d;
                 resched_after = true;
-                sched_state = xcd_feedback ? 2 : 0;
-            } else if (xcd_feedback) {
+                sched_state = xcd_feedback_for(ntile) ? 2 : 0;
+            } else if (xcd_feedback_for(ntile)) {
                 for (int k = 0; k < 8; ++k) xcd_clock_h[16 + k] = 0ull;
                 for (int k = 8; k < 16; ++k) xcd_clock_h[16 + k] = ~0ull;
                 HC(hipMemcpyAsync(xcd_clock_d, xcd_clock_h + 16, 16 * 8, hipMemcpyHostToDevice, stream));
