@@ -34,6 +34,8 @@ def test_random_call_sequences_keep_slabs_and_one_device_together(seed, request)
     p, s = request.getfixturevalue(case)
     one = make_engine(p, s, device_float_bytes=8)
     dd = make_engine(p, s, device_float_bytes=8, devices=[0] * world)
+    if os.environ.get("SPHMI_EXPECT_TRANSPORT"):               # (test_the_same_sequences_over_the_rccl_branch below: the slabs must really talk through it)
+        assert dd.multi_info().transport == int(os.environ["SPHMI_EXPECT_TRANSPORT"])
     log = [f"{case} x{world}"]
     perm_one = perm_dd = None
     for step in range(10):
@@ -77,3 +79,24 @@ def test_random_call_sequences_keep_slabs_and_one_device_together(seed, request)
         assert (pa.iteration, pa.steps_done, pa.n_rebuilds, pa.index_counter) == (pb.iteration, pb.steps_done, pb.n_rebuilds, pb.index_counter), what
         assert pa.total_time == pytest.approx(pb.total_time, rel=1e-12) and pa.last_dt == pytest.approx(pb.last_dt, rel=1e-12), what
         _same(one, dd, what)
+
+
+def test_the_same_sequences_over_the_rccl_branch():
+    """The sequences once more with the slabs of the handle talking through the RCCL branch (ncclCommInitAll, grouped ncclSend / ncclRecv, the per-step
+    allreduce) — behind the checking double of tests/mock_rccl/, which turns a send without its receive, a size mismatch or an open group into an error:
+    a second upload, forces_once between two intervals and the rest must leave both ends of every exchange in step.  A subprocess: the library binds
+    its RCCL once per process."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "mock_rccl"))
+    try:
+        import build as mock_build
+        mock = mock_build.build()
+    finally:
+        sys.path.remove(os.path.join(here, "mock_rccl"))
+    env = dict(os.environ, SPHMI_TRANSPORT="rccl", SPHMI_RCCL_LIB=mock, SPHMI_EXPECT_TRANSPORT="1", SPHMI_SEQ_SEED0=str(SEED0 + 5000), MOCK_RCCL_TIMEOUT="60")
+    pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "random_call_sequences"],
+                        env=env, capture_output=True, text=True, timeout=1200)
+    assert pr.returncode == 0, pr.stdout[-3000:] + pr.stderr[-2000:]
+    assert "12 passed" in pr.stdout and "VIOLATION" not in pr.stderr
