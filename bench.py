@@ -62,7 +62,7 @@ BYTES_PER_UPDATE_3D_FP32 = (11 * 3 + 5) * 4 + 2      # 154 B, SURVEY.md §8d
 # quad-cycle per instruction instead (measured issue cost of most of this kernel's instructions: tools/ubench/valu_rates2.hip).
 SHADER_CLOCK_HZ, N_CU = 2.4e9, 256
 VALU_ISSUE_PEAK = N_CU * 4 * SHADER_CLOCK_HZ / 2.0
-COUNTER_RECORD = "profiles/r05_counters.json"
+COUNTER_RECORD = "profiles/r06_counters.json"
 DP1 = 0.00425
 BENCH_KERNELS = {"predictor": "k_neighbor_force<float, 3, 1, 33, 2, 2>", "corrector": "k_neighbor_force<float, 3, 2, 33, 2, 2>"}
 
