@@ -1463,7 +1463,9 @@ k_neighbor_force(const ForceParams<T> P) {
         if (MODEL < 0 && P.kout) { kgx = both(kgx); kgy = both(kgy); kgz = both(kgz); kw = both(kw); }
     }
 #if SPHMI_DIAG != 0
-    { const T z = (T)P.exact_cut; drho *= z; ax *= z; ay *= z; az *= z; }      // (0 at run time for the compiled-in model: the state stays sane, the loop stays alive)
+    // (P.exact_cut is 0 at run time for the compiled-in model: the state stays sane — a select, not a multiply: a diagnostic loop may have produced NaN — and the
+    // loop stays alive: the compiler cannot know)
+    { const bool keep = P.exact_cut != 0; drho = keep ? drho : T(0); ax = keep ? ax : T(0); ay = keep ? ay : T(0); az = keep ? az : T(0); }
 #endif
     // measured work of this tile (a pair-loop iteration ≈ 270, a chunk ≈ 475 vector-ALU cycles): the schedule of the rest
     // of the rebuild interval is rebuilt from it (Engine::reschedule)
