@@ -18,8 +18,14 @@
 //   * every wait has a deadline ($MOCK_RCCL_TIMEOUT seconds, default 60): the failing call returns ncclSystemError and
 //     ncclGetLastError says which operation of which rank was waiting for which peer.
 // A violation poisons the segment: every rank's next call fails with the first violation's text instead of waiting.
-// Semantics are STRONGER than RCCL's in one respect: an operation has completed when the call (or the closing ncclGroupEnd)
-// returns, so stream-ordering mistakes of the caller stay hidden here; message-list mistakes do not.
+// Default mode: an operation has completed when the call (or the closing ncclGroupEnd) returns — STRONGER than RCCL, so stream-ordering
+// mistakes of the caller stay hidden; message-list mistakes do not.
+// $MOCK_RCCL_ASYNC=1: RCCL's own timing.  The call only records an event on the stream it names and queues a wait on a signal word
+// (hipStreamWaitValue32) behind it; a proxy thread waits for the event — everything the caller queued BEFORE the call — reads the send
+// buffers THEN, moves the bytes, writes the receive buffers and releases the signal: the caller's later work on that stream sees the
+// data, work it queued on OTHER streams without an event does not wait.  A send buffer refilled too early, a receive buffer read
+// without waiting for its stream: both become wrong bytes that the parity comparison of the tests sees.  (A wait parks a hardware
+// queue: run with GPU_MAX_HW_QUEUES=8 so that the proxy's copies do not share one with a parked stream.)
 //
 // Build: hipcc (host code only) -shared -fPIC mock_rccl.cpp -o libmockrccl.so     (tests/mock_rccl/build.py)
 
@@ -31,6 +37,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -107,6 +115,8 @@ struct Comm {
     uint64_t n_sent[kMaxWorld] = {}, n_recvd[kMaxWorld] = {};
     std::string last_error;
     bool dead = false;
+    std::atomic<int> async_error{0};                    // MOCK_RCCL_ASYNC: the result of a batch that failed on the proxy thread; every later call returns it
+    std::atomic<uint64_t> queued{0}, retired{0};        // … batches of this communicator handed to / finished by the proxy
 };
 std::mutex g_comm_mu;
 std::set<Comm*> g_live;
@@ -280,11 +290,14 @@ bool step(Op& o, std::string& why) {
     return true;
 }
 
-ncclResult_t run_ops(std::vector<Op>& ops) {
-    if (ops.empty()) return ncclSuccess;
-    int dev0 = 0;
-    if (!host_mode()) (void)hipGetDevice(&dev0);
-    // every group that talks to a peer is one more epoch of that pair (collectives talk to everybody)
+bool async_mode() {
+    static bool a = [] { const char* e = getenv("MOCK_RCCL_ASYNC"); return e && atoi(e) != 0 && !host_mode(); }();
+    return a;
+}
+hipStream_t g_proxy_stream = nullptr;                   // the proxy thread's own stream (async mode)
+
+// prepare (caller thread): the bookkeeping that defines WHICH message / collective an operation is
+ncclResult_t prepare_ops(std::vector<Op>& ops) {
     {
         std::set<std::pair<Comm*, int>> touched;
         for (Op& o : ops) {
@@ -299,12 +312,6 @@ ncclResult_t run_ops(std::vector<Op>& ops) {
         if (poisoned(c, why)) { t_last_error = c->last_error = why; return ncclRemoteError; }
         op.bytes = op.count * dt_size(op.dt);
         op.host.resize(op.bytes ? op.bytes : 1);
-        if (host_mode()) { if (op.kind != RECV && op.bytes) memcpy(op.host.data(), op.sbuf, op.bytes); }
-        else {
-            HIPQ(hipSetDevice(c->device));
-            HIPQ(hipStreamSynchronize(op.stream));                  // stream order: everything queued before the call has run
-            if (op.kind != RECV && op.bytes) { HIPQ(hipMemcpyAsync(op.host.data(), op.sbuf, op.bytes, hipMemcpyDeviceToHost, op.stream)); HIPQ(hipStreamSynchronize(op.stream)); }
-        }
         if (op.kind == SEND) { op.index = c->n_sent[op.peer]++; op.epoch_tag = c->epoch[op.peer]; }
         if (op.kind == RECV) { op.index = c->n_recvd[op.peer]++; op.epoch_tag = c->epoch[op.peer]; }
         if (op.kind == ALLREDUCE) {
@@ -313,6 +320,31 @@ ncclResult_t run_ops(std::vector<Op>& ops) {
         }
         std::lock_guard<std::mutex> g(g_stats.mu);
         (op.kind == ALLREDUCE ? g_stats.coll_streams : g_stats.p2p_streams).insert((const void*)op.stream);
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t transfer_ops(std::vector<Op>& ops, bool on_proxy);
+
+ncclResult_t run_ops(std::vector<Op>& ops) {
+    if (ops.empty()) return ncclSuccess;
+    ncclResult_t rc = prepare_ops(ops);
+    if (rc != ncclSuccess) return rc;
+    return transfer_ops(ops, false);
+}
+
+// move the bytes: gather what is sent, run the channels, deliver what is received.  on_proxy: the caller's streams are not touched —
+// the events of the batch have been waited for, copies run on the proxy's stream.
+ncclResult_t transfer_ops(std::vector<Op>& ops, bool on_proxy) {
+    int dev0 = 0;
+    if (!host_mode()) (void)hipGetDevice(&dev0);
+    for (Op& op : ops) {
+        Comm* c = op.c;
+        if (host_mode()) { if (op.kind != RECV && op.bytes) memcpy(op.host.data(), op.sbuf, op.bytes); continue; }
+        HIPQ(hipSetDevice(c->device));
+        hipStream_t q = on_proxy ? g_proxy_stream : op.stream;
+        if (!on_proxy) HIPQ(hipStreamSynchronize(op.stream));       // stream order: everything queued before the call has run
+        if (op.kind != RECV && op.bytes) { HIPQ(hipMemcpyAsync(op.host.data(), op.sbuf, op.bytes, hipMemcpyDeviceToHost, q)); HIPQ(hipStreamSynchronize(q)); }
     }
     const auto t0 = Clock::now();
     size_t left = ops.size();
@@ -348,12 +380,92 @@ ncclResult_t run_ops(std::vector<Op>& ops) {
         if (!op.bytes) continue;
         if (host_mode()) { memcpy(op.rbuf, op.host.data(), op.bytes); continue; }
         HIPQ(hipSetDevice(op.c->device));
-        HIPQ(hipMemcpyAsync(op.rbuf, op.host.data(), op.bytes, hipMemcpyHostToDevice, op.stream));
-        HIPQ(hipStreamSynchronize(op.stream));
+        hipStream_t q = on_proxy ? g_proxy_stream : op.stream;
+        HIPQ(hipMemcpyAsync(op.rbuf, op.host.data(), op.bytes, hipMemcpyHostToDevice, q));
+        HIPQ(hipStreamSynchronize(q));
     }
     if (!host_mode()) (void)hipSetDevice(dev0);
     g_stats.groups += 1;
     return ncclSuccess;
+}
+
+// ---- MOCK_RCCL_ASYNC: the proxy ------------------------------------------------------------------------------------------------
+struct Wait { int device; void* signal; uint32_t value; };
+struct Batch { std::vector<Op> ops; std::vector<hipEvent_t> ready; std::vector<Wait> waits; };
+struct Proxy {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<std::unique_ptr<Batch>> q;
+    std::thread th; bool started = false, stop = false;
+    struct Slot { void* p = nullptr; uint32_t next = 0; };
+    std::vector<Slot> slots; size_t rr = 0;
+    ~Proxy() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+    void run() {
+        for (;;) {
+            std::unique_ptr<Batch> b;
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || !q.empty(); }); if (q.empty()) return; b = std::move(q.front()); q.pop_front(); }
+            ncclResult_t rc = ncclSuccess;
+            for (size_t k = 0; k < b->ops.size(); ++k) {             // everything the caller queued before the call has run
+                (void)hipSetDevice(b->ops[k].c->device);
+                if (hipEventSynchronize(b->ready[k]) != hipSuccess) rc = ncclUnhandledCudaError;
+                (void)hipEventDestroy(b->ready[k]);
+            }
+            if (rc == ncclSuccess) rc = transfer_ops(b->ops, true);
+            std::set<Comm*> comms;
+            for (Op& o : b->ops) comms.insert(o.c);
+            for (Comm* c : comms) { if (rc != ncclSuccess) { int z = 0; c->async_error.compare_exchange_strong(z, (int)rc); } }
+            // release the streams WHATEVER happened: a parked stream is a hung device
+            for (const Wait& w : b->waits) { (void)hipSetDevice(w.device); (void)hipStreamWriteValue32(g_proxy_stream, w.signal, w.value, 0); }
+            (void)hipStreamSynchronize(g_proxy_stream);
+            for (Comm* c : comms) c->retired.fetch_add(1, std::memory_order_release);
+        }
+    }
+    ncclResult_t submit(std::vector<Op>& ops) {
+        if (!started) {
+            if (hipStreamCreateWithFlags(&g_proxy_stream, hipStreamNonBlocking) != hipSuccess) return ncclUnhandledCudaError;
+            slots.resize(64);
+            th = std::thread([this] { run(); }); started = true;
+        }
+        for (Op& o : ops) { const int e = o.c->async_error.load(); if (e) { t_last_error = o.c->last_error; return (ncclResult_t)e; } }
+        ncclResult_t rc = prepare_ops(ops);
+        if (rc != ncclSuccess) return rc;
+        auto b = std::make_unique<Batch>();
+        std::set<std::pair<int, hipStream_t>> streams;
+        for (Op& o : ops) {
+            if (hipSetDevice(o.c->device) != hipSuccess) return ncclUnhandledCudaError;
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, o.stream) != hipSuccess) return ncclUnhandledCudaError;
+            b->ready.push_back(ev);
+            streams.insert({o.c->device, o.stream});
+        }
+        for (auto& ds : streams) {                                    // later work on the stream waits for the batch
+            Slot& sl = slots[rr++ % slots.size()];
+            (void)hipSetDevice(ds.first);
+            if (!sl.p && hipExtMallocWithFlags(&sl.p, 8, hipMallocSignalMemory) != hipSuccess) return ncclUnhandledCudaError;
+            const uint32_t v = ++sl.next;
+            if (hipStreamWaitValue32(ds.second, sl.p, v, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) return ncclUnhandledCudaError;
+            b->waits.push_back({ds.first, sl.p, v});
+        }
+        std::set<Comm*> comms;
+        for (Op& o : ops) comms.insert(o.c);
+        for (Comm* c : comms) c->queued.fetch_add(1);
+        b->ops = std::move(ops);
+        { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(b)); }
+        cv.notify_one();
+        return ncclSuccess;
+    }
+    void drain(Comm* c) {                                             // every batch of this communicator has left the proxy
+        const auto t0 = Clock::now();
+        while (c->retired.load(std::memory_order_acquire) < c->queued.load()) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (std::chrono::duration<double>(Clock::now() - t0).count() > 2 * timeout_s() + 5) break;
+        }
+    }
+} g_proxy;
+
+ncclResult_t dispatch(std::vector<Op>& ops) {
+    if (ops.empty()) return ncclSuccess;
+    if (async_mode()) { int dev0 = 0; (void)hipGetDevice(&dev0); const ncclResult_t rc = g_proxy.submit(ops); (void)hipSetDevice(dev0); return rc; }
+    return run_ops(ops);
 }
 
 ncclResult_t submit(Op&& op) {
@@ -367,7 +479,7 @@ ncclResult_t submit(Op&& op) {
     if (op.count && ((op.kind != RECV && !op.sbuf) || (op.kind != SEND && !op.rbuf))) return violation(op.c, ncclInvalidArgument, std::string(kind_name(op.kind)) + ": null buffer");
     if (t_depth > 0) { t_ops.push_back(std::move(op)); return ncclSuccess; }
     std::vector<Op> one; one.push_back(std::move(op));
-    return run_ops(one);
+    return dispatch(one);
 }
 
 Seg* attach(const ncclUniqueId* id, int world, int rank, std::shared_ptr<void>& keep, std::string& err) {
@@ -464,6 +576,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
         if (!g_live.count(c)) { g_stats.violations += 1; t_last_error = "[mock-rccl] VIOLATION: ncclCommDestroy of a communicator that is not alive"; fprintf(stderr, "%s\n", t_last_error.c_str()); return ncclInvalidArgument; }
     }
     ncclResult_t rc = ncclSuccess;
+    if (async_mode()) { g_proxy.drain(c); if (c->async_error.load()) rc = (ncclResult_t)c->async_error.load(); }
     if (t_depth) rc = violation(c, ncclInvalidUsage, "ncclCommDestroy inside an open ncclGroupStart");
     if (!c->seg->poisoned.load()) {
         for (int q = 0; q < c->world; ++q) {
@@ -485,7 +598,7 @@ ncclResult_t ncclGroupEnd() {
     if (t_depth <= 0) return violation(nullptr, ncclInvalidUsage, "ncclGroupEnd without ncclGroupStart");
     if (--t_depth > 0) return ncclSuccess;
     std::vector<Op> ops; ops.swap(t_ops);
-    return run_ops(ops);
+    return dispatch(ops);
 }
 
 ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {

@@ -128,6 +128,37 @@ def test_rccl_branch_rank_processes_match_one_device(mock_lib, case, world, step
         assert int(q["info"][6]) == (1 if exchange == "mailbox" else 0)
 
 
+ASYNC = {"MOCK_RCCL_ASYNC": "1", "GPU_MAX_HW_QUEUES": "24", "MOCK_RCCL_TIMEOUT": "60"}
+
+
+@pytest.mark.parametrize("case,world,steps,fb,tol,mode,exchange", [
+    ("dam_break_3d_shipped", 2, 40, 8, 1e-9, "run", "allreduce"),
+    ("dam_break_3d_shipped", 3, 40, 4, 1e-5, "run", "allreduce"),
+    ("dam_break_3d_shipped", 4, 30, 8, 1e-9, "run", "mailbox"),
+    ("moving_square", 2, 150, 8, 1e-9, "run", "allreduce"),
+    ("dam_break_2d_mdbc", 3, 40, 8, 1e-9, "run", "allreduce"),
+    ("dam_break_3d_shipped", 3, 40, 8, 1e-9, "run_slabs", "allreduce"),
+    ("dam_break_2d_mdbc", 2, 40, 8, 1e-9, "run_slabs", "allreduce")])
+def test_rccl_branch_under_rccl_timing(mock_lib, case, world, steps, fb, tol, mode, exchange, request, tmp_path):
+    """$MOCK_RCCL_ASYNC=1: the double keeps RCCL's own timing — a call only queues; a proxy thread reads the send buffers when the stream reaches the
+    call, writes the receive buffers, and releases the stream behind it.  A send buffer packed again too early, an unpack or an edge launch that does
+    not wait for the stream the receive was posted on, a control that reads the maxima before the allreduce has landed: each would be wrong BYTES here
+    (the default mode of the double completes every operation inside the call and cannot see them).  Same assertions as above."""
+    extra = dict(ASYNC, SPHMI_EXCHANGE=exchange, SPHMI_MBOX_TIMEOUT="30")
+    res = _spawn(mock_lib, world, lambda r: (case, steps, fb, str(tmp_path), 1, -1), mode=mode, extra_env=extra, timeout=300, n_procs=None if mode == "run" else 1)
+    for rc, o, e in res:
+        assert rc == 0, e[-3000:]
+        assert "VIOLATION" not in e
+    p, ref, progs = _reference(request, case, fb, steps, 1)
+    if mode == "run":
+        parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+        _check_union(parts, p, ref, progs, fb, tol, 1)
+    else:
+        parts = [np.load(tmp_path / "rank0.npz")]
+        _check_union(parts, p, ref, progs, fb, tol, world)
+    _check_mock(parts, world)
+
+
 def test_rccl_branch_with_one_communicator(mock_lib, request, tmp_path):
     """$SPHMI_RCCL_ONE_COMM=1: point-to-point traffic and the per-step allreduce on ONE communicator, called from two streams — legal only
     while every rank issues the calls in the same order, which is what the double's group-sequence check is about."""
