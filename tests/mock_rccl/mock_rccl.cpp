@@ -88,7 +88,7 @@ struct Seg {
 
 struct Stats {
     std::atomic<uint64_t> comms{0}, groups{0}, sends{0}, recvs{0}, send_bytes{0}, recv_bytes{0}, allreduces{0}, violations{0}, max_send{0},
-        open_comms{0}, timeouts{0};
+        open_comms{0}, timeouts{0}, proxied{0};
     std::mutex mu;
     std::set<const void*> p2p_streams, coll_streams;
 } g_stats;
@@ -129,6 +129,7 @@ struct Op {
     std::vector<char> host;
     // progress
     int stage = 0; size_t done_bytes = 0; uint64_t end_head = 0; bool finished = false; uint64_t coll_no = 0; uint64_t epoch_tag = 0; uint64_t index = 0;
+    std::vector<uint64_t> epochs;                           // ALLREDUCE: the group count with every peer when the call was made (the proxy runs later)
 };
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
@@ -261,7 +262,7 @@ bool step(Op& o, std::string& why) {
     RedSlot& mine = s->red[c->rank];
     if (o.stage == 0) {
         mine.count[par] = o.count; mine.dtype[par] = (uint64_t)o.dt; mine.op[par] = (uint64_t)o.rop;
-        for (int q = 0; q < kMaxWorld; ++q) mine.epoch[par][q] = c->epoch[q];
+        for (int q = 0; q < kMaxWorld; ++q) mine.epoch[par][q] = o.epochs[q];
         memcpy(mine.data[par], o.host.data(), o.bytes);
         mine.posted.store(o.coll_no, std::memory_order_release);
         o.stage = 1;
@@ -276,10 +277,10 @@ bool step(Op& o, std::string& why) {
                      (unsigned long long)o.coll_no, q, (unsigned long long)r.count[par], (unsigned long long)r.dtype[par], (unsigned long long)r.op[par], c->rank, o.count, (int)o.dt, (int)o.rop);
             why = b; return false;
         }
-        if (q != c->rank && r.epoch[par][c->rank] != c->epoch[q]) {
+        if (q != c->rank && r.epoch[par][c->rank] != o.epochs[q]) {
             char b[300];
             snprintf(b, sizeof b, "collective #%llu: rank %d has had %llu groups with rank %d on this communicator, rank %d has had %llu with rank %d: point-to-point and collective calls are interleaved differently on the two ranks",
-                     (unsigned long long)o.coll_no, q, (unsigned long long)r.epoch[par][c->rank], c->rank, c->rank, (unsigned long long)c->epoch[q], q);
+                     (unsigned long long)o.coll_no, q, (unsigned long long)r.epoch[par][c->rank], c->rank, c->rank, (unsigned long long)o.epochs[q], q);
             why = b; return false;
         }
         if (q == 0) memcpy(acc.data(), r.data[par], o.bytes);
@@ -294,6 +295,7 @@ bool async_mode() {
     static bool a = [] { const char* e = getenv("MOCK_RCCL_ASYNC"); return e && atoi(e) != 0 && !host_mode(); }();
     return a;
 }
+int async_delay_us() { static int d = [] { const char* e = getenv("MOCK_RCCL_ASYNC_DELAY_US"); return e ? atoi(e) : 0; }(); return d; }
 hipStream_t g_proxy_stream = nullptr;                   // the proxy thread's own stream (async mode)
 
 // prepare (caller thread): the bookkeeping that defines WHICH message / collective an operation is
@@ -317,6 +319,7 @@ ncclResult_t prepare_ops(std::vector<Op>& ops) {
         if (op.kind == ALLREDUCE) {
             if (op.bytes > kRedMax) return violation(c, ncclInvalidArgument, "ncclAllReduce of more than 256 KiB: the mock keeps collectives in one slot");
             op.coll_no = ++c->coll_seq;
+            op.epochs.assign(c->epoch, c->epoch + kMaxWorld);
         }
         std::lock_guard<std::mutex> g(g_stats.mu);
         (op.kind == ALLREDUCE ? g_stats.coll_streams : g_stats.p2p_streams).insert((const void*)op.stream);
@@ -404,11 +407,13 @@ struct Proxy {
             std::unique_ptr<Batch> b;
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || !q.empty(); }); if (q.empty()) return; b = std::move(q.front()); q.pop_front(); }
             ncclResult_t rc = ncclSuccess;
+            g_stats.proxied += 1;
             for (size_t k = 0; k < b->ops.size(); ++k) {             // everything the caller queued before the call has run
                 (void)hipSetDevice(b->ops[k].c->device);
                 if (hipEventSynchronize(b->ready[k]) != hipSuccess) rc = ncclUnhandledCudaError;
                 (void)hipEventDestroy(b->ready[k]);
             }
+            if (async_delay_us() > 0) std::this_thread::sleep_for(std::chrono::microseconds(async_delay_us()));   // RCCL's kernels are not instant either
             if (rc == ncclSuccess) rc = transfer_ops(b->ops, true);
             std::set<Comm*> comms;
             for (Op& o : b->ops) comms.insert(o.c);
@@ -440,7 +445,10 @@ struct Proxy {
         for (auto& ds : streams) {                                    // later work on the stream waits for the batch
             Slot& sl = slots[rr++ % slots.size()];
             (void)hipSetDevice(ds.first);
-            if (!sl.p && hipExtMallocWithFlags(&sl.p, 8, hipMallocSignalMemory) != hipSuccess) return ncclUnhandledCudaError;
+            if (!sl.p) {
+                if (hipExtMallocWithFlags(&sl.p, 8, hipMallocSignalMemory) != hipSuccess) return ncclUnhandledCudaError;
+                *(volatile uint64_t*)sl.p = 0;                       // signal memory comes uninitialised: a stale word ≥ 1 would let the first wait through
+            }
             const uint32_t v = ++sl.next;
             if (hipStreamWaitValue32(ds.second, sl.p, v, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) return ncclUnhandledCudaError;
             b->waits.push_back({ds.first, sl.p, v});
@@ -635,13 +643,14 @@ const char* ncclGetLastError(ncclComm_t comm) {
 // ---- what the tests read (not part of the RCCL surface) --------------------------------------------------------------
 // out[0] communicators made, [1] groups (or lone calls) completed, [2] sends, [3] receives, [4] bytes sent, [5] bytes received,
 // [6] allreduces, [7] violations, [8] distinct streams named by point-to-point calls, [9] by collectives, [10] longest send in bytes,
-// [11] communicators alive, [12] current group depth of the calling thread, [13] deadline expiries
+// [11] communicators alive, [12] current group depth of the calling thread, [13] deadline expiries, [14] batches the proxy thread ran
+// ($MOCK_RCCL_ASYNC=1; 0 in the default mode)
 int mockrccl_stats(uint64_t* out, int cap) {
-    uint64_t v[14] = {g_stats.comms, g_stats.groups, g_stats.sends, g_stats.recvs, g_stats.send_bytes, g_stats.recv_bytes, g_stats.allreduces, g_stats.violations, 0, 0,
-                      g_stats.max_send, g_stats.open_comms, (uint64_t)t_depth, g_stats.timeouts};
+    uint64_t v[15] = {g_stats.comms, g_stats.groups, g_stats.sends, g_stats.recvs, g_stats.send_bytes, g_stats.recv_bytes, g_stats.allreduces, g_stats.violations, 0, 0,
+                      g_stats.max_send, g_stats.open_comms, (uint64_t)t_depth, g_stats.timeouts, g_stats.proxied};
     { std::lock_guard<std::mutex> g(g_stats.mu); v[8] = g_stats.p2p_streams.size(); v[9] = g_stats.coll_streams.size(); }
-    for (int i = 0; i < cap && i < 14; ++i) out[i] = v[i];
-    return 14;
+    for (int i = 0; i < cap && i < 15; ++i) out[i] = v[i];
+    return 15;
 }
 const char* mockrccl_version(void) { return "mock-rccl 1 (tests/mock_rccl/mock_rccl.cpp): staged copies over POSIX shared memory, checked message lists"; }
 

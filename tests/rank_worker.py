@@ -58,7 +58,7 @@ def main():
         n_own = eng.owned_count() if mode == "run" else len(d["drhodt"])
         d["drhodt"], d["acc"] = d["drhodt"][:n_own], d["acc"][:n_own]
         d["ID_forces"] = eng.download(("ID",))["ID"]
-    mock = np.zeros(14, dtype=np.uint64)
+    mock = np.zeros(15, dtype=np.uint64)
     sub = os.environ.get("SPHMI_RCCL_LIB")
     if sub:
         # the substitute library's own counters AFTER the handle is gone (ncclCommDestroy checks for unreceived messages and open groups):
@@ -67,8 +67,8 @@ def main():
         m = C.CDLL(sub)
         if hasattr(m, "mockrccl_stats"):
             m.mockrccl_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-            v = (C.c_uint64 * 14)()
-            m.mockrccl_stats(v, 14)
+            v = (C.c_uint64 * 15)()
+            m.mockrccl_stats(v, 15)
             mock = np.array(list(v), dtype=np.uint64)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), prog=np.array(prog, dtype=np.float64), info=info, mock=mock, **d)
 

@@ -89,10 +89,11 @@ def _check_union(parts, p, ref, progs, fb, tol, n_local):
     assert np.abs(got["Position"] - r["Position"]).max() / np.abs(r["Position"]).max() < tol
 
 
-def _check_mock(parts, world, two_comms=True, overlapped=True):
+def _check_mock(parts, world, two_comms=True, overlapped=True, proxied=False):
     for rank, q in enumerate(parts):
         m = [int(x) for x in q["mock"]]
-        comms, groups, sends, recvs, sbytes, rbytes, allred, viol, p2p_streams, coll_streams, _, alive, depth, late = m
+        comms, groups, sends, recvs, sbytes, rbytes, allred, viol, p2p_streams, coll_streams, _, alive, depth, late, by_proxy = m
+        assert (by_proxy == groups and groups > 0) if proxied else by_proxy == 0, m
         assert viol == 0 and late == 0 and alive == 0 and depth == 0, m
         assert comms == (2 if two_comms else 1) * (1 if len(parts) > 1 else world), m
         assert sends > 0 and recvs > 0 and sbytes > 0 and rbytes > 0 and allred > 0, m
@@ -156,7 +157,26 @@ def test_rccl_branch_under_rccl_timing(mock_lib, case, world, steps, fb, tol, mo
     else:
         parts = [np.load(tmp_path / "rank0.npz")]
         _check_union(parts, p, ref, progs, fb, tol, world)
-    _check_mock(parts, world)
+    _check_mock(parts, world, proxied=True)
+
+
+def test_double_sees_stream_order_mistakes(mock_lib):
+    """What the asynchronous mode is for, shown on two deliberate mistakes (tests/mock_rccl/stream_order_probe.py): a consumer stream that reads the
+    receive buffer without waiting for the stream the receive was posted on, and a send buffer overwritten right after the call.  The default mode
+    completes every operation inside the call and sees neither; under $MOCK_RCCL_ASYNC=1 both deliver wrong bytes, and the ordered caller stays right."""
+    import json
+    rounds = 8
+    seen = {}
+    for name, extra in (("default", {}), ("async", dict(ASYNC, MOCK_RCCL_ASYNC_DELAY_US="3000"))):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "stream_order_probe.py"), str(rounds)], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-3000:]
+        seen[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert seen[name]["violations"] == 0
+    assert seen["default"]["by_proxy"] == 0 and seen["async"]["by_proxy"] == seen["async"]["groups"] == 3 * rounds
+    assert seen["default"]["right"] == {"ordered": rounds, "early_read": rounds, "early_pack": rounds}, seen      # blind: every call is a full stop
+    assert seen["async"]["right"]["ordered"] == rounds, seen
+    assert seen["async"]["right"]["early_read"] == 0 and seen["async"]["right"]["early_pack"] == 0, seen
 
 
 def test_rccl_branch_with_one_communicator(mock_lib, request, tmp_path):
