@@ -24,8 +24,10 @@
 // (hipStreamWaitValue32) behind it; a proxy thread waits for the event — everything the caller queued BEFORE the call — reads the send
 // buffers THEN, moves the bytes, writes the receive buffers and releases the signal: the caller's later work on that stream sees the
 // data, work it queued on OTHER streams without an event does not wait.  A send buffer refilled too early, a receive buffer read
-// without waiting for its stream: both become wrong bytes that the parity comparison of the tests sees.  (A wait parks a hardware
-// queue: run with GPU_MAX_HW_QUEUES=8 so that the proxy's copies do not share one with a parked stream.)
+// without waiting for its stream: both become wrong bytes that the parity comparison of the tests sees
+// (stream_order_probe.py makes both mistakes on purpose).  $MOCK_RCCL_ASYNC_DELAY_US: the proxy sleeps that long before it reads the
+// send buffers — RCCL's kernels are not instant either.  A wait parks a hardware queue: run with GPU_MAX_HW_QUEUES=24 so that the proxy's
+// copies and the caller's other streams do not share one with a parked stream.
 //
 // Build: hipcc (host code only) -shared -fPIC mock_rccl.cpp -o libmockrccl.so     (tests/mock_rccl/build.py)
 

@@ -129,7 +129,7 @@ def test_rccl_branch_rank_processes_match_one_device(mock_lib, case, world, step
         assert int(q["info"][6]) == (1 if exchange == "mailbox" else 0)
 
 
-ASYNC = {"MOCK_RCCL_ASYNC": "1", "GPU_MAX_HW_QUEUES": "24", "MOCK_RCCL_TIMEOUT": "60"}
+ASYNC = {"MOCK_RCCL_ASYNC": "1", "MOCK_RCCL_ASYNC_DELAY_US": "800", "GPU_MAX_HW_QUEUES": "24", "MOCK_RCCL_TIMEOUT": "60"}
 
 
 @pytest.mark.parametrize("case,world,steps,fb,tol,mode,exchange", [
