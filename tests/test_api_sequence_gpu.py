@@ -81,11 +81,13 @@ def test_random_call_sequences_keep_slabs_and_one_device_together(seed, request)
         _same(one, dd, what)
 
 
-def test_the_same_sequences_over_the_rccl_branch():
+@pytest.mark.parametrize("timing", ["complete_in_call", "stream_ordered"])
+def test_the_same_sequences_over_the_rccl_branch(timing):
     """The sequences once more with the slabs of the handle talking through the RCCL branch (ncclCommInitAll, grouped ncclSend / ncclRecv, the per-step
     allreduce) — behind the checking double of tests/mock_rccl/, which turns a send without its receive, a size mismatch or an open group into an error:
     a second upload, forces_once between two intervals and the rest must leave both ends of every exchange in step.  A subprocess: the library binds
-    its RCCL once per process."""
+    its RCCL once per process.  `stream_ordered`: the double in its asynchronous mode ($MOCK_RCCL_ASYNC=1, calls only queue; fresh sequences) — a
+    download, a second upload or forces_once that did not wait for an exchange still in flight would read or overwrite its buffers."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -96,6 +98,8 @@ def test_the_same_sequences_over_the_rccl_branch():
     finally:
         sys.path.remove(os.path.join(here, "mock_rccl"))
     env = dict(os.environ, SPHMI_TRANSPORT="rccl", SPHMI_RCCL_LIB=mock, SPHMI_EXPECT_TRANSPORT="1", SPHMI_SEQ_SEED0=str(SEED0 + 5000), MOCK_RCCL_TIMEOUT="60")
+    if timing == "stream_ordered":
+        env.update(MOCK_RCCL_ASYNC="1", MOCK_RCCL_ASYNC_DELAY_US="500", GPU_MAX_HW_QUEUES="24", SPHMI_SEQ_SEED0=str(SEED0 + 6000))
     pr = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "random_call_sequences"],
                         env=env, capture_output=True, text=True, timeout=1200)
     assert pr.returncode == 0, pr.stdout[-3000:] + pr.stderr[-2000:]

@@ -48,6 +48,35 @@ def test_bench_line_single_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_line_of_rank_processes_over_the_rccl_branch(world):
+    """The launch the driver uses for its scaling runs — `torch.distributed.run … bench.py --gpus N`, one rank process per slab, the slabs talking
+    through the RCCL branch of the library — end to end on ONE GPU: librccl replaced by the checking double of tests/mock_rccl/ in its stream-ordered
+    mode (the real library refuses ranks that share a device).  The line must name the RCCL transport and no fallback."""
+    import torch
+    if torch.cuda.device_count() > 1:
+        pytest.skip("more than one GPU: tests/test_multi_device_gpu.py runs this launch over the real RCCL")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
+    try:
+        import build as mock_build
+        mock = mock_build.build()
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tests", "mock_rccl"))
+    env = dict(os.environ, SPHMI_TRANSPORT="rccl", SPHMI_RCCL_LIB=mock, MOCK_RCCL_ASYNC="1", MOCK_RCCL_ASYNC_DELAY_US="200", GPU_MAX_HW_QUEUES="24",
+               MOCK_RCCL_TIMEOUT="60", SPHMI_BENCH_SETUP_TIMEOUT="200", SPHMI_BENCH_RUN_TIMEOUT="300")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29551 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--dp", "0.012",
+                        "--precondition-ms", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "VIOLATION" not in r.stderr and "RCCL set-up failed" not in r.stderr, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == world and j["scaling"] == "weak"
+    par = j["config"]["parallelism"]
+    assert "RCCL (ncclSend/ncclRecv" in par and "FALLBACK" not in par and "SHARED-MEMORY" not in par and "sphmi_create_rank" in par, par
+    assert j["value"] > 0 and j["steps"] == 6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("transport", [None, "rccl"])
 def test_bench_line_two_ranks_on_one_gpu(transport):
     """transport = "rccl": RCCL is ASKED for and refuses (two ranks on one device) — every rank learns it, the run falls back to
