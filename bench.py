@@ -325,7 +325,12 @@ def parallelism_text(world, info, n_dev, how):
              "interior tiles overlap the exchange",
           0: "stream-ordered device-to-device copies between the slabs of one process (peer access over xGMI when the slabs sit on different GPUs)",
           2: f"the HOST SHARED-MEMORY transport ({world} ranks on {n_dev} GPU(s); messages staged through the host: not a valid multi-GPU measurement)"}[info.transport]
-    return base + tr + f"; {how}"
+    note = ""
+    if info.transport == 1 and os.environ.get("SPHMI_RCCL_LIB"):
+        # a line produced over a stand-in for librccl (tests/mock_rccl: several ranks on one GPU) must say so
+        note = (f"; librccl SUBSTITUTED by $SPHMI_RCCL_LIB={os.environ['SPHMI_RCCL_LIB']} ({world} ranks on {n_dev} GPU(s)): a test of the launch, "
+                "not a valid multi-GPU measurement")
+    return base + tr + f"; {how}" + note
 
 
 def self_spawn(world, argv):

@@ -73,6 +73,7 @@ def test_bench_line_of_rank_processes_over_the_rccl_branch(world):
     assert KEYS <= set(j) and j["n_gpus"] == world and j["scaling"] == "weak"
     par = j["config"]["parallelism"]
     assert "RCCL (ncclSend/ncclRecv" in par and "FALLBACK" not in par and "SHARED-MEMORY" not in par and "sphmi_create_rank" in par, par
+    assert "librccl SUBSTITUTED" in par and "not a valid multi-GPU measurement" in par, par        # the line owns up to the stand-in
     assert j["value"] > 0 and j["steps"] == 6
 
 
