@@ -205,6 +205,41 @@ def test_error_paths(dam_break_2d):
     assert ei.value.status == ERR_DOMAIN
 
 
+@pytest.mark.parametrize("slabs", [1, 2])
+def test_calls_out_of_order_are_refused_not_run(dam_break_2d, slabs):
+    """SPHMI_ERR_STATE (include/sphmi.h:50): every entry point that needs particles says so when there are none yet — status 5 and a text that names the
+    call, never a kernel launched on empty arrays — and the handle is still good afterwards: the upload that was missing makes all of them work.  One-device
+    and two-slab handles."""
+    from sphexample_amd._abi import ERR_STATE
+    from sphexample_amd.engine import Engine, make_engine
+    p, s = dam_break_2d
+    cfg = make_config(len(p), s.SimConstants, s.SimKernel, s.SimMetaData, s.SimViscosity, s.SimDensityDiffusion, device_float_bytes=8)
+    if slabs > 1:
+        cfg.n_devices = slabs
+        for k in range(slabs):
+            cfg.devices[k] = 0
+    eng = Engine(cfg)
+    calls = {"sphmi_advance": lambda: eng.advance(1.0, max_steps=1), "sphmi_download": lambda: eng.download(("ID",)),
+             "sphmi_forces_once": lambda: eng.forces_once(), "sphmi_download_permutation": lambda: eng.download_permutation(),
+             "sphmi_download_kernel_output": lambda: eng.kernel_output()}
+    for name, call in calls.items():
+        with pytest.raises(SphmiError) as ei:
+            call()
+        assert ei.value.status == ERR_STATE, (name, ei.value.status, str(ei.value))
+        assert name in str(ei.value), (name, str(ei.value))
+    eng.upload_particles(p)
+    with pytest.raises(SphmiError) as ei:                  # uploaded now, but the handle does not store the kernel sums
+        eng.kernel_output()
+    assert ei.value.status == ERR_STATE and "kernel_output = STORE" in str(ei.value)
+    pr = eng.advance(1e9, max_steps=3)
+    ref = make_engine(p, s, device_float_bytes=8)
+    pr2 = ref.advance(1e9, max_steps=3)
+    assert pr.iteration == pr2.iteration == 3 and pr.total_time == pytest.approx(pr2.total_time, rel=1e-12)
+    a, b = by_id(eng.download()), by_id(ref.download())
+    assert relmax(a["Density"], b["Density"]) < 1e-9 and relmax(a["Position"], b["Position"]) < 1e-9
+    assert sorted(eng.download_permutation().tolist()) == list(range(len(p)))
+
+
 @pytest.mark.parametrize("fb,tol", [(8, 1e-10), (4, 2e-4)])
 def test_eta_squared_zero(dam_break_2d, fb, tol):
     """η² = 0 is a legal SPHKernelInstance (src/SPHKernels.jl:41: η² ≥ 0): the reference's pair loop never visits i == j, the engine's accept masks hold the self
