@@ -678,7 +678,12 @@ struct MultiEngine final : EngineBase {
         for (auto& r : R) {
             r.has_left = r.rank > 0; r.has_right = r.rank < world - 1;
             HC(hipSetDevice(r.device));
-            HC(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+            {   // $SPHMI_SIDE_PRIORITY=1: the exchange chain (halo -> unpack -> slab-edge tiles) is dispatched ahead of the interior tiles it runs beside
+                const char* sp = getenv("SPHMI_SIDE_PRIORITY");
+                int lo = 0, hi = 0;
+                if (sp && atoi(sp) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) HC(hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, hi));
+                else HC(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+            }
             HC(hipEventCreateWithFlags(&r.ev_pack, hipEventDisableTiming));
             HC(hipEventCreateWithFlags(&r.ev_edge, hipEventDisableTiming));
             HC(hipEventCreateWithFlags(&r.ev_red, hipEventDisableTiming));
